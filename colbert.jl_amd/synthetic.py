@@ -1,0 +1,114 @@
+"""Deterministic synthetic corpora for parity tests and bench.py.
+
+Search-only corpora are generated directly in compressed form, with the index layout of the
+reference's Searcher (src/searching.jl:1-16): centroids (dim,K) fp32, bucket_weights fp32[2^nbits],
+codes UInt32[n_emb] (1-based), residuals UInt8 (dim/8*nbits, n_emb), doclens Int64[n_docs],
+ivf Int64[n_emb] (1-based embedding ids grouped by centroid, ascending inside a list -- what
+`_build_ivf`'s stable sortperm produces, collection_indexer.jl:349-353) and ivf_lengths Int64[K].
+Arrays are numpy, column-major where the reference's are matrices.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# values logged by the reference's README run (README.md:100)
+README_BUCKET_CUTOFFS = np.array([-0.021662371, -0.00015685707, 0.020033525], dtype=np.float32)
+README_BUCKET_WEIGHTS = np.array([-0.041035336, -0.009812315, 0.008938393, 0.039779153], dtype=np.float32)
+
+
+def num_partitions_for(n_docs: int, avg_doclen: float) -> int:
+    """The reference's own sizing rule (collection_indexer.jl:122-126), uncapped."""
+    est = np.float32(n_docs) * np.float32(avg_doclen)
+    return int(2 ** math.floor(math.log2(float(np.float32(16.0) * np.sqrt(est)))))
+
+
+def build_ivf(codes: np.ndarray, K: int):
+    """_build_ivf (collection_indexer.jl:349-353) on the host: stable sort of the codes."""
+    ivf = np.argsort(codes, kind="stable").astype(np.int64) + 1
+    lens = np.bincount(codes, minlength=K + 1)[1:].astype(np.int64)
+    return ivf, lens
+
+
+def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbits: int = 2,
+               doclen_mean: float = 80.0, doclen_std: float = 16.0, constant_doclen: bool = False,
+               topical: bool = True):
+    """A compressed index of `n_docs` passages.  `topical`: each passage draws 80 % of its tokens
+    from the 16 centroids nearest (by id, a cheap stand-in for similarity) to 4 per-passage topic
+    centroids, the rest uniformly -- uniform codes are the worst case for candidate counts."""
+    rng = np.random.default_rng(seed)
+    if constant_doclen:
+        doclens = np.full(n_docs, int(doclen_mean), dtype=np.int64)
+    else:
+        doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, 220).astype(np.int64)
+    n_emb = int(doclens.sum())
+    if K is None:
+        K = num_partitions_for(n_docs, float(doclens.mean()))
+    cent = rng.standard_normal((K, dim), dtype=np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cent *= rng.uniform(0.6, 1.0, size=(K, 1)).astype(np.float32)   # k-means means are sub-unit-norm
+    centroids = np.asfortranarray(cent.T)                            # (dim, K) column-major
+    if topical:
+        doc_of = np.repeat(np.arange(n_docs), doclens)
+        topics = rng.integers(0, K, size=(n_docs, 4))
+        pick = rng.integers(0, 4, size=n_emb)
+        near = (topics[doc_of, pick] + rng.integers(-8, 8, size=n_emb)) % K
+        uni = rng.integers(0, K, size=n_emb)
+        codes = np.where(rng.random(n_emb) < 0.8, near, uni).astype(np.uint32) + 1
+    else:
+        codes = rng.integers(1, K + 1, size=n_emb, dtype=np.uint32)
+    rows = dim // 8 * nbits
+    residuals = np.asfortranarray(
+        rng.integers(0, 256, size=(n_emb, rows), dtype=np.uint8).T)   # (rows, n_emb) column-major
+    if nbits == 2:
+        weights = README_BUCKET_WEIGHTS.copy()
+        cutoffs = README_BUCKET_CUTOFFS.copy()
+    else:
+        weights = np.sort(rng.normal(0, 0.03, 1 << nbits).astype(np.float32))
+        cutoffs = ((weights[1:] + weights[:-1]) / 2).astype(np.float32)
+    ivf, ivf_lengths = build_ivf(codes, K)
+    return {"dim": dim, "nbits": nbits, "centroids": centroids, "bucket_weights": weights,
+            "bucket_cutoffs": cutoffs, "doclens": doclens, "codes": codes, "residuals": residuals,
+            "ivf": ivf, "ivf_lengths": ivf_lengths}
+
+
+def decompress_numpy(index: dict, eids0: np.ndarray) -> np.ndarray:
+    """fp64-accurate decompression of a few embeddings (0-based ids) -- used only to build queries."""
+    dim, nbits = index["dim"], index["nbits"]
+    res = index["residuals"][:, eids0]
+    per = 8 // nbits
+    idx = np.stack([(res >> (nbits * i)) & ((1 << nbits) - 1) for i in range(per)], axis=1).reshape(dim, -1)
+    x = index["centroids"][:, index["codes"][eids0].astype(np.int64) - 1] + index["bucket_weights"][idx]
+    return x / (np.linalg.norm(x, axis=0, keepdims=True) + np.finfo(np.float32).eps)
+
+
+def make_queries(index: dict, seed: int, n_queries: int, T: int = 32, noise: float = 0.3) -> np.ndarray:
+    """(dim, T, n_queries) unit vectors: decompressed tokens of a random passage plus Gaussian
+    noise, renormalised (gives realistic score gaps)."""
+    rng = np.random.default_rng(seed)
+    dim = index["dim"]
+    off = np.concatenate([[0], np.cumsum(index["doclens"])])
+    out = np.empty((dim, T, n_queries), dtype=np.float32, order="F")
+    docs = rng.integers(0, index["doclens"].size, size=n_queries)
+    for j, p in enumerate(docs):
+        eids = off[p] + rng.integers(0, index["doclens"][p], size=T)
+        q = decompress_numpy(index, eids) + noise * rng.standard_normal((dim, T)) / math.sqrt(dim)
+        q /= np.linalg.norm(q, axis=0, keepdims=True)
+        out[:, :, j] = q.astype(np.float32)
+    return out
+
+
+def make_embeddings(seed: int, n_docs: int, dim: int = 128, doclen_mean: float = 80.0,
+                    doclen_std: float = 16.0, n_components: int = 4096):
+    """Config-2 style input for the index build: unit vectors from a Gaussian mixture
+    (centre + 0.25 * Gaussian, normalised).  Returns (embs (dim, n_emb) col-major, doclens)."""
+    rng = np.random.default_rng(seed)
+    doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, 220).astype(np.int64)
+    n_emb = int(doclens.sum())
+    centres = rng.standard_normal((n_components, dim), dtype=np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    comp = rng.integers(0, n_components, size=n_emb)
+    x = centres[comp] + 0.25 * rng.standard_normal((n_emb, dim), dtype=np.float32) / np.float32(math.sqrt(dim)) * np.float32(math.sqrt(dim) / 4)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.asfortranarray(x.T.astype(np.float32)), doclens
