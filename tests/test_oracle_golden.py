@@ -345,7 +345,7 @@ def test_setup_sizing(oracle, kats):
             assert np.float32(plan["num_embeddings_est"]) == np.float32(c["num_embeddings_est"])
     plan = oracle.setup(100, 50.0, 37, None, 2)                   # test/indexing/collection_indexer.jl:38-83
     assert plan["num_partitions"] == 37 and plan["chunksize"] == 51 and plan["num_chunks"] == 2
-    assert oracle.num_sampled_pids(10) == 10 and oracle.num_sampled_pids(141431) == 65916
+    assert oracle.num_sampled_pids(10) == 10 and oracle.num_sampled_pids(141431) == 65915
     assert oracle.heldout_size(10 ** 7) == 50000 and oracle.heldout_size(3) == 1
 
 
