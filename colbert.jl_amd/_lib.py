@@ -1,0 +1,103 @@
+"""ctypes binding of libcolbert_hip.so (include/colbert_hip.h).  There is no CPU fallback: if the
+library is missing, or there is no GPU, calls raise -- loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcolbert_hip.so")
+HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "colbert_hip.h"))
+
+
+class ColBERTError(RuntimeError):
+    code = -1
+
+
+class DimensionMismatch(ColBERTError):
+    code = 1
+
+
+class DomainError(ColBERTError):
+    code = 2
+
+
+class BoundsError(ColBERTError):
+    code = 3
+
+
+class ArgumentError(ColBERTError):
+    code = 4
+
+
+class HipError(ColBERTError):
+    code = 10
+
+
+class Unsupported(ColBERTError):
+    code = 11
+
+
+class OutOfMemory(ColBERTError):
+    code = 12
+
+
+_ERRORS = {c.code: c for c in (DimensionMismatch, DomainError, BoundsError, ArgumentError, HipError,
+                               Unsupported, OutOfMemory)}
+
+
+def build(force: bool = False, jobs: int = 3) -> str:
+    """Compile libcolbert_hip.so for gfx950 with hipcc (colbert.jl_amd/csrc/Makefile)."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/colbert_hip.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(clb_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ColBERTError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        l.clb_version.restype = C.c_char_p
+        l.clb_last_error.restype = C.c_char_p
+        l.clb_searcher_device_bytes.restype = C.c_int64
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().clb_last_error().decode(errors="replace")
+        raise _ERRORS.get(rc, ColBERTError)(msg or f"libcolbert_hip error {rc}")
+
+
+def fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def colmajor(a, dtype) -> np.ndarray:
+    """A numpy array laid out like the Julia Array of the same shape (column-major, dense)."""
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+i64 = C.c_int64

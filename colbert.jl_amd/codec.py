@@ -1,0 +1,151 @@
+"""Host-side mirrors of the reference's codec / index-build functions over the C ABI.
+Same names and argument meaning as src/indexing/codecs/residual.jl, src/utils.jl and
+src/indexing/collection_indexer.jl; arrays keep the Julia shapes (column-major)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from ._lib import check, colmajor, fptr, i64, lib
+
+
+def _normalize_array(X, dims: int = 1, device: int = 0):
+    """_normalize_array!(X, dims=1)  (src/utils.jl:320-325); returns the normalised copy."""
+    if dims != 1:
+        raise NotImplementedError("only dims=1 runs on the device")
+    X = colmajor(X, np.float32).copy(order="F")
+    dim = X.shape[0]
+    n = X.size // max(dim, 1)
+    check(lib().clb_normalize_columns(device, fptr(X), i64(dim), i64(n)))
+    return X
+
+
+def compress_into_codes(centroids, embs, device: int = 0, n_codes=None):
+    """compress_into_codes!  (residual.jl:67-81)"""
+    c = colmajor(centroids, np.float32); x = colmajor(embs, np.float32)
+    n = x.shape[1]
+    codes = np.zeros(n if n_codes is None else n_codes, dtype=np.uint32)
+    check(lib().clb_compress_into_codes(device, fptr(codes), i64(codes.size), fptr(c), i64(c.shape[0]),
+                                        i64(c.shape[1]), fptr(x), i64(n)))
+    return codes
+
+
+def compress(centroids, bucket_cutoffs, dim: int, nbits: int, embs, device: int = 0):
+    """compress  (residual.jl:586-604) -> (codes UInt32[n], residuals UInt8 (dim/8*nbits, n))"""
+    c = colmajor(centroids, np.float32); cu = np.ascontiguousarray(bucket_cutoffs, dtype=np.float32)
+    x = colmajor(embs, np.float32)
+    n = x.shape[1]
+    codes = np.zeros(n, dtype=np.uint32)
+    res = np.zeros((max(dim // 8, 0) * nbits, n), dtype=np.uint8, order="F")
+    check(lib().clb_compress(device, fptr(c), i64(c.shape[1]), fptr(cu), i64(cu.size), i64(dim), C.c_int(nbits),
+                             fptr(x), i64(n), fptr(codes), fptr(res)))
+    return codes, res
+
+
+def decompress(dim: int, nbits: int, centroids, bucket_weights, codes, residuals, device: int = 0):
+    """decompress  (residual.jl:759-784) -> Float32 (dim, n)"""
+    c = colmajor(centroids, np.float32); w = np.ascontiguousarray(bucket_weights, dtype=np.float32)
+    co = np.ascontiguousarray(codes, dtype=np.uint32); r = colmajor(residuals, np.uint8)
+    out = np.zeros((dim, co.size), dtype=np.float32, order="F")
+    check(lib().clb_decompress(device, i64(dim), C.c_int(nbits), fptr(c), i64(c.shape[1]), fptr(w), i64(w.size),
+                               fptr(co), i64(co.size), fptr(r), i64(r.shape[0]), i64(r.shape[1]), fptr(out)))
+    return out
+
+
+def maxsim(Q, D, pids, doclens, device: int = 0):
+    """maxsim  (src/search/ranking.jl:69-86)"""
+    q = colmajor(Q, np.float32); d = colmajor(D, np.float32)
+    p = np.ascontiguousarray(pids, dtype=np.int64); dl = np.ascontiguousarray(doclens, dtype=np.int64)
+    scores = np.zeros(p.size, dtype=np.float32)
+    check(lib().clb_maxsim(device, fptr(q), i64(q.shape[0]), i64(q.shape[1]), fptr(d),
+                           i64(d.shape[1] if d.ndim == 2 else 0), fptr(p), i64(p.size), fptr(dl), i64(dl.size),
+                           fptr(scores)))
+    return scores
+
+
+def kmeans(data, init_centroids, max_iters: int = 10, tol: float = 1e-4, point_bsize: int = 1000,
+           device: int = 0):
+    """kmeans_gpu_onehot!  (src/utils.jl:253-318) with the initial centroids injected.
+    Returns (centroids, assignments Int32 1-based, iterations executed)."""
+    x = colmajor(data, np.float32); c = colmajor(init_centroids, np.float32).copy(order="F")
+    dim, n = x.shape
+    assign = np.zeros(n, dtype=np.int32)
+    iters = i64(0)
+    check(lib().clb_kmeans(device, fptr(x), i64(dim), i64(n), fptr(c), i64(c.shape[1]), i64(max_iters),
+                           C.c_float(tol), i64(point_bsize), fptr(assign), C.byref(iters)))
+    return c, assign, iters.value
+
+
+def compute_avg_residuals(nbits: int, centroids, heldout, device: int = 0, n_codes=None):
+    """_compute_avg_residuals!  (collection_indexer.jl:177-195) -> (cutoffs, weights, avg_residual, codes)"""
+    c = colmajor(centroids, np.float32); h = colmajor(heldout, np.float32)
+    n = h.shape[1]
+    codes = np.zeros(n if n_codes is None else n_codes, dtype=np.uint32)
+    cut = np.zeros((1 << nbits) - 1, dtype=np.float32); w = np.zeros(1 << nbits, dtype=np.float32)
+    avg = C.c_float(0)
+    check(lib().clb_compute_avg_residuals(device, C.c_int(nbits), fptr(c), i64(c.shape[0]), i64(c.shape[1]),
+                                          fptr(h), i64(n), fptr(codes), i64(codes.size), fptr(cut), fptr(w),
+                                          C.byref(avg)))
+    return cut, w, np.float32(avg.value), codes
+
+
+def build_ivf(codes, num_partitions: int, device: int = 0):
+    """_build_ivf  (collection_indexer.jl:349-353) -> (ivf Int64[n] 1-based, ivf_lengths Int64[K])"""
+    co = np.ascontiguousarray(codes, dtype=np.uint32)
+    ivf = np.zeros(co.size, dtype=np.int64); lens = np.zeros(num_partitions, dtype=np.int64)
+    check(lib().clb_build_ivf(device, fptr(co), i64(co.size), i64(num_partitions), fptr(ivf), fptr(lens)))
+    return ivf, lens
+
+
+def doc_epilogue(D, integer_ids, skiplist, device: int = 0):
+    """_doc_embeddings_and_doclens after the encoder forward  (checkpoint.jl:30-51)"""
+    Dm = colmajor(D, np.float32)
+    dim, L, N = Dm.shape
+    ids = colmajor(integer_ids, np.int32); sk = np.ascontiguousarray(skiplist, dtype=np.int64)
+    out = np.zeros((dim, max(L * N, 1)), dtype=np.float32, order="F")
+    doclens = np.zeros(N, dtype=np.int64)
+    n_out = i64(0)
+    check(lib().clb_doc_epilogue(device, fptr(Dm), i64(dim), i64(L), i64(N), fptr(ids), fptr(sk), i64(sk.size),
+                                 fptr(out), fptr(doclens), C.byref(n_out)))
+    return np.asfortranarray(out[:, : n_out.value]), doclens
+
+
+def query_epilogue(Q, integer_ids, skiplist, device: int = 0):
+    """_query_embeddings after the encoder forward  (checkpoint.jl:61-69)"""
+    Qm = colmajor(Q, np.float32).copy(order="F")
+    dim, L, N = Qm.shape
+    ids = colmajor(integer_ids, np.int32); sk = np.ascontiguousarray(skiplist, dtype=np.int64)
+    check(lib().clb_query_epilogue(device, fptr(Qm), i64(dim), i64(L), i64(N), fptr(ids), fptr(sk), i64(sk.size)))
+    return Qm
+
+
+# ---- host-only planning helpers (collection_indexer.jl:17-24, 81-91, 115-139, 342-347) --------------
+def num_sampled_pids(num_documents: int) -> int:
+    v = 16 * math.sqrt(120 * num_documents)
+    return int(min(1 + math.floor(v), num_documents))
+
+
+def heldout_size(num_sample_embs: int, heldout_fraction: float = 0.05) -> int:
+    prod = np.float32(heldout_fraction) * np.float32(num_sample_embs)
+    return int(max(1, math.floor(min(np.float32(50000), prod))))
+
+
+def setup(num_documents: int, avg_doclen_est: float, num_clustering_embs: int, chunksize, nranks: int) -> dict:
+    if chunksize is None:
+        chunksize = min(25000, 1 + num_documents // nranks)
+    num_chunks = -(-num_documents // chunksize)
+    est = np.float32(num_documents) * np.float32(avg_doclen_est)
+    parts = math.floor(2 ** math.floor(math.log2(float(np.float32(16) * np.sqrt(est)))))
+    return {"chunksize": int(chunksize), "num_chunks": int(num_chunks),
+            "num_partitions": int(min(num_clustering_embs, parts)), "num_documents": int(num_documents),
+            "num_embeddings_est": float(est), "avg_doclen_est": float(np.float32(avg_doclen_est))}
+
+
+def collect_embedding_id_offset(chunk_emb_counts):
+    cnt = list(chunk_emb_counts)
+    if not cnt:
+        return 0, np.zeros(1, dtype=np.int64)
+    off = np.cumsum([1] + cnt[:-1]).astype(np.int64)
+    return int(sum(cnt)), off

@@ -1,0 +1,376 @@
+// codec.hip -- stand-alone codec / index-build / encoder-epilogue entry points of the C ABI
+// (include/colbert_hip.h).  Host buffers in, host buffers out; all compute on the selected device.
+#include <algorithm>
+#include <cmath>
+
+#include "codec_kernels.hpp"
+#include "sort.hpp"
+
+using namespace clb;
+
+namespace {
+
+inline int blocks_for(int64_t n, int bs = 256) { return (int)std::max<int64_t>(1, (n + bs - 1) / bs); }
+
+struct Stream {
+    hipStream_t st = nullptr;
+    int init() {
+        CLB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return CLB_OK;
+    }
+    ~Stream() {
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+// device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means
+template <int MODE>
+int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim, int K, const float* dX, int64_t n,
+                      uint32_t* dOut) {
+    if (n == 0) return CLB_OK;
+    if (dim == kDim) {
+        const int64_t ptiles = (n + 31) / 32;
+        hipLaunchKernelGGL(nearest_centroid_mfma_kernel<MODE>, dim3((unsigned)((ptiles + 1) / 2)), dim3(128),
+                           2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX, n, dOut);
+    } else {
+        hipLaunchKernelGGL(nearest_centroid_generic_kernel<MODE>, dim3(blocks_for(n, 64)), dim3(64), 0, st, dC, dc2,
+                           dim, K, dX, n, dOut);
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+// Statistics.quantile (type 7) on a sorted device array: reads the two neighbours it needs
+int quantile7_device(const float* d_sorted, int64_t n, double p, float* out) {
+    const double m = 1.0 + p * (1.0 - 1.0 - 1.0);
+    const double aleph = (double)n * p + m;
+    int64_t j = (int64_t)std::trunc(aleph);
+    j = std::min<int64_t>(std::max<int64_t>(j, 1), n - 1);
+    double g = aleph - (double)j;
+    g = std::min(std::max(g, 0.0), 1.0);
+    float ab[2];
+    if (n == 1) {
+        CLB_HIP(hipMemcpy(ab, d_sorted, sizeof(float), hipMemcpyDeviceToHost));
+        ab[1] = ab[0];
+    } else {
+        CLB_HIP(hipMemcpy(ab, d_sorted + (j - 1), 2 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    const float diff = ab[1] - ab[0];
+    *out = (float)((double)ab[0] + g * (double)diff);
+    return CLB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clb_normalize_columns(int device, float* X, int64_t dim, int64_t n) {
+    if (dim < 0 || n < 0) return fail(CLB_EARGUMENT, "negative size");
+    CLB_TRY(use_device(device));
+    if (dim == 0 || n == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    DevBuf d;
+    CLB_TRY(upload(d, X, sizeof(float) * dim * n, s.st));
+    hipLaunchKernelGGL(normalize_columns_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, s.st, d.as<float>(), (int)dim, n);
+    CLB_HIP(hipMemcpyAsync(X, d.p, sizeof(float) * dim * n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_decompress(int device, int64_t dim, int nbits, const float* centroids, int64_t K,
+                   const float* bucket_weights, int64_t n_weights, const uint32_t* codes, int64_t n_codes,
+                   const uint8_t* residuals, int64_t res_rows, int64_t res_cols, float* out) {
+    // argument contract of decompress / decompress_residuals (residual.jl:701-706, 763-768)
+    if (n_codes != res_cols) return fail(CLB_EDOMAIN, "The number of codes should be equal to the number of residual embeddings!");
+    for (int64_t e = 0; e < n_codes; ++e)
+        if (codes[e] < 1 || (int64_t)codes[e] > K) return fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!");
+    if (dim % 8 != 0) return fail(CLB_EDOMAIN, "dim should be a multiple of 8!");
+    if (nbits < 1 || res_rows != dim / 8 * nbits) return fail(CLB_EDOMAIN, "The dimension each residual in binary_residuals should be (dim / 8) * nbits!");
+    if (n_weights != ((int64_t)1 << nbits)) return fail(CLB_EDOMAIN, "bucket_weights should have length 2^nbits!");
+    if (nbits != 1 && nbits != 2 && nbits != 4 && nbits != 8)
+        return fail(CLB_EUNSUPPORTED, "the HIP codec supports nbits in {1,2,4,8} (got %d)", nbits);
+    CLB_TRY(use_device(device));
+    if (n_codes == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    DevBuf dC, dW, dCodes, dRes, dOut;
+    CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(upload(dW, bucket_weights, sizeof(float) * n_weights, s.st));
+    CLB_TRY(upload(dCodes, codes, sizeof(uint32_t) * n_codes, s.st));
+    CLB_TRY(upload(dRes, residuals, (size_t)res_rows * res_cols, s.st));
+    CLB_TRY(dOut.alloc(sizeof(float) * dim * n_codes));
+    if (dim == kDim && nbits <= 4) {
+        const int grid = (int)std::min<int64_t>(2048, (n_codes + 63) / 64);
+        switch (nbits) {
+            case 1: hipLaunchKernelGGL(decompress_dim128_kernel<1>, dim3(grid), dim3(256), 0, s.st, dC.as<float>(), dW.as<float>(), dCodes.as<uint32_t>(), dRes.as<uint8_t>(), n_codes, dOut.as<float>()); break;
+            case 2: hipLaunchKernelGGL(decompress_dim128_kernel<2>, dim3(grid), dim3(256), 0, s.st, dC.as<float>(), dW.as<float>(), dCodes.as<uint32_t>(), dRes.as<uint8_t>(), n_codes, dOut.as<float>()); break;
+            default: hipLaunchKernelGGL(decompress_dim128_kernel<4>, dim3(grid), dim3(256), 0, s.st, dC.as<float>(), dW.as<float>(), dCodes.as<uint32_t>(), dRes.as<uint8_t>(), n_codes, dOut.as<float>()); break;
+        }
+    } else {
+        hipLaunchKernelGGL(decompress_generic_kernel, dim3(blocks_for(n_codes, 64)), dim3(64), 0, s.st, (int)dim, nbits,
+                           dC.as<float>(), dW.as<float>(), dCodes.as<uint32_t>(), dRes.as<uint8_t>(), n_codes, dOut.as<float>());
+    }
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(out, dOut.p, sizeof(float) * dim * n_codes, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_maxsim(int device, const float* Q, int64_t dim, int64_t T, const float* D, int64_t n_D,
+               const int64_t* pids, int64_t n_pids, const int64_t* doclens, int64_t n_docs, float* scores) {
+    std::vector<int64_t> off((size_t)n_pids + 1, 0);
+    for (int64_t j = 0; j < n_pids; ++j) {
+        if (pids[j] < 1 || pids[j] > n_docs) return fail(CLB_EBOUNDS, "pid %lld outside 1..%lld", (long long)pids[j], (long long)n_docs);
+        off[j + 1] = off[j] + doclens[pids[j] - 1];
+    }
+    if (off[n_pids] != n_D)  // ranking.jl:71-74
+        return fail(CLB_EDIMENSION, "The total number of embeddings for pids does not match with the dimension of D!");
+    for (int64_t j = 0; j < n_pids; ++j)
+        if (off[j + 1] == off[j]) return fail(CLB_EARGUMENT, "reducing over an empty collection is not allowed (passage %lld has no embeddings)", (long long)pids[j]);
+    CLB_TRY(use_device(device));
+    if (n_pids == 0) return CLB_OK;
+    if (T > 1024) return fail(CLB_EUNSUPPORTED, "T > 1024");
+    Stream s; CLB_TRY(s.init());
+    DevBuf dQ, dD, dOff, dS;
+    CLB_TRY(upload(dQ, Q, sizeof(float) * dim * T, s.st));
+    CLB_TRY(upload(dD, D, sizeof(float) * dim * n_D, s.st));
+    CLB_TRY(upload(dOff, off.data(), sizeof(int64_t) * off.size(), s.st));
+    CLB_TRY(dS.alloc(sizeof(float) * n_pids));
+    const int bs = (int)std::min<int64_t>(256, (T + 63) / 64 * 64);
+    hipLaunchKernelGGL(maxsim_generic_kernel, dim3((unsigned)n_pids), dim3(bs), sizeof(float) * T, s.st, dQ.as<float>(),
+                       (int)dim, (int)T, dD.as<float>(), dOff.as<int64_t>(), dS.as<float>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(scores, dS.p, sizeof(float) * n_pids, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_compress_into_codes(int device, uint32_t* codes, int64_t n_codes, const float* centroids, int64_t dim,
+                            int64_t K, const float* embs, int64_t n) {
+    if (n_codes != n) return fail(CLB_EDIMENSION, "length(codes) must be equal to the number of embeddings!");
+    if (K < 1 && n > 0) return fail(CLB_EARGUMENT, "no centroids");
+    CLB_TRY(use_device(device));
+    if (n == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    DevBuf dC, dX, dOut;
+    CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(upload(dX, embs, sizeof(float) * dim * n, s.st));
+    CLB_TRY(dOut.alloc(sizeof(uint32_t) * n));
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dOut.as<uint32_t>()));
+    CLB_HIP(hipMemcpyAsync(codes, dOut.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_compress(int device, const float* centroids, int64_t K, const float* bucket_cutoffs, int64_t n_cutoffs,
+                 int64_t dim, int nbits, const float* embs, int64_t n, uint32_t* codes, uint8_t* residuals) {
+    if (dim % 8 != 0) return fail(CLB_EDOMAIN, "dims should be a multiple of 8!");
+    if (nbits < 1 || nbits > 16 || n_cutoffs != ((int64_t)1 << nbits) - 1) return fail(CLB_EDOMAIN, "length(bucket_cutoffs) should be 2^nbits - 1!");
+    if (K < 1 && n > 0) return fail(CLB_EARGUMENT, "no centroids");
+    CLB_TRY(use_device(device));
+    if (n == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    const int64_t rows = dim / 8 * nbits;
+    DevBuf dC, dX, dCut, dCodes, dRes;
+    CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(upload(dX, embs, sizeof(float) * dim * n, s.st));
+    CLB_TRY(upload(dCut, bucket_cutoffs, sizeof(float) * std::max<int64_t>(n_cutoffs, 1), s.st));
+    CLB_TRY(dCodes.alloc(sizeof(uint32_t) * n));
+    CLB_TRY(dRes.alloc((size_t)rows * n));
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>()));
+    hipLaunchKernelGGL(pack_residuals_kernel, dim3(blocks_for(n * rows)), dim3(256), 0, s.st, dC.as<float>(),
+                       dCut.as<float>(), (int)n_cutoffs, (int)dim, nbits, dX.as<float>(), dCodes.as<uint32_t>(), n,
+                       dRes.as<uint8_t>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(codes, dCodes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipMemcpyAsync(residuals, dRes.p, (size_t)rows * n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* centroids, int64_t K,
+               int64_t max_iters, float tol, int64_t point_bsize, int32_t* assignments, int64_t* iters_done) {
+    if (K < 1 || dim < 1 || point_bsize < 1) return fail(CLB_EDIMENSION, "size(centroids, 2) must be k!");
+    if (n >= (int64_t)0xffffffffll) return fail(CLB_EUNSUPPORTED, "n too large");
+    CLB_TRY(use_device(device));
+    Stream s; CLB_TRY(s.init());
+    DevBuf dX, dC, dNew, dC2, dAssign, dOrder, dIota, dKeys, dCounts, dStart, dDelta, dErr, dCnt32;
+    CLB_TRY(upload(dX, data, sizeof(float) * dim * std::max<int64_t>(n, 1), s.st));
+    CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(dNew.alloc(sizeof(float) * dim * K));
+    CLB_TRY(dC2.alloc(sizeof(float) * K));
+    CLB_TRY(dAssign.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dOrder.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dIota.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dKeys.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dCounts.alloc(sizeof(uint32_t) * (K + 1)));
+    CLB_TRY(dStart.alloc(sizeof(uint32_t) * (K + 2)));
+    CLB_TRY(dCnt32.alloc(sizeof(int) * K));
+    CLB_TRY(dDelta.alloc(sizeof(unsigned int)));
+    CLB_TRY(dErr.alloc(sizeof(int)));
+    if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dIota.as<uint32_t>(), n);
+    int end_bit = 1;
+    while (((int64_t)1 << end_bit) <= K) ++end_bit;
+    int64_t it = 0;
+    for (it = 0; it < max_iters; ++it) {
+        hipLaunchKernelGGL(centroid_sumsq_kernel, dim3(blocks_for(K, 64)), dim3(64), 0, s.st, dC.as<float>(), (int)dim,
+                           (int)K, dC2.as<float>());
+        CLB_TRY(nearest_centroids<1>(s.st, dC.as<float>(), dC2.as<float>(), (int)dim, (int)K, dX.as<float>(), n,
+                                     dAssign.as<uint32_t>()));
+        // group the points by cluster, ascending point id inside a cluster (stable)
+        CLB_HIP(hipMemsetAsync(dCounts.p, 0, sizeof(uint32_t) * (K + 1), s.st));
+        CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), s.st));
+        if (n > 0) {
+            hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dAssign.as<uint32_t>(), n,
+                               (uint32_t)K, dCounts.as<unsigned int>(), dErr.as<int>());
+            CLB_TRY(sort_pairs_u32(dAssign.as<uint32_t>(), dKeys.as<uint32_t>(), dIota.as<uint32_t>(),
+                                   dOrder.as<uint32_t>(), (size_t)n, end_bit, s.st));
+        }
+        CLB_TRY(exclusive_scan_u32(dCounts.as<uint32_t>(), dStart.as<uint32_t>(), (size_t)K, s.st));
+        hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, s.st, dX.as<float>(),
+                           (int)dim, dOrder.as<uint32_t>(), dStart.as<uint32_t>(), (int)K, (int)point_bsize,
+                           dNew.as<float>(), dCnt32.as<int>());
+        CLB_HIP(hipMemsetAsync(dDelta.p, 0, sizeof(unsigned int), s.st));
+        hipLaunchKernelGGL(kmeans_finalize_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, s.st, dNew.as<float>(),
+                           dCnt32.as<int>(), dC.as<float>(), (int)dim, (int)K, dDelta.as<unsigned int>());
+        CLB_HIP(hipGetLastError());
+        unsigned int bits = 0;
+        CLB_HIP(hipMemcpyAsync(&bits, dDelta.p, sizeof bits, hipMemcpyDeviceToHost, s.st));
+        CLB_HIP(hipStreamSynchronize(s.st));
+        float delta;
+        memcpy(&delta, &bits, sizeof delta);
+        if (delta < tol) { ++it; break; }  // utils.jl:308-311: the previous centroids stay
+        CLB_HIP(hipMemcpyAsync(dC.p, dNew.p, sizeof(float) * dim * K, hipMemcpyDeviceToDevice, s.st));
+    }
+    if (iters_done) *iters_done = it;
+    CLB_HIP(hipMemcpyAsync(centroids, dC.p, sizeof(float) * dim * K, hipMemcpyDeviceToHost, s.st));
+    if (n > 0 && max_iters > 0)
+        CLB_HIP(hipMemcpyAsync(assignments, dAssign.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int64_t dim, int64_t K,
+                              const float* heldout, int64_t n, uint32_t* codes, int64_t n_codes,
+                              float* bucket_cutoffs, float* bucket_weights, float* avg_residual) {
+    if (n_codes != n) return fail(CLB_EDIMENSION, "length(codes) must be equal to the number of embeddings in heldout!");
+    if (n < 1 || dim < 1) return fail(CLB_EARGUMENT, "empty heldout set");
+    if (nbits < 1 || nbits > 16) return fail(CLB_EDOMAIN, "nbits out of range");
+    CLB_TRY(use_device(device));
+    Stream s; CLB_TRY(s.init());
+    DevBuf dC, dX, dCodes, dRes, dSorted, dAbs;
+    CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(upload(dX, heldout, sizeof(float) * dim * n, s.st));
+    CLB_TRY(dCodes.alloc(sizeof(uint32_t) * n));
+    CLB_TRY(dRes.alloc(sizeof(float) * dim * n));
+    CLB_TRY(dSorted.alloc(sizeof(float) * dim * n));
+    CLB_TRY(dAbs.alloc(sizeof(double)));
+    CLB_HIP(hipMemsetAsync(dAbs.p, 0, sizeof(double), s.st));
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>()));
+    hipLaunchKernelGGL(heldout_residual_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, s.st, dC.as<float>(), (int)dim,
+                       dX.as<float>(), dCodes.as<uint32_t>(), n, dRes.as<float>(), dAbs.as<double>());
+    CLB_HIP(hipGetLastError());
+    CLB_TRY(sort_keys_f32(dRes.as<float>(), dSorted.as<float>(), (size_t)(dim * n), s.st));
+    double abs_sum = 0;
+    CLB_HIP(hipMemcpy(&abs_sum, dAbs.p, sizeof(double), hipMemcpyDeviceToHost));
+    CLB_HIP(hipMemcpy(codes, dCodes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    *avg_residual = (float)(abs_sum / (double)(dim * n));
+    const int64_t nopt = (int64_t)1 << nbits;
+    for (int64_t q = 1; q < nopt; ++q)
+        CLB_TRY(quantile7_device(dSorted.as<float>(), dim * n, (double)q / (double)nopt, &bucket_cutoffs[q - 1]));
+    for (int64_t q = 0; q < nopt; ++q)
+        CLB_TRY(quantile7_device(dSorted.as<float>(), dim * n, (double)q / (double)nopt + 0.5 / (double)nopt, &bucket_weights[q]));
+    return CLB_OK;
+}
+
+int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64_t* ivf, int64_t* ivf_lengths) {
+    if (K < 0 || n < 0) return fail(CLB_EARGUMENT, "negative size");
+    if (n >= (int64_t)0xffffffffll) return fail(CLB_EUNSUPPORTED, "n too large");
+    CLB_TRY(use_device(device));
+    Stream s; CLB_TRY(s.init());
+    DevBuf dCodes, dKeys, dIota, dOrder, dCounts, dErr, dIvf;
+    CLB_TRY(upload(dCodes, codes, sizeof(uint32_t) * std::max<int64_t>(n, 1), s.st));
+    CLB_TRY(dKeys.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dIota.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dOrder.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dCounts.alloc(sizeof(uint32_t) * std::max<int64_t>(K, 1)));
+    CLB_TRY(dIvf.alloc(sizeof(int64_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dErr.alloc(sizeof(int)));
+    CLB_HIP(hipMemsetAsync(dCounts.p, 0, dCounts.bytes, s.st));
+    CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), s.st));
+    if (n > 0) {
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dIota.as<uint32_t>(), n);
+        hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dCodes.as<uint32_t>(), n,
+                           (uint32_t)K, dCounts.as<unsigned int>(), dErr.as<int>());
+        int herr = 0;
+        CLB_HIP(hipMemcpyAsync(&herr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, s.st));
+        CLB_HIP(hipStreamSynchronize(s.st));
+        if (herr) return fail(CLB_EBOUNDS, "codes outside 1..num_partitions");  // counts(values, K) would throw
+        int end_bit = 1;
+        while (((int64_t)1 << end_bit) <= K) ++end_bit;
+        CLB_TRY(sort_pairs_u32(dCodes.as<uint32_t>(), dKeys.as<uint32_t>(), dIota.as<uint32_t>(), dOrder.as<uint32_t>(),
+                               (size_t)n, end_bit, s.st));
+        hipLaunchKernelGGL(ivf_widen_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dOrder.as<uint32_t>(), n,
+                           dIvf.as<int64_t>());
+        CLB_HIP(hipMemcpyAsync(ivf, dIvf.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, s.st));
+    }
+    std::vector<uint32_t> cnt((size_t)std::max<int64_t>(K, 1));
+    CLB_HIP(hipMemcpyAsync(cnt.data(), dCounts.p, sizeof(uint32_t) * std::max<int64_t>(K, 1), hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    for (int64_t c = 0; c < K; ++c) ivf_lengths[c] = cnt[c];
+    return CLB_OK;
+}
+
+int clb_doc_epilogue(int device, const float* D, int64_t dim, int64_t L, int64_t N, const int32_t* integer_ids,
+                     const int64_t* skiplist, int64_t n_skip, float* out, int64_t* doclens, int64_t* n_out) {
+    CLB_TRY(use_device(device));
+    *n_out = 0;
+    if (L * N == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    DevBuf dD, dIds, dSkip, dMask, dLens, dStart, dOut;
+    CLB_TRY(upload(dD, D, sizeof(float) * dim * L * N, s.st));
+    CLB_TRY(upload(dIds, integer_ids, sizeof(int32_t) * L * N, s.st));
+    CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), s.st));
+    CLB_TRY(dMask.alloc((size_t)L * N));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
+    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, s.st, dIds.as<int32_t>(), (int)L,
+                       (int)N, dSkip.as<int64_t>(), (int)n_skip, dMask.as<uint8_t>(), dLens.as<int64_t>());
+    CLB_HIP(hipMemcpyAsync(doclens, dLens.p, sizeof(int64_t) * N, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    std::vector<int64_t> start((size_t)N);
+    int64_t run = 0;
+    for (int64_t i = 0; i < N; ++i) { start[i] = run; run += doclens[i]; }
+    *n_out = run;
+    if (run == 0) return CLB_OK;
+    CLB_TRY(upload(dStart, start.data(), sizeof(int64_t) * N, s.st));
+    CLB_TRY(dOut.alloc(sizeof(float) * dim * run));
+    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, s.st, dD.as<float>(), (int)dim,
+                       (int)L, (int)N, dMask.as<uint8_t>(), dStart.as<int64_t>(), dOut.as<float>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(out, dOut.p, sizeof(float) * dim * run, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+int clb_query_epilogue(int device, float* Q, int64_t dim, int64_t L, int64_t N, const int32_t* integer_ids,
+                       const int64_t* skiplist, int64_t n_skip) {
+    CLB_TRY(use_device(device));
+    if (L * N == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    DevBuf dQ, dIds, dSkip, dMask, dLens, dOut;
+    CLB_TRY(upload(dQ, Q, sizeof(float) * dim * L * N, s.st));
+    CLB_TRY(upload(dIds, integer_ids, sizeof(int32_t) * L * N, s.st));
+    CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), s.st));
+    CLB_TRY(dMask.alloc((size_t)L * N));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
+    CLB_TRY(dOut.alloc(sizeof(float) * dim * L * N));
+    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, s.st, dIds.as<int32_t>(), (int)L,
+                       (int)N, dSkip.as<int64_t>(), (int)n_skip, dMask.as<uint8_t>(), dLens.as<int64_t>());
+    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, s.st, dQ.as<float>(), (int)dim,
+                       (int)L, (int)N, dMask.as<uint8_t>(), (const int64_t*)nullptr, dOut.as<float>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(Q, dOut.p, sizeof(float) * dim * L * N, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,386 @@
+// codec_kernels.hpp -- residual codec, index-build and encoder-epilogue kernels (gfx950).
+// General-shape kernels (any dim that the reference accepts); every floating-point reduction follows the
+// canonical order of oracle/colbert_oracle.h, so results are bit-identical to the CPU oracle.
+//   dot       d-ascending fmaf chain           sumsq   4 interleaved partial sums, (p0+p1)+(p2+p3)
+#pragma once
+#include "common.hpp"
+#include "search_kernels.hpp"
+
+namespace clb {
+
+__device__ __forceinline__ float dot_canonical(const float* __restrict__ a, const float* __restrict__ b, int dim) {
+    float acc = 0.f;
+    for (int d = 0; d < dim; ++d) acc = fmaf(a[d], b[d], acc);
+    return acc;
+}
+__device__ __forceinline__ float sumsq_canonical(const float* __restrict__ x, int dim, int stride = 1) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int d = 0;
+    for (; d + 3 < dim; d += 4) {
+        const float a = x[(size_t)d * stride], b = x[(size_t)(d + 1) * stride];
+        const float c = x[(size_t)(d + 2) * stride], e = x[(size_t)(d + 3) * stride];
+        const float sa = a * a, sb = b * b, sc = c * c, se = e * e;
+        p0 = p0 + sa; p1 = p1 + sb; p2 = p2 + sc; p3 = p3 + se;
+    }
+    if (d < dim) { const float a = x[(size_t)d * stride]; const float s = a * a; p0 = p0 + s; ++d; }
+    if (d < dim) { const float a = x[(size_t)d * stride]; const float s = a * a; p1 = p1 + s; ++d; }
+    if (d < dim) { const float a = x[(size_t)d * stride]; const float s = a * a; p2 = p2 + s; ++d; }
+    return (p0 + p1) + (p2 + p3);
+}
+
+// _normalize_array!(X, dims=1)  utils.jl:320-325 ; one thread per column
+static __global__ void normalize_columns_kernel(float* __restrict__ X, int dim, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float* x = X + e * dim;
+    const float den = sqrtf(sumsq_canonical(x, dim)) + FLT_EPSILON;
+    for (int d = 0; d < dim; ++d) x[d] = x[d] / den;
+}
+
+// decompress  residual.jl:759-784, any dim % 8 == 0, nbits in {1,2,4,8}; one thread per embedding
+static __global__ void decompress_generic_kernel(int dim, int nbits, const float* __restrict__ C,
+                                          const float* __restrict__ weights,
+                                          const uint32_t* __restrict__ codes /*1-based*/,
+                                          const uint8_t* __restrict__ residuals, int64_t n,
+                                          float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int rows = dim / 8 * nbits;
+    const uint8_t* r = residuals + e * rows;
+    const float* c = C + (size_t)(codes[e] - 1) * dim;
+    float* x = out + e * dim;
+    const uint32_t mask = (1u << nbits) - 1u;
+    for (int d = 0; d < dim; ++d) {
+        const int p = d * nbits;
+        const uint32_t idx = ((uint32_t)r[p >> 3] >> (p & 7)) & mask;
+        x[d] = c[d] + weights[idx];
+    }
+    const float den = sqrtf(sumsq_canonical(x, dim)) + FLT_EPSILON;
+    for (int d = 0; d < dim; ++d) x[d] = x[d] / den;
+}
+
+// The same decompression the fused search kernel performs (dim 128), written out -- lets the tests
+// pin the product path's decompression bit-for-bit.  One 16-embedding group per wave step.
+template <int NBITS>
+static __global__ __launch_bounds__(256) void decompress_dim128_kernel(const float* __restrict__ C,
+                                                               const float* __restrict__ weights,
+                                                               const uint32_t* __restrict__ codes /*1-based*/,
+                                                               const uint8_t* __restrict__ residuals,
+                                                               int64_t n, float* __restrict__ out) {
+    constexpr int RD = NBITS * 4;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    float wlane = 0.f;
+    if constexpr (NBITS <= 2) {
+#pragma unroll
+        for (int j = 0; j < (1 << NBITS); ++j) w[j] = weights[j];
+    } else {
+        wlane = lane < (1 << NBITS) ? weights[lane] : 0.f;
+    }
+    const int64_t groups = (n + 15) / 16;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t el = grp * 16 + r;
+        const int64_t e = el < n ? el : n - 1;
+        uint32_t R[RD];
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * (RD * 4));
+#pragma unroll
+        for (int k4 = 0; k4 < RD; k4 += 4) {
+            uint4 v = *reinterpret_cast<const uint4*>(rp + k4);
+            R[k4] = v.x; R[k4 + 1] = v.y; R[k4 + 2] = v.z; R[k4 + 3] = v.w;
+        }
+        float x[32];
+        decompress_lane_dims<NBITS>(C + (size_t)(codes[e] - 1) * kDim + g, R, g, w, wlane, x);
+        if (el < n) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) out[(size_t)e * kDim + 4 * s + g] = x[s];
+        }
+    }
+}
+
+// maxsim  ranking.jl:69-86 ; one workgroup per pid, thread t owns query token t
+static __global__ void maxsim_generic_kernel(const float* __restrict__ Q, int dim, int T, const float* __restrict__ D,
+                                      const int64_t* __restrict__ offsets /*n_pids+1*/,
+                                      float* __restrict__ scores) {
+    extern __shared__ float sm[];
+    const int j = blockIdx.x;
+    const int64_t lo = offsets[j], hi = offsets[j + 1];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float m = 0.f;
+        for (int64_t e = lo; e < hi; ++e) {
+            const float s = dot_canonical(Q + (size_t)t * dim, D + (size_t)e * dim, dim);
+            m = (e == lo || s > m) ? s : m;
+        }
+        sm[t] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc = acc + sm[t];
+        scores[j] = acc;
+    }
+}
+
+// compress_into_codes!  residual.jl:67-81 : argmax inner product, first index on ties (generic dim)
+// MODE 0: argmax dot (codes, 1-based UInt32) ; MODE 1: argmin ((-2 dot + c2) + x2) (k-means, Int32 1-based)
+template <int MODE>
+static __global__ void nearest_centroid_generic_kernel(const float* __restrict__ C, const float* __restrict__ c2,
+                                                int dim, int K, const float* __restrict__ X, int64_t n,
+                                                uint32_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* x = X + e * dim;
+    float x2 = 0.f;
+    if (MODE == 1) x2 = sumsq_canonical(x, dim);
+    int best = 0;
+    float bestv = 0.f;
+    for (int c = 0; c < K; ++c) {
+        float v = dot_canonical(MODE == 1 ? C + (size_t)c * dim : x, MODE == 1 ? x : C + (size_t)c * dim, dim);
+        if (MODE == 1) {
+            v = -2.0f * v;
+            v = v + c2[c];
+            v = v + x2;
+            if (c == 0 || v < bestv) { bestv = v; best = c; }
+        } else {
+            if (c == 0 || v > bestv) { bestv = v; best = c; }
+        }
+    }
+    out[e] = (uint32_t)(best + 1);
+}
+
+// dim = 128 fast path of the above on the f32 MFMA: one wave owns 32 points (B operand, resident in
+// registers) and streams every centroid tile through LDS exactly like centroid_scores_kernel.
+// grid = ceil(n/32/2) workgroups of 128 threads; LDS = 2*32*132*4.
+template <int MODE>
+static __global__ __launch_bounds__(128) void nearest_centroid_mfma_kernel(const float* __restrict__ C,
+                                                                    const float* __restrict__ c2, int K,
+                                                                    const float* __restrict__ X, int64_t n,
+                                                                    uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    float* my = lds + wave * (32 * kCentTileStride);
+    const int64_t ptile = (int64_t)blockIdx.x * 2 + wave;
+    if (ptile * 32 >= n) return;  // whole wave exits together
+    const int64_t pt = ptile * 32 + i;
+    const float* xrow = X + (size_t)(pt < n ? pt : n - 1) * kDim;
+    float qf[64];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        float4 v = *reinterpret_cast<const float4*>(xrow + 4 * m);
+        qf[2 * m] = h ? v.y : v.x;
+        qf[2 * m + 1] = h ? v.w : v.z;
+    }
+    float x2 = 0.f;
+    if (MODE == 1) x2 = sumsq_canonical(xrow, kDim);
+    float bestv = 0.f;
+    int best = 0x7fffffff;
+    const int n_tiles = (K + 31) / 32;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int c0 = tile * 32;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int row = 2 * m + h;
+            int c = c0 + row;
+            c = c < K ? c : K - 1;
+            float4 v = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 4 * i);
+            *reinterpret_cast<float4*>(my + row * kCentTileStride + 4 * i) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 a4 = *reinterpret_cast<const float4*>(my + i * kCentTileStride + 4 * m);
+            const float a0 = h ? a4.y : a4.x;
+            const float a1 = h ? a4.w : a4.z;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qf[2 * m], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qf[2 * m + 1], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rows (centroids) ascend with r for a fixed half h: (r&3) + 8*(r>>2) + 4h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (c < K) {
+                float v = acc[r];
+                if (MODE == 1) {
+                    v = -2.0f * v;
+                    v = v + c2[c];
+                    v = v + x2;
+                    if (best == 0x7fffffff || v < bestv || (v == bestv && c < best)) { bestv = v; best = c; }
+                } else {
+                    if (best == 0x7fffffff || v > bestv || (v == bestv && c < best)) { bestv = v; best = c; }
+                }
+            }
+        }
+    }
+    // merge the two halves (same point, disjoint centroid rows); the lower index wins ties
+    const float ov = __shfl_xor(bestv, 32, 64);
+    const int oi = __shfl_xor(best, 32, 64);
+    const bool take = MODE == 1 ? (ov < bestv || (ov == bestv && oi < best)) : (ov > bestv || (ov == bestv && oi < best));
+    if (oi != 0x7fffffff && (best == 0x7fffffff || take)) { bestv = ov; best = oi; }
+    if (h == 0 && pt < n) out[pt] = (uint32_t)(best + 1);
+}
+
+static __global__ void centroid_sumsq_kernel(const float* __restrict__ C, int dim, int K, float* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < K) c2[c] = sumsq_canonical(C + (size_t)c * dim, dim);
+}
+
+// compress  residual.jl:586-604 after the codes: residual = x - C[:,code], bucket index =
+// searchsortedfirst(cutoffs, r) - 1 (residual.jl:348-351), LSB-first bit packing (residual.jl:400-407).
+// One thread per output byte: fully coalesced stores, no read-modify-write.
+static __global__ void pack_residuals_kernel(const float* __restrict__ C, const float* __restrict__ cutoffs, int ncut,
+                                      int dim, int nbits, const float* __restrict__ X,
+                                      const uint32_t* __restrict__ codes /*1-based*/, int64_t n,
+                                      uint8_t* __restrict__ out) {
+    const int rows = dim / 8 * nbits;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * rows) return;
+    const int64_t e = gid / rows;
+    const int j = (int)(gid % rows);
+    const float* x = X + e * dim;
+    const float* c = C + (size_t)(codes[e] - 1) * dim;
+    uint32_t byte = 0;
+    for (int bit = 0; bit < 8; ++bit) {
+        const int p = 8 * j + bit;
+        const int d = p / nbits, b = p % nbits;
+        const float r = x[d] - c[d];
+        int lo = 0, hi = ncut + 1;  // Julia's searchsortedfirst
+        while (lo < hi - 1) {
+            const int m = lo + ((hi - lo) >> 1);
+            if (cutoffs[m - 1] < r) lo = m; else hi = m;
+        }
+        const int idx = hi - 1;
+        byte |= (uint32_t)((idx >> b) & 1) << bit;
+    }
+    out[gid] = (uint8_t)byte;
+}
+
+// residual values of the held-out sample  collection_indexer.jl:185-187 (+ sum |r| for avg_residual)
+static __global__ void heldout_residual_kernel(const float* __restrict__ C, int dim, const float* __restrict__ X,
+                                        const uint32_t* __restrict__ codes, int64_t n, float* __restrict__ res,
+                                        double* __restrict__ abs_sum) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double a = 0.0;
+    if (gid < n * dim) {
+        const int64_t e = gid / dim;
+        const int d = (int)(gid % dim);
+        const float r = X[gid] - C[(size_t)(codes[e] - 1) * dim + d];
+        res[gid] = r;
+        a = fabs((double)r);
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(abs_sum, a);
+}
+
+// ---- k-means update  utils.jl:288-303 -------------------------------------------------------------
+// Members of each cluster are visited in ascending point order (stable sort by assignment); within a
+// batch of `point_bsize` points the contributions are summed first and the batch sum is then added to
+// the running centroid sum -- the order `mul!(new_centroids, batch_data, one_hot', 1, 1)` produces.
+// One thread per (cluster, dim): coalesced over dims.
+static __global__ void kmeans_accumulate_kernel(const float* __restrict__ X, int dim, const uint32_t* __restrict__ order /*point ids, grouped by cluster*/,
+                                         const uint32_t* __restrict__ start /*K+1*/, int K, int point_bsize,
+                                         float* __restrict__ newc, int* __restrict__ counts) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)K * dim) return;
+    const int c = (int)(gid / dim), d = (int)(gid % dim);
+    const uint32_t lo = start[c], hi = start[c + 1];
+    float total = 0.f, part = 0.f;
+    uint32_t cur_batch = 0xffffffffu;
+    for (uint32_t m = lo; m < hi; ++m) {
+        const uint32_t pt = order[m];
+        const uint32_t bt = pt / (uint32_t)point_bsize;
+        if (bt != cur_batch) {
+            if (cur_batch != 0xffffffffu) total = total + part;
+            part = 0.f;
+            cur_batch = bt;
+        }
+        part = part + X[(size_t)pt * dim + d];
+    }
+    if (cur_batch != 0xffffffffu) total = total + part;
+    newc[gid] = total;
+    if (d == 0) counts[c] = (int)(hi - lo);
+}
+
+// new ./= max.(counts,1) ; delta = maximum(abs.(centroids - new))   utils.jl:302-306
+static __global__ void kmeans_finalize_kernel(float* __restrict__ newc, const int* __restrict__ counts,
+                                       const float* __restrict__ oldc, int dim, int K,
+                                       unsigned int* __restrict__ delta_bits) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float diff = 0.f;
+    if (gid < (int64_t)K * dim) {
+        const int c = (int)(gid / dim);
+        const int cnt = counts[c];
+        const float v = newc[gid] / (float)(cnt > 1 ? cnt : 1);
+        newc[gid] = v;
+        diff = fabsf(oldc[gid] - v);
+    }
+    for (int o = 32; o > 0; o >>= 1) diff = fmaxf(diff, __shfl_down(diff, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(delta_bits, __float_as_uint(diff));  // diff >= 0: bits order like floats
+}
+
+static __global__ void iota_kernel(uint32_t* __restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+// histogram of 1-based codes into counts[K]; flags codes outside 1..K
+static __global__ void code_histogram_kernel(const uint32_t* __restrict__ codes, int64_t n, uint32_t K,
+                                      unsigned int* __restrict__ counts, int* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = codes[i];
+    if (c < 1u || c > K) { atomicOr(err, 1); return; }
+    atomicAdd(&counts[c - 1], 1u);
+}
+static __global__ void ivf_widen_kernel(const uint32_t* __restrict__ order, int64_t n, int64_t* __restrict__ ivf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ivf[i] = (int64_t)order[i] + 1;
+}
+
+// ---- encoder epilogue  checkpoint.jl:27-71, embedding_utils.jl:172-205 ----------------------------
+// mask[l,n] = ids[l,n] not in skiplist ; doclens[n] = sum(mask[:,n]) ; one thread per document
+static __global__ void epilogue_mask_kernel(const int32_t* __restrict__ ids, int L, int N, const int64_t* __restrict__ skip,
+                                     int nskip, uint8_t* __restrict__ mask, int64_t* __restrict__ doclens) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int64_t len = 0;
+    for (int l = 0; l < L; ++l) {
+        const int32_t id = ids[(size_t)n * L + l];
+        bool keep = true;
+        for (int s = 0; s < nskip; ++s) keep = keep && ((int64_t)id != skip[s]);
+        mask[(size_t)n * L + l] = keep ? 1 : 0;
+        len += keep ? 1 : 0;
+    }
+    doclens[n] = len;
+}
+// one thread per token column: D .* mask, normalise, write to its compacted slot (or in place)
+static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, int dim, int L, int N,
+                                          const uint8_t* __restrict__ mask, const int64_t* __restrict__ doc_start /*N, exclusive scan of doclens; null = in place*/,
+                                          float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (int64_t)L * N) return;
+    const int n = (int)(j / L), l = (int)(j % L);
+    const bool keep = mask[j] != 0;
+    const float* x = D + j * dim;
+    if (doc_start) {
+        if (!keep) return;
+        int before = 0;
+        for (int q = 0; q < l; ++q) before += mask[(size_t)n * L + q];
+        float* o = out + (size_t)(doc_start[n] + before) * dim;
+        const float den = sqrtf(sumsq_canonical(x, dim)) + FLT_EPSILON;
+        for (int d = 0; d < dim; ++d) o[d] = x[d] / den;
+    } else {
+        float* o = out + j * dim;
+        if (!keep) {
+            // D .* mask zeroes the column (-0.0 for negative entries); 0/(0+eps) keeps it
+            for (int d = 0; d < dim; ++d) o[d] = (x[d] * 0.0f) / FLT_EPSILON;
+            return;
+        }
+        const float den = sqrtf(sumsq_canonical(x, dim)) + FLT_EPSILON;
+        for (int d = 0; d < dim; ++d) o[d] = x[d] / den;
+    }
+}
+
+}  // namespace clb

@@ -1,0 +1,506 @@
+// search.hip -- the Searcher handle and the search entry points of the C ABI (include/colbert_hip.h).
+// Replaces: struct Searcher / Searcher(index_path) (src/searching.jl:1-91) and search() after the
+// encoder (src/searching.jl:102-127), retrieve/gather/maxsim (src/search/ranking.jl).
+#include <algorithm>
+#include <numeric>
+
+#include "approx_kernels.hpp"
+#include "search_kernels.hpp"
+
+using namespace clb;
+
+namespace {
+
+enum KernelId {
+    KID_CENTROID_SCORES = 0,
+    KID_TOPN,
+    KID_MARK,
+    KID_COMPACT,
+    KID_SCORE_EXACT,
+    KID_SCORE_APPROX,
+    KID_SELECT,
+    KID_TOPK,
+    KID_COUNT
+};
+const char* kKernelNames[KID_COUNT] = {"centroid_scores", "top_nprobe", "mark_candidates", "compact_candidates",
+                                       "score_exact",     "score_approx", "select_margin", "topk"};
+
+struct Prof {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KID_COUNT];
+    std::vector<hipEvent_t> pool;
+    double total_ms[KID_COUNT] = {0};
+    int64_t launches[KID_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+
+}  // namespace
+
+struct clb_searcher {
+    int device = 0;
+    int64_t dim = 0, K = 0, n_docs = 0, n_emb = 0, pid_offset = 0;
+    int nbits = 0;
+    int mode = 0;
+    bool approx_ok = false;
+    hipStream_t stream = nullptr;
+    // resident index (HBM)
+    DevBuf centroids;   // fp32 [K][128]
+    DevBuf weights;     // fp32 [2^nbits]
+    DevBuf codes0;      // u32 [n_emb], 0-based
+    DevBuf residuals;   // u8 [n_emb][16*nbits]
+    DevBuf doc_off;     // u32 [n_docs+1]
+    DevBuf ivf_off;     // u32 [K+1]
+    DevBuf ivf_pid;     // u32 [n_emb] local passage ids grouped by centroid
+    DevBuf inv_norm;    // fp32 [n_emb]  (two-pass mode)
+    std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
+    // workspace, sized for (Bcap, Tcap, nprobe_cap, kcap)
+    int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
+    size_t cand_cap = 0;
+    int W = 0, nblk_bitmap = 0, topn_blocks = 0;
+    DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, scores, list, nlist, thresh,
+        outp, outs, flags, stats;
+    Prof prof;
+    int64_t last_cand_docs = 0, last_cand_embs = 0, last_resc_docs = 0, last_resc_embs = 0;
+    int64_t index_bytes = 0;
+};
+
+namespace {
+
+struct Timed {
+    clb_searcher* s;
+    int id;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(clb_searcher* s_, int id_, hipStream_t st_) : s(s_), id(id_), st(st_) {
+        if (s->prof.on) {
+            a = s->prof.get();
+            b = s->prof.get();
+            (void)hipEventRecord(a, st);
+        }
+    }
+    ~Timed() {
+        if (s->prof.on) {
+            (void)hipEventRecord(b, st);
+            s->prof.pending[id].push_back({a, b});
+        }
+    }
+};
+
+// token tiles of 32 for the cells table: Tpad in {32, 64, 128} so that it divides the 256-thread scan
+inline int token_tiles(int64_t T) { return T <= 32 ? 1 : T <= 64 ? 2 : 4; }
+
+int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+int ensure_workspace(clb_searcher* s, int64_t B, int64_t T, int64_t nprobe, int64_t k) {
+    if (B <= s->Bcap && T <= s->Tcap && nprobe <= s->npcap && k <= s->kcap) return CLB_OK;
+    CLB_HIP(hipStreamSynchronize(s->stream));
+    B = std::max(B, s->Bcap); T = std::max(T, s->Tcap);
+    nprobe = std::max(nprobe, s->npcap); k = std::max(k, s->kcap);
+    const int64_t Tpad = token_tiles(T) * 32;
+    // candidates of one query <= sum of the T*nprobe longest IVF lists (and <= n_docs)
+    size_t lists = (size_t)std::min<int64_t>(T * nprobe, s->K);
+    size_t cap = 0;
+    for (size_t i = 0; i < lists; ++i) cap += s->ivf_len_sorted[i];
+    cap = std::min<size_t>(cap, (size_t)s->n_docs);
+    cap = std::max<size_t>(cap, 1);
+    s->cand_cap = (cap + 3) & ~(size_t)3;
+    s->W = (int)((s->n_docs + 31) / 32);
+    s->nblk_bitmap = (s->W + kScanBlock * kWordsPerThread - 1) / (kScanBlock * kWordsPerThread);
+    s->topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
+    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
+    CLB_TRY(s->Qdev.ensure(sizeof(float) * B * T * kDim));
+    CLB_TRY(s->cells.ensure(sizeof(float) * B * s->K * Tpad));
+    CLB_TRY(s->partial.ensure(sizeof(ValIdx) * B * s->topn_blocks * Tpad * NPs));
+    CLB_TRY(s->sel.ensure(sizeof(int) * B * Tpad * NPs));
+    const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * s->W;
+    const bool bm_new = bm_bytes > s->bitmap.bytes || !s->bitmap.p;
+    CLB_TRY(s->bitmap.ensure(bm_bytes));
+    if (bm_new) CLB_HIP(hipMemsetAsync(s->bitmap.p, 0, s->bitmap.bytes, s->stream));
+    CLB_TRY(s->blocksum.ensure(sizeof(int) * B * s->nblk_bitmap));
+    CLB_TRY(s->ncand.ensure(sizeof(int) * B));
+    CLB_TRY(s->cand.ensure(sizeof(uint32_t) * B * s->cand_cap));
+    CLB_TRY(s->scores.ensure(sizeof(float) * B * s->cand_cap));
+    CLB_TRY(s->list.ensure(sizeof(int) * B * s->cand_cap));
+    CLB_TRY(s->nlist.ensure(sizeof(int) * B));
+    CLB_TRY(s->thresh.ensure(sizeof(float) * B * 2));
+    CLB_TRY(s->outp.ensure(sizeof(int64_t) * B * k));
+    CLB_TRY(s->outs.ensure(sizeof(float) * B * k));
+    CLB_TRY(s->flags.ensure(sizeof(int) * B));
+    CLB_TRY(s->stats.ensure(sizeof(unsigned long long) * 8));
+    if (s->approx_ok) CLB_TRY(s->cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
+    s->Bcap = B; s->Tcap = T; s->npcap = nprobe; s->kcap = k;
+    CLB_HIP(hipStreamSynchronize(s->stream));
+    return CLB_OK;
+}
+
+template <int NP>
+void launch_topn(clb_searcher* s, hipStream_t st, int B, int Tpad) {
+    hipLaunchKernelGGL(topn_partial_kernel<NP>, dim3(s->topn_blocks, B), dim3(256), 0, st,
+                       s->cells.as<float>(), s->partial.as<ValIdx>(), (int)s->K, Tpad);
+    hipLaunchKernelGGL(topn_final_kernel<NP>, dim3(B), dim3(Tpad), 0, st, s->partial.as<ValIdx>(),
+                       s->sel.as<int>(), s->topn_blocks, Tpad);
+}
+
+template <int NBITS>
+void launch_score_exact(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, const int* list,
+                        const int* nlist, int grid_x) {
+    hipLaunchKernelGGL(score_exact_kernel<NBITS>, dim3(grid_x, B), dim3(256), 0, st,
+                       s->centroids.as<float>(), s->weights.as<float>(), s->codes0.as<uint32_t>(),
+                       s->residuals.as<uint8_t>(), s->doc_off.as<uint32_t>(), dQ, s->cand.as<uint32_t>(),
+                       s->ncand.as<int>(), s->scores.as<float>(), T, s->cand_cap, list, nlist);
+}
+
+// Candidate generation S1-S3 for B queries on stream st; leaves cand/ncand on the device.
+int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
+    const int TT = token_tiles(T), Tpad = TT * 32;
+    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
+    const int n_tiles = (int)((s->K + 31) / 32);
+    {
+        Timed t(s, KID_CENTROID_SCORES, st);
+        const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B * TT)));
+        hipLaunchKernelGGL(centroid_scores_kernel, dim3(gx, B * TT), dim3(128),
+                           2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
+                           s->cells.as<float>(), (int)s->K, T, TT, n_tiles);
+    }
+    {
+        Timed t(s, KID_TOPN, st);
+        if (NPs == 2) launch_topn<2>(s, st, B, Tpad);
+        else if (NPs == 8) launch_topn<8>(s, st, B, Tpad);
+        else launch_topn<32>(s, st, B, Tpad);
+    }
+    {
+        Timed t(s, KID_MARK, st);
+        hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, s->sel.as<int>(),
+                           s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), s->bitmap.as<uint32_t>(), T,
+                           Tpad, NPs, nprobe, s->W);
+    }
+    {
+        Timed t(s, KID_COMPACT, st);
+        hipLaunchKernelGGL(bitmap_count_kernel, dim3(s->nblk_bitmap, B), dim3(kScanBlock), 0, st,
+                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->W);
+        hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, s->blocksum.as<int>(),
+                           s->ncand.as<int>(), s->nblk_bitmap);
+        hipLaunchKernelGGL(bitmap_emit_kernel, dim3(s->nblk_bitmap, B), dim3(kScanBlock), 0, st,
+                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->cand.as<uint32_t>(), s->W,
+                           s->cand_cap);
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int64_t k) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (T < 1 || T > 128) return fail(CLB_EUNSUPPORTED, "query length T=%lld outside 1..128", (long long)T);
+    if (B < 1) return fail(CLB_EARGUMENT, "batch size must be >= 1");
+    if (nprobe < 1 || nprobe > s->K) return fail(CLB_EBOUNDS, "nprobe=%lld outside 1..K=%lld (partialsortperm)", (long long)nprobe, (long long)s->K);
+    if (nprobe > 32) return fail(CLB_EUNSUPPORTED, "nprobe > 32 not supported by the HIP path");
+    if (k < 1) return fail(CLB_EBOUNDS, "k must be >= 1");
+    if (k > kMaxTopK) return fail(CLB_EUNSUPPORTED, "k=%lld > %d not supported by the HIP path", (long long)k, kMaxTopK);
+    return CLB_OK;
+}
+
+// The whole search for B device-resident queries, enqueued on st.
+int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
+               int64_t* d_out_pids, float* d_out_scores) {
+    CLB_TRY(run_retrieve(s, st, dQ, B, T, nprobe));
+    const int kpow2 = next_pow2(k);
+    CLB_HIP(hipMemsetAsync(s->flags.p, 0, sizeof(int) * B, st));
+    if (s->prof.on) CLB_HIP(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * 8, st));
+    const int* list = nullptr;
+    const int* nlist = nullptr;
+    {
+        Timed t(s, KID_SCORE_EXACT, st);
+        const int gx = list ? std::max(1, 512 / B) : std::max(1, 2048 / B);
+        switch (s->nbits) {
+            case 1: launch_score_exact<1>(s, st, dQ, B, T, list, nlist, gx); break;
+            case 2: launch_score_exact<2>(s, st, dQ, B, T, list, nlist, gx); break;
+            case 4: launch_score_exact<4>(s, st, dQ, B, T, list, nlist, gx); break;
+            default: return fail(CLB_EUNSUPPORTED, "nbits=%d not supported by the HIP search path", s->nbits);
+        }
+    }
+    {
+        Timed t(s, KID_TOPK, st);
+        hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
+                           s->scores.as<float>(), s->cand.as<uint32_t>(), s->ncand.as<int>(), list, nlist, k,
+                           kpow2, s->cand_cap, s->pid_offset, d_out_pids, d_out_scores, s->flags.as<int>());
+    }
+    if (s->prof.on) {
+        hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, s->cand.as<uint32_t>(),
+                           s->ncand.as<int>(), list, nlist, s->doc_off.as<uint32_t>(), s->cand_cap,
+                           s->stats.as<unsigned long long>());
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* clb_version(void) { return "colbert_hip 0.1 (gfx950)"; }
+const char* clb_last_error(void) { return clb::last_error().c_str(); }
+int clb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
+                        const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                        const uint32_t* codes, const uint8_t* residuals, const int64_t* ivf,
+                        const int64_t* ivf_lengths, int64_t pid_offset, clb_searcher** out) {
+    if (!out) return fail(CLB_EARGUMENT, "out is null");
+    *out = nullptr;
+    if (dim != kDim) return fail(CLB_EUNSUPPORTED, "the HIP search path is built for dim=128 (got %lld)", (long long)dim);
+    if (nbits != 1 && nbits != 2 && nbits != 4)
+        return fail(CLB_EUNSUPPORTED, "the HIP search path supports nbits in {1,2,4} (got %d)", nbits);
+    if (K < 1 || n_docs < 0 || n_emb < 0) return fail(CLB_EARGUMENT, "negative or empty sizes");
+    if (n_emb >= (int64_t)0xffffffffll || n_docs >= (int64_t)0x7fffffffll)
+        return fail(CLB_EUNSUPPORTED, "a shard holds at most 2^32-1 embeddings / 2^31-1 passages");
+    // host-side structure checks (the reference's DimensionMismatch in _cids_to_eids!, ranking.jl:9-12)
+    std::vector<uint32_t> doc_off((size_t)n_docs + 1);
+    int64_t run = 0;
+    for (int64_t p = 0; p < n_docs; ++p) {
+        if (doclens[p] < 0) return fail(CLB_EARGUMENT, "negative doclen at passage %lld", (long long)(p + 1));
+        doc_off[p] = (uint32_t)run;
+        run += doclens[p];
+    }
+    doc_off[n_docs] = (uint32_t)run;
+    if (run != n_emb) return fail(CLB_EDIMENSION, "sum(doclens)=%lld must equal the number of embeddings %lld", (long long)run, (long long)n_emb);
+    std::vector<uint32_t> ivf_off((size_t)K + 1);
+    run = 0;
+    for (int64_t c = 0; c < K; ++c) {
+        if (ivf_lengths[c] < 0) return fail(CLB_EARGUMENT, "negative ivf length");
+        ivf_off[c] = (uint32_t)run;
+        run += ivf_lengths[c];
+    }
+    ivf_off[K] = (uint32_t)run;
+    if (run != n_emb) return fail(CLB_EDIMENSION, "length(ivf) must be equal to sum(ivf_lengths)!");
+    CLB_TRY(use_device(device));
+
+    clb_searcher* s = new clb_searcher();
+    s->device = device; s->dim = dim; s->nbits = nbits; s->K = K; s->n_docs = n_docs; s->n_emb = n_emb;
+    s->pid_offset = pid_offset;
+    auto bail = [&](int rc) { clb_searcher_destroy(s); return rc; };
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(CLB_EHIP, "hipStreamCreate failed"));
+    s->ivf_len_sorted.resize((size_t)K);
+    for (int64_t c = 0; c < K; ++c) s->ivf_len_sorted[c] = (uint32_t)ivf_lengths[c];
+    std::sort(s->ivf_len_sorted.begin(), s->ivf_len_sorted.end(), std::greater<uint32_t>());
+
+    const size_t rows = (size_t)(dim / 8 * nbits);
+    int rc;
+    if ((rc = upload(s->centroids, centroids, sizeof(float) * dim * K, s->stream))) return bail(rc);
+    if ((rc = upload(s->weights, bucket_weights, sizeof(float) * ((size_t)1 << nbits), s->stream))) return bail(rc);
+    if ((rc = upload(s->codes0, codes, sizeof(uint32_t) * n_emb, s->stream))) return bail(rc);
+    if ((rc = upload(s->residuals, residuals, rows * n_emb, s->stream))) return bail(rc);
+    if ((rc = upload(s->doc_off, doc_off.data(), sizeof(uint32_t) * doc_off.size(), s->stream))) return bail(rc);
+    if ((rc = upload(s->ivf_off, ivf_off.data(), sizeof(uint32_t) * ivf_off.size(), s->stream))) return bail(rc);
+    if ((rc = s->ivf_pid.alloc(sizeof(uint32_t) * n_emb))) return bail(rc);
+    DevBuf ivf_raw, err;
+    if ((rc = upload(ivf_raw, ivf, sizeof(int64_t) * n_emb, s->stream))) return bail(rc);
+    if ((rc = err.alloc(sizeof(int)))) return bail(rc);
+    if (hipMemsetAsync(err.p, 0, sizeof(int), s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
+    if (n_emb > 0) {
+        const int blocks = (int)((n_emb + 255) / 256);
+        hipLaunchKernelGGL(ivf_to_pid_kernel, dim3(blocks), dim3(256), 0, s->stream, ivf_raw.as<int64_t>(),
+                           s->doc_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), n_emb, (int)n_docs, err.as<int>());
+        hipLaunchKernelGGL(codes_to_zero_based_kernel, dim3(blocks), dim3(256), 0, s->stream,
+                           s->codes0.as<uint32_t>(), n_emb, (uint32_t)K, err.as<int>());
+    }
+    int herr = 0;
+    if (hipMemcpyAsync(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess)
+        return bail(fail(CLB_EHIP, "index upload failed: %s", hipGetErrorString(hipGetLastError())));
+    if (herr & 1) return bail(fail(CLB_EBOUNDS, "ivf holds embedding ids outside 1..n_emb"));
+    if (herr & 2) return bail(fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!"));
+
+    s->approx_ok = approx_supported((int)dim, nbits);
+    if (s->approx_ok) {
+        if ((rc = s->inv_norm.alloc(sizeof(float) * std::max<int64_t>(n_emb, 1)))) return bail(rc);
+        if ((rc = build_inv_norms(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
+                                  s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb,
+                                  s->inv_norm.as<float>())))
+            return bail(rc);
+        if (hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "inv-norm build failed"));
+    }
+    s->mode = s->approx_ok ? 1 : 0;
+    s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
+                               s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes + s->inv_norm.bytes);
+    *out = s;
+    return CLB_OK;
+}
+
+int clb_searcher_destroy(clb_searcher* s) {
+    if (!s) return CLB_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) {
+        (void)hipStreamSynchronize(s->stream);
+        for (auto& v : s->prof.pending)
+            for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto e : s->prof.pool) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(s->stream);
+    }
+    delete s;
+    return CLB_OK;
+}
+
+int64_t clb_searcher_device_bytes(const clb_searcher* s) {
+    if (!s) return 0;
+    const DevBuf* ws[] = {&s->Qdev, &s->cells, &s->cells_q, &s->partial, &s->sel, &s->bitmap, &s->blocksum, &s->ncand,
+                          &s->cand, &s->scores, &s->list, &s->nlist, &s->thresh, &s->outp, &s->outs, &s->flags, &s->stats};
+    int64_t tot = s->index_bytes;
+    for (auto* b : ws) tot += (int64_t)b->bytes;
+    return tot;
+}
+
+int clb_searcher_set_mode(clb_searcher* s, int mode) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (mode != 0 && mode != 1) return fail(CLB_EARGUMENT, "mode must be 0 (exact) or 1 (two-pass)");
+    if (mode == 1 && !s->approx_ok) return fail(CLB_EUNSUPPORTED, "two-pass mode needs dim=128, nbits=2");
+    s->mode = mode;
+    return CLB_OK;
+}
+int clb_searcher_get_mode(const clb_searcher* s) { return s ? s->mode : -1; }
+
+int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                            int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
+                            void* hip_stream) {
+    CLB_TRY(check_search_args(s, T, B, nprobe, k));
+    CLB_TRY(use_device(s->device));
+    CLB_TRY(ensure_workspace(s, B, T, nprobe, k));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+    CLB_TRY(run_search(s, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores));
+    if (d_n_cand) {
+        hipLaunchKernelGGL(widen_counts_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, st,
+                           s->ncand.as<int>(), d_n_cand, (int)B);
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                     int pad_short, int64_t* out_pids, float* out_scores, int64_t* n_cand) {
+    CLB_TRY(check_search_args(s, T, B, nprobe, k));
+    CLB_TRY(use_device(s->device));
+    CLB_TRY(ensure_workspace(s, B, T, nprobe, k));
+    hipStream_t st = s->stream;
+    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * B * T * kDim, hipMemcpyHostToDevice, st));
+    CLB_TRY(run_search(s, st, s->Qdev.as<float>(), (int)B, (int)T, (int)nprobe, (int)k, s->outp.as<int64_t>(),
+                       s->outs.as<float>()));
+    std::vector<int> nc((size_t)B), fl((size_t)B);
+    CLB_HIP(hipMemcpyAsync(out_pids, s->outp.p, sizeof(int64_t) * B * k, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(out_scores, s->outs.p, sizeof(float) * B * k, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(nc.data(), s->ncand.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(fl.data(), s->flags.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    int64_t docs = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        if (n_cand) n_cand[b] = nc[b];
+        docs += nc[b];
+    }
+    s->last_cand_docs = docs;
+    if (!pad_short)
+        for (int64_t b = 0; b < B; ++b)
+            if (fl[b])  // searching.jl:127 `pids[1:k]` on a shorter vector
+                return fail(CLB_EBOUNDS, "query %lld has %d candidate passages, fewer than k=%lld", (long long)b, nc[b], (long long)k);
+    return CLB_OK;
+}
+
+int clb_search(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t k, int64_t* out_pids,
+               float* out_scores, int64_t* n_cand) {
+    return clb_search_batch(s, Q, T, 1, nprobe, k, 0, out_pids, out_scores, n_cand);
+}
+
+int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
+                 int64_t* n_out) {
+    CLB_TRY(check_search_args(s, T, 1, nprobe, 1));
+    CLB_TRY(use_device(s->device));
+    CLB_TRY(ensure_workspace(s, 1, T, nprobe, 1));
+    hipStream_t st = s->stream;
+    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
+    CLB_TRY(run_retrieve(s, st, s->Qdev.as<float>(), 1, (int)T, (int)nprobe));
+    int nc = 0;
+    CLB_HIP(hipMemcpyAsync(&nc, s->ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    std::vector<uint32_t> c((size_t)nc);
+    if (nc) CLB_HIP(hipMemcpy(c.data(), s->cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nc; ++i) out_pids[i] = s->pid_offset + (int64_t)c[i] + 1;
+    *n_out = nc;
+    return CLB_OK;
+}
+
+int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scores, int64_t k, int64_t n_lists,
+                          int64_t B, int64_t* d_out_pids, float* d_out_scores, void* hip_stream) {
+    if (k < 1 || n_lists < 1 || B < 1) return fail(CLB_EARGUMENT, "k, n_lists and B must be >= 1");
+    CLB_TRY(use_device(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)((B * k + 255) / 256)), dim3(256), 0, st, d_out_pids,
+                       d_out_scores, B * k);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((n_lists * k + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                       d_pids, d_scores, (int)k, (int)n_lists, (int)B, d_out_pids, d_out_scores);
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+int clb_profile_enable(clb_searcher* s, int on) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    s->prof.on = on != 0;
+    return CLB_OK;
+}
+
+int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int64_t* launches, int cap) {
+    if (!s) return 0;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    int n = 0;
+    for (int id = 0; id < KID_COUNT && n < cap; ++id) {
+        for (auto& pr : s->prof.pending[id]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                s->prof.total_ms[id] += ms;
+                s->prof.launches[id] += 1;
+            }
+            s->prof.pool.push_back(pr.first);
+            s->prof.pool.push_back(pr.second);
+        }
+        s->prof.pending[id].clear();
+        names[n] = kKernelNames[id];
+        total_ms[n] = s->prof.total_ms[id];
+        launches[n] = s->prof.launches[id];
+        s->prof.total_ms[id] = 0;
+        s->prof.launches[id] = 0;
+        ++n;
+    }
+    return n;
+}
+
+int clb_last_batch_stats(clb_searcher* s, int64_t* cand_docs, int64_t* cand_embs, int64_t* rescored_docs,
+                         int64_t* rescored_embs) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    CLB_TRY(use_device(s->device));
+    CLB_HIP(hipDeviceSynchronize());
+    // computed on demand from the device-side counts of the last batch
+    unsigned long long h[8] = {0};
+    if (s->stats.p) CLB_HIP(hipMemcpy(h, s->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    if (cand_docs) *cand_docs = (int64_t)h[0];
+    if (cand_embs) *cand_embs = (int64_t)h[1];
+    if (rescored_docs) *rescored_docs = (int64_t)h[2];
+    if (rescored_embs) *rescored_embs = (int64_t)h[3];
+    return CLB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,664 @@
+// search_kernels.hpp -- HIP kernels (gfx950) for ColBERT.jl's search path, exact variant.
+//
+// Reference stages:  S1 centroid scores (ranking.jl:27)  S2 top-nprobe (utils.jl:327-332,
+// ranking.jl:31-32)  S3 IVF union -> candidate pids (ranking.jl:7-21,35-43)  S4 gather (ranking.jl:46-67)
+// S5 decompress (residual.jl:698-784)  S6 maxsim (ranking.jl:69-86)  S7 sortperm + first k
+// (searching.jl:125-127).  S4-S6 are one fused kernel: nothing decompressed is ever written to HBM.
+//
+// Arithmetic follows the canonical order stated in oracle/colbert_oracle.h bit-for-bit:
+//   dot products  = d-ascending fmaf chains: gfx950's f32 MFMA (v_mfma_f32_32x32x2_f32 /
+//                   v_mfma_f32_16x16x4_f32) is exactly that chain when k is walked in order;
+//   sum of squares= 4 interleaved partial sums (d mod 4), products rounded before the add;
+//   x / (sqrtf(n2) + eps) with IEEE sqrt and divide (-fhip-fp32-correctly-rounded-divide-sqrt);
+//   maxsim        = per-token max over the passage, sequential sum over tokens.
+// Built with -ffp-contract=off so that no other multiply-add is fused behind our back.
+#pragma once
+#include "common.hpp"
+
+namespace clb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDim = 128;             // embedding dimension of the HIP search path
+constexpr int kCentTileStride = 132;  // dwords per staged centroid row: 16-B aligned, b128-conflict-free
+constexpr int kMaxTopK = 4096;        // k limit of the single-workgroup final sort
+
+// -------------------------------------------------------------------------------------------------
+// S1  cells[b][c][t] = dot(Q[b][:,t], C[:,c])            (ranking.jl:27  `Q' * centroids`)
+// One wave owns a 32-centroid x 32-token tile: v_mfma_f32_32x32x2_f32, 64 chained steps (k = d).
+// Centroid rows are staged through a wave-private LDS tile in full 512-B rows (coalesced dwordx4),
+// read back conflict-free with ds_read_b128 (row stride 132 dwords).  MFMA-bound: 2*32*128 flop per
+// centroid against 512 B read.
+// grid = (workgroups over centroid tiles, B * TT), block = 128 (2 waves), LDS = 2 * 32 * 132 * 4.
+// -------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(128) void centroid_scores_kernel(const float* __restrict__ C,
+                                                               const float* __restrict__ Q,
+                                                               float* __restrict__ cells, int K, int T,
+                                                               int TT, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y / TT, tt = blockIdx.y % TT;
+    const int Tpad = TT * 32;
+    float* my = lds + wave * (32 * kCentTileStride);
+
+    // B operand: lane (token i, half h) holds Q[t][2s+h], s = 0..63
+    float qf[64];
+    {
+        const int t = tt * 32 + i;
+        const float* qrow = Q + ((size_t)b * T + (t < T ? t : T - 1)) * kDim;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 v = *reinterpret_cast<const float4*>(qrow + 4 * m);
+            if (t >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[2 * m] = h ? v.y : v.x;
+            qf[2 * m + 1] = h ? v.w : v.z;
+        }
+    }
+    const int waves_total = gridDim.x * 2;
+    for (int tile = blockIdx.x * 2 + wave; tile < n_tiles; tile += waves_total) {
+        const int c0 = tile * 32;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int row = 2 * m + h;
+            int c = c0 + row;
+            c = c < K ? c : K - 1;
+            float4 v = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 4 * i);
+            *reinterpret_cast<float4*>(my + row * kCentTileStride + 4 * i) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 a4 = *reinterpret_cast<const float4*>(my + i * kCentTileStride + 4 * m);
+            const float a0 = h ? a4.y : a4.x;
+            const float a1 = h ? a4.w : a4.z;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qf[2 * m], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qf[2 * m + 1], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int c = c0 + row;
+            if (c < K) cells[((size_t)b * K + c) * Tpad + tt * 32 + i] = acc[r];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// S2  top-nprobe centroids per query token, ordered by (score desc, index asc) -- what
+// mapslices(partialsortperm(v, 1:nprobe, rev=true)) returns (utils.jl:327-332).
+// Stage a: each workgroup scans a slice of centroids for all tokens (coalesced rows of Tpad floats)
+// and writes one partial list per token.  Stage b merges the partial lists.
+// -------------------------------------------------------------------------------------------------
+struct ValIdx {
+    float v;
+    int i;
+};
+__device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
+
+template <int NP>
+__device__ __forceinline__ void topn_insert(float (&bv)[NP], int (&bi)[NP], float v, int idx) {
+    if (!better(v, idx, bv[NP - 1], bi[NP - 1])) return;
+    bv[NP - 1] = v;
+    bi[NP - 1] = idx;
+#pragma unroll
+    for (int p = NP - 1; p > 0; --p) {
+        if (better(bv[p], bi[p], bv[p - 1], bi[p - 1])) {
+            float tv = bv[p]; bv[p] = bv[p - 1]; bv[p - 1] = tv;
+            int ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
+        }
+    }
+}
+
+// grid = (NBLK, B), block = 256.  partial: [B][NBLK][Tpad][NP]
+template <int NP>
+static __global__ __launch_bounds__(256) void topn_partial_kernel(const float* __restrict__ cells,
+                                                           ValIdx* __restrict__ partial, int K, int Tpad) {
+    __shared__ ValIdx sh[256 * NP];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int t = threadIdx.x % Tpad, sub = threadIdx.x / Tpad, nsub = 256 / Tpad;
+    const int chunk = (K + nblk - 1) / nblk;
+    const int c_begin = blk * chunk, c_end = min(K, c_begin + chunk);
+    float bv[NP];
+    int bi[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { bv[p] = kNegInf; bi[p] = 0x7fffffff; }
+    const float* base = cells + (size_t)b * K * Tpad + t;
+    for (int c = c_begin + sub; c < c_end; c += nsub) topn_insert<NP>(bv, bi, base[(size_t)c * Tpad], c);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) sh[threadIdx.x * NP + p] = ValIdx{bv[p], bi[p]};
+    __syncthreads();
+    if (sub == 0) {
+        for (int s = 1; s < nsub; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                ValIdx x = sh[(s * Tpad + t) * NP + p];
+                topn_insert<NP>(bv, bi, x.v, x.i);
+            }
+        ValIdx* out = partial + (((size_t)b * nblk + blk) * Tpad + t) * NP;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) out[p] = ValIdx{bv[p], bi[p]};
+    }
+}
+
+// grid = B, block = Tpad.  sel: [B][Tpad][NP] centroid ids (0-based)
+template <int NP>
+static __global__ void topn_final_kernel(const ValIdx* __restrict__ partial, int* __restrict__ sel, int nblk,
+                                  int Tpad) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float bv[NP];
+    int bi[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { bv[p] = kNegInf; bi[p] = 0x7fffffff; }
+    for (int blk = 0; blk < nblk; ++blk) {
+        const ValIdx* in = partial + (((size_t)b * nblk + blk) * Tpad + t) * NP;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) topn_insert<NP>(bv, bi, in[p].v, in[p].i);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) sel[((size_t)b * Tpad + t) * NP + p] = bi[p];
+}
+
+// -------------------------------------------------------------------------------------------------
+// S3  candidate pids = sort(unique(emb2pid[ union of the selected centroids' IVF lists ]))
+// (ranking.jl:32-43).  The IVF is stored as passage ids (emb2pid applied once at load), the union is
+// a bitmap over the shard's passages (atomicOr), and the ascending pid list falls out of a bitmap
+// compaction -- no sort.  grid = (T*nprobe, B), block = 256.
+// -------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void mark_candidates_kernel(const int* __restrict__ sel,
+                                                              const uint32_t* __restrict__ ivf_off,
+                                                              const uint32_t* __restrict__ ivf_pid,
+                                                              uint32_t* __restrict__ bitmap, int T,
+                                                              int Tpad, int NP, int nprobe, int W) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x / nprobe, p = blockIdx.x % nprobe;
+    const int* s = sel + (size_t)b * Tpad * NP;
+    const int cid = s[t * NP + p];
+    // the same centroid selected by an earlier (token, rank): its list is already being marked
+    for (int e = 0; e < (int)blockIdx.x; ++e)
+        if (s[(e / nprobe) * NP + (e % nprobe)] == cid) return;
+    (void)T;
+    uint32_t* bm = bitmap + (size_t)b * W;
+    const uint32_t lo = ivf_off[cid], hi = ivf_off[cid + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t pid = ivf_pid[i];
+        atomicOr(&bm[pid >> 5], 1u << (pid & 31));
+    }
+}
+
+constexpr int kScanBlock = 256;      // threads
+constexpr int kWordsPerThread = 4;   // bitmap words per thread in count/emit
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* sh /*>=8 ints*/, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    int base = 0;
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int s = sh[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+// grid = (nblk, B)
+static __global__ __launch_bounds__(kScanBlock) void bitmap_count_kernel(const uint32_t* __restrict__ bitmap,
+                                                                  int* __restrict__ blocksum, int W) {
+    __shared__ int sh[8];
+    const int b = blockIdx.y;
+    const uint32_t* bm = bitmap + (size_t)b * W;
+    const int w0 = (blockIdx.x * kScanBlock + threadIdx.x) * kWordsPerThread;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kWordsPerThread; ++j)
+        if (w0 + j < W) cnt += __popc(bm[w0 + j]);
+    int total;
+    (void)block_exclusive_scan_256(cnt, sh, total);
+    if (threadIdx.x == 0) blocksum[(size_t)b * gridDim.x + blockIdx.x] = total;
+}
+
+// grid = B, block = 256: exclusive scan of the block sums (in place), total -> ncand[b]
+static __global__ __launch_bounds__(kScanBlock) void bitmap_scan_kernel(int* __restrict__ blocksum,
+                                                                 int* __restrict__ ncand, int nblk) {
+    __shared__ int sh[8];
+    const int b = blockIdx.x;
+    int* bs = blocksum + (size_t)b * nblk;
+    int running = 0;
+    for (int base = 0; base < nblk; base += kScanBlock) {
+        const int idx = base + threadIdx.x;
+        const int v = idx < nblk ? bs[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, sh, total);
+        if (idx < nblk) bs[idx] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) ncand[b] = running;
+}
+
+// grid = (nblk, B): emit ascending local pids (0-based) and clear the bitmap for the next query
+static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t* __restrict__ bitmap,
+                                                                 const int* __restrict__ blockoff,
+                                                                 uint32_t* __restrict__ cand, int W,
+                                                                 size_t cand_cap) {
+    __shared__ int sh[8];
+    const int b = blockIdx.y;
+    uint32_t* bm = bitmap + (size_t)b * W;
+    const int w0 = (blockIdx.x * kScanBlock + threadIdx.x) * kWordsPerThread;
+    uint32_t w[kWordsPerThread];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kWordsPerThread; ++j) {
+        w[j] = (w0 + j < W) ? bm[w0 + j] : 0u;
+        cnt += __popc(w[j]);
+    }
+    int total;
+    int pos = block_exclusive_scan_256(cnt, sh, total) + blockoff[(size_t)b * gridDim.x + blockIdx.x];
+    uint32_t* out = cand + (size_t)b * cand_cap;
+#pragma unroll
+    for (int j = 0; j < kWordsPerThread; ++j) {
+        uint32_t x = w[j];
+        if (x) bm[w0 + j] = 0u;
+        while (x) {
+            const int bit = __ffs((int)x) - 1;
+            x &= x - 1;
+            if ((size_t)pos < cand_cap) out[pos] = (uint32_t)((w0 + j) * 32 + bit);
+            ++pos;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// S4+S5+S6 fused, exact: for every candidate passage gather its packed codes/residuals, decompress
+// (centroid + bucket weight, L2-normalise), Q'D on the f32 MFMA, per-token max over the passage,
+// sequential sum over tokens.  (ranking.jl:46-86, residual.jl:698-784, utils.jl:320-325)
+//
+// One wave per passage, 16 embeddings per step (v_mfma_f32_16x16x4_f32: rows = embeddings,
+// cols = query tokens, k = 4 consecutive dims).  Lane (r = lane&15, g = lane>>4) owns dims 4s+g of
+// embedding r, s = 0..31 -- exactly one of the four interleaved partial sums of the canonical norm.
+// grid = (G, B), block = 256 (4 waves).
+// -------------------------------------------------------------------------------------------------
+template <int NBITS>
+__device__ __forceinline__ float bucket_weight(uint32_t idx, const float (&w)[4], float wlane) {
+    if constexpr (NBITS == 1) {
+        return idx ? w[1] : w[0];
+    } else if constexpr (NBITS == 2) {
+        const float lo = (idx & 1) ? w[1] : w[0];
+        const float hi = (idx & 1) ? w[3] : w[2];
+        return (idx & 2) ? hi : lo;
+    } else {
+        return __shfl(wlane, (int)idx, 64);  // table spread over lanes 0..2^NBITS-1
+    }
+}
+
+// Decompresses the 32 dims {4s+g} of one embedding and L2-normalises; returns the values in x[].
+// R = the embedding's packed residual as dwords (NBITS*4 of them).
+template <int NBITS>
+__device__ __forceinline__ void decompress_lane_dims(const float* __restrict__ cent_row /*+g*/,
+                                                     const uint32_t (&R)[NBITS * 4], int g,
+                                                     const float (&w)[4], float wlane, float (&x)[32]) {
+    float p = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int bitpos = 4 * s * NBITS;  // + g*NBITS at run time; never crosses a dword
+        const uint32_t idx = (R[bitpos >> 5] >> ((bitpos & 31) + g * NBITS)) & ((1u << NBITS) - 1u);
+        const float v = cent_row[4 * s] + bucket_weight<NBITS>(idx, w, wlane);
+        x[s] = v;
+        const float sq = v * v;
+        p = p + sq;
+    }
+    // (p0+p1)+(p2+p3): partners differ in g, i.e. lane^16 and lane^32
+    const float a = p + __shfl_xor(p, 16, 64);
+    const float n2 = a + __shfl_xor(a, 32, 64);
+    const float den = sqrtf(n2) + FLT_EPSILON;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) x[s] = x[s] / den;
+}
+
+template <int NBITS>
+static __global__ __launch_bounds__(256) void score_exact_kernel(
+    const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
+    const uint8_t* __restrict__ residuals, const uint32_t* __restrict__ doc_off,
+    const float* __restrict__ Q, const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
+    float* __restrict__ scores, int T, size_t cand_cap, const int* __restrict__ list /*optional*/,
+    const int* __restrict__ nlist) {
+    constexpr int RD = NBITS * 4;  // residual dwords per embedding
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int n = list ? nlist[b] : ncand[b];
+    const int TT = (T + 31) >> 5;
+
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    float wlane = 0.f;
+    if constexpr (NBITS <= 2) {
+#pragma unroll
+        for (int j = 0; j < (1 << NBITS); ++j) w[j] = weights[j];
+    } else {
+        wlane = lane < (1 << NBITS) ? weights[lane] : 0.f;
+    }
+    const uint32_t* cnd = cand + (size_t)b * cand_cap;
+    const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
+
+    for (int j = wave_global; j < n; j += nwaves) {
+        const int slot = lst ? lst[j] : j;  // index into the candidate array
+        const uint32_t pid0 = cnd[slot];
+        const uint32_t off = doc_off[pid0];
+        const int len = (int)(doc_off[pid0 + 1] - off);
+        float total = 0.f;
+        for (int tt = 0; tt < TT; ++tt) {
+            // B operands: lane (token r, k = g) holds Q[t][4s+g] for t = 32tt + r and 32tt + 16 + r
+            float q0[32], q1[32];
+            {
+                const int t0 = tt * 32 + r, t1 = t0 + 16;
+                const float* qa = Q + ((size_t)b * T + (t0 < T ? t0 : T - 1)) * kDim + g;
+                const float* qb = Q + ((size_t)b * T + (t1 < T ? t1 : T - 1)) * kDim + g;
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    q0[s] = t0 < T ? qa[4 * s] : 0.f;
+                    q1[s] = t1 < T ? qb[4 * s] : 0.f;
+                }
+            }
+            float m0 = kNegInf, m1 = kNegInf;
+            for (int base = 0; base < len; base += 16) {
+                const int el = base + r;
+                const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
+                const uint32_t code = codes0[e];
+                uint32_t R[RD];
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * (RD * 4));
+#pragma unroll
+                for (int k4 = 0; k4 < RD; k4 += 4) {
+                    uint4 v = *reinterpret_cast<const uint4*>(rp + k4);
+                    R[k4] = v.x; R[k4 + 1] = v.y; R[k4 + 2] = v.z; R[k4 + 3] = v.w;
+                }
+                float x[32];
+                decompress_lane_dims<NBITS>(C + (size_t)code * kDim + g, R, g, w, wlane, x);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], q0[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], q1[s], a1, 0, 0, 0);
+                }
+                // accumulator rows: embedding base + 4*g + reg ; cols: token r
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = base + 4 * g + q < len;
+                    m0 = ok ? fmaxf(m0, a0[q]) : m0;
+                    m1 = ok ? fmaxf(m1, a1[q]) : m1;
+                }
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+            // sequential sum over tokens (ranking.jl:83 `sum(maximum(..., dims=2))`)
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const float v = __shfl(t < 16 ? m0 : m1, t & 15, 64);
+                if (tt * 32 + t < T) total = total + v;
+            }
+        }
+        if (lane == 0) scores[(size_t)b * cand_cap + slot] = total;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// S7  indices = sortperm(scores, rev=true) ; first k     (searching.jl:125-127)
+// The sort is stable, so ties keep ascending candidate order = ascending pid.  One workgroup per
+// query: radix-select the k-th largest score, ordered compaction of {score > tau} plus the first
+// (k - count_gt) of {score == tau}, bitonic sort of those k by (score desc, index asc).
+// When `list` is given, only the listed candidate slots take part (two-pass mode).
+// grid = B, block = 1024, LDS = 8 * next_pow2(k) + small.
+// -------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores,
+                                                    const uint32_t* __restrict__ cand,
+                                                    const int* __restrict__ ncand,
+                                                    const int* __restrict__ list,
+                                                    const int* __restrict__ nlist, int k, int kpow2,
+                                                    size_t cand_cap, int64_t pid_offset,
+                                                    int64_t* __restrict__ out_pids,
+                                                    float* __restrict__ out_scores,
+                                                    int* __restrict__ short_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // kpow2 entries
+    __shared__ int hist[256];
+    __shared__ int sh_scan[32];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining, s_run_sel, s_run_eq;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = list ? nlist[b] : ncand[b];
+    const float* sc = scores + (size_t)b * cand_cap;
+    const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
+    const int keff = n < k ? n : k;
+    if (tid == 0 && n < k) short_flag[b] = 1;
+
+    // ---- radix select: tau = keff-th largest key -------------------------------------------------
+    if (tid == 0) { s_prefix = 0u; s_remaining = keff; }
+    __syncthreads();
+    if (keff > 0) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < n; i += 1024) {
+                const uint32_t key = f32_order_key(sc[lst ? lst[i] : i]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining, d = 255;
+                for (; d > 0; --d) {
+                    if (hist[d] >= rem) break;
+                    rem -= hist[d];
+                }
+                s_prefix = prefix | ((uint32_t)d << shift);
+                s_remaining = rem;
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t tau = s_prefix;
+    const int need_eq = s_remaining;  // how many of the == tau entries to take, lowest index first
+
+    // ---- ordered compaction ---------------------------------------------------------------------
+    for (int i = tid; i < kpow2; i += 1024) skeys[i] = 0ull;
+    if (tid == 0) { s_run_sel = 0; s_run_eq = 0; }
+    __syncthreads();
+    if (keff > 0) {
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            uint32_t key = 0;
+            int slot = 0;
+            bool gt = false, eq = false;
+            if (i < n) {
+                slot = lst ? lst[i] : i;
+                key = f32_order_key(sc[slot]);
+                gt = key > tau;
+                eq = key == tau;
+            }
+            // packed scan: low 16 bits = eq count, high 16 bits = gt count
+            int v = (gt ? (1 << 16) : 0) | (eq ? 1 : 0);
+            const int lane = tid & 63, wave = tid >> 6;
+            int x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) sh_scan[wave] = x;
+            __syncthreads();
+            int wbase = 0, tot = 0;
+            for (int w2 = 0; w2 < 16; ++w2) {
+                const int s = sh_scan[w2];
+                if (w2 < wave) wbase += s;
+                tot += s;
+            }
+            const int ex = wbase + x - v;
+            const int eq_rank = s_run_eq + (ex & 0xffff);
+            const int gt_before = s_run_sel + (ex >> 16);
+            // position = (#gt before) + (#eq taken before) ; eq taken before = min(eq_rank, need_eq)
+            const bool take = gt || (eq && eq_rank < need_eq);
+            if (take) {
+                const int pos = gt_before + (eq_rank < need_eq ? eq_rank : need_eq);
+                // slot ascends with i, so ~slot makes lower index = larger key on equal scores
+                skeys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
+            }
+            __syncthreads();
+            if (tid == 0) { s_run_sel += tot >> 16; s_run_eq += tot & 0xffff; }
+            __syncthreads();
+        }
+    }
+    // ---- bitonic sort, descending -----------------------------------------------------------------
+    for (int size = 2; size <= kpow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (kpow2 >> 1); i += 1024) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = skeys[lo], c = skeys[hi];
+                if ((a < c) == desc) { skeys[lo] = c; skeys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t* cnd = cand + (size_t)b * cand_cap;
+    for (int i = tid; i < k; i += 1024) {
+        int64_t pid = 0;
+        float s = kNegInf;
+        if (i < keff) {
+            const unsigned long long key = skeys[i];
+            const uint32_t slot = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+            pid = pid_offset + (int64_t)cnd[slot] + 1;
+            s = sc[slot];
+        }
+        out_pids[(size_t)b * k + i] = pid;
+        out_scores[(size_t)b * k + i] = s;
+    }
+}
+
+// ---- load-time helpers ---------------------------------------------------------------------------
+// ivf (1-based embedding ids) -> local passage ids via binary search in doc_off (emb2pid, searching.jl:82-91)
+static __global__ void ivf_to_pid_kernel(const int64_t* __restrict__ ivf, const uint32_t* __restrict__ doc_off,
+                                  uint32_t* __restrict__ ivf_pid, int64_t n_emb, int n_docs,
+                                  int* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_emb) return;
+    const int64_t eid = ivf[i] - 1;
+    if (eid < 0 || eid >= n_emb) { atomicOr(err, 1); ivf_pid[i] = 0; return; }
+    int lo = 0, hi = n_docs;  // largest p with doc_off[p] <= eid
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)doc_off[mid] <= eid) lo = mid; else hi = mid;
+    }
+    ivf_pid[i] = (uint32_t)lo;
+}
+
+// codes: 1-based -> 0-based, range check (decompress's DomainError, residual.jl:766-768)
+static __global__ void codes_to_zero_based_kernel(uint32_t* __restrict__ codes, int64_t n, uint32_t K,
+                                           int* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = codes[i];
+    if (c < 1u || c > K) { atomicOr(err, 2); codes[i] = 0; } else codes[i] = c - 1u;
+}
+
+static __global__ void widen_counts_kernel(const int* __restrict__ in, int64_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// work counters of one batch: [0] candidate passages, [1] candidate embeddings, [2] passages in the
+// exact re-score list, [3] their embeddings.  grid = (32, B), block = 256.
+static __global__ void batch_stats_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
+                                   const int* __restrict__ list, const int* __restrict__ nlist,
+                                   const uint32_t* __restrict__ doc_off, size_t cand_cap,
+                                   unsigned long long* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const uint32_t* cnd = cand + (size_t)b * cand_cap;
+    unsigned long long embs = 0, lembs = 0;
+    const int n = ncand[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = cnd[i];
+        embs += doc_off[p + 1] - doc_off[p];
+    }
+    const int nl = list ? nlist[b] : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
+        const uint32_t p = cnd[list[(size_t)b * cand_cap + i]];
+        lembs += doc_off[p + 1] - doc_off[p];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        embs += __shfl_down(embs, o, 64);
+        lembs += __shfl_down(lembs, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (embs) atomicAdd(&stats[1], embs);
+        if (lembs) atomicAdd(&stats[3], lembs);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[0], (unsigned long long)n);
+        atomicAdd(&stats[2], (unsigned long long)nl);
+    }
+}
+
+// Cross-shard merge of sorted top-k lists (the final sortperm of search(), searching.jl:125-127, applied
+// to the union of the shards' results).  in: [n_lists][B][k] records sorted by (score desc, pid asc),
+// padded with (0, -Inf).  Every record finds its rank in the merged order by binary search in the other
+// lists (pids are unique across shards, so ranks are unique).  grid = (ceil(n_lists*k/256), B).
+__device__ __forceinline__ bool rec_before(float s, int64_t p, float s2, int64_t p2) {
+    return s > s2 || (s == s2 && p < p2);
+}
+static __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restrict__ pids,
+                                                         const float* __restrict__ scores, int k, int n_lists,
+                                                         int B, int64_t* __restrict__ out_pids,
+                                                         float* __restrict__ out_scores) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lists * k) return;
+    const int l = idx / k, i = idx % k;
+    const size_t me = ((size_t)l * B + b) * k + i;
+    const int64_t p = pids[me];
+    const float s = scores[me];
+    if (p <= 0) return;  // padding
+    int rank = i;
+    for (int l2 = 0; l2 < n_lists; ++l2) {
+        if (l2 == l) continue;
+        const size_t base = ((size_t)l2 * B + b) * k;
+        int lo = 0, hi = k;  // number of records of list l2 that come before (s, p)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int64_t p2 = pids[base + mid];
+            const float s2 = scores[base + mid];
+            if (p2 > 0 && rec_before(s2, p2, s, p)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank < k) {
+        out_pids[(size_t)b * k + rank] = p;
+        out_scores[(size_t)b * k + rank] = s;
+    }
+}
+static __global__ void fill_pad_kernel(int64_t* __restrict__ pids, float* __restrict__ scores, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { pids[i] = 0; scores[i] = kNegInf; }
+}
+
+}  // namespace clb

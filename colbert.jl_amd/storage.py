@@ -1,0 +1,80 @@
+"""Index directory I/O.  The reference writes JLD2 (HDF5) + JSON files (src/savers.jl, src/loaders.jl);
+this host driver keeps the reference's file stems and JSON files but stores arrays as .npy (the Julia
+shim goes through JLD2.jl instead).  A JLD2-compatible reader/writer is listed as next work in DESIGN.md.
+
+Files: config.json, plan.json, centroids / bucket_cutoffs / bucket_weights /
+avg_residual, <i>.codes, <i>.residuals, doclens.<i>, <i>.metadata.json, ivf, ivf_lengths (chunks 1-based)."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+
+def _save(path: str, a) -> None:
+    np.save(path + ".npy", np.asarray(a))
+
+
+def _load(path: str):
+    return np.load(path + ".npy")
+
+
+def save_codec(index_path, centroids, bucket_cutoffs, bucket_weights, avg_residual) -> None:
+    """save_codec (savers.jl:16-29)"""
+    os.makedirs(index_path, exist_ok=True)
+    _save(os.path.join(index_path, "centroids"), np.asfortranarray(centroids, dtype=np.float32))
+    _save(os.path.join(index_path, "bucket_cutoffs"), np.asarray(bucket_cutoffs, dtype=np.float32))
+    _save(os.path.join(index_path, "bucket_weights"), np.asarray(bucket_weights, dtype=np.float32))
+    _save(os.path.join(index_path, "avg_residual"), np.float32(avg_residual))
+
+
+def save_chunk(index_path, codes, residuals, chunk_idx: int, passage_offset: int, doclens) -> None:
+    """save_chunk (savers.jl:52-84); chunk_idx and passage_offset are 1-based"""
+    _save(os.path.join(index_path, f"{chunk_idx}.codes"), np.asarray(codes, dtype=np.uint32))
+    _save(os.path.join(index_path, f"{chunk_idx}.residuals"), np.asfortranarray(residuals, dtype=np.uint8))
+    _save(os.path.join(index_path, f"doclens.{chunk_idx}"), np.asarray(doclens, dtype=np.int64))
+    with open(os.path.join(index_path, f"{chunk_idx}.metadata.json"), "w") as f:
+        json.dump({"passage_offset": int(passage_offset), "num_passages": int(len(doclens)),
+                   "num_embeddings": int(len(codes))}, f, indent=4)
+
+
+def save_json(index_path, name, obj) -> None:
+    with open(os.path.join(index_path, name), "w") as f:
+        json.dump(obj, f, indent=4)
+
+
+def load_json(index_path, name):
+    with open(os.path.join(index_path, name)) as f:
+        return json.load(f)
+
+
+def check_all_files_are_saved(index_path: str) -> bool:
+    """_check_all_files_are_saved (collection_indexer.jl:299-340)"""
+    if not os.path.isfile(os.path.join(index_path, "plan.json")):
+        return False
+    plan = load_json(index_path, "plan.json")
+    files = ["config.json"] + [s + ".npy" for s in ("centroids", "bucket_cutoffs", "bucket_weights", "avg_residual",
+                                                    "ivf", "ivf_lengths")]
+    for i in range(1, plan["num_chunks"] + 1):
+        files += [f"{i}.codes.npy", f"{i}.residuals.npy", f"doclens.{i}.npy", f"{i}.metadata.json"]
+    return all(os.path.isfile(os.path.join(index_path, f)) for f in files)
+
+
+def load_index(index_path: str) -> dict:
+    """load_codec / load_doclens / load_compressed_embs (loaders.jl:10-38, 76-113) + ivf files."""
+    plan = load_json(index_path, "plan.json")
+    cfg = load_json(index_path, "config.json")
+    codes, res, dl = [], [], []
+    for i in range(1, plan["num_chunks"] + 1):
+        codes.append(_load(os.path.join(index_path, f"{i}.codes")))
+        res.append(_load(os.path.join(index_path, f"{i}.residuals")))
+        dl.append(_load(os.path.join(index_path, f"doclens.{i}")))
+    return {"dim": cfg["dim"], "nbits": cfg["nbits"],
+            "centroids": _load(os.path.join(index_path, "centroids")),
+            "bucket_cutoffs": _load(os.path.join(index_path, "bucket_cutoffs")),
+            "bucket_weights": _load(os.path.join(index_path, "bucket_weights")),
+            "avg_residual": _load(os.path.join(index_path, "avg_residual")),
+            "codes": np.concatenate(codes), "residuals": np.asfortranarray(np.concatenate(res, axis=1)),
+            "doclens": np.concatenate(dl), "ivf": _load(os.path.join(index_path, "ivf")),
+            "ivf_lengths": _load(os.path.join(index_path, "ivf_lengths"))}

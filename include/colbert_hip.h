@@ -1,0 +1,159 @@
+/*
+ * colbert_hip.h -- C ABI of libcolbert_hip.so, the MI355X (gfx950) implementation of ColBERT.jl's
+ * hot path: candidate generation + fused decompress/MaxSim + top-k (src/search, src/searching.jl),
+ * the residual codec and index-build kernels (src/indexing, src/utils.jl) and the encoder epilogue
+ * (src/modelling/embedding_utils.jl).
+ *
+ * The reference (pure Julia) has no FFI of its own; each entry point below replaces the Julia call
+ * site cited next to it, and `julia/ColBERT/src/ColBERT.jl` + INTEGRATION.md show the `ccall`
+ * binding a maintainer adds.  Conventions are the reference's:
+ *   - matrices are column-major and densely packed (a Julia Array's memory, passed as Ptr{T});
+ *   - centroid codes, pids and embedding ids are 1-based; Int is int64_t;
+ *   - element types: float (Float32), uint32_t codes, uint8_t packed residuals, int64_t doclens/pids/ivf.
+ * Ownership: the caller owns every host buffer; the library copies in/out before returning and never
+ * retains a host pointer.  All device memory belongs to the library (handles are opaque).
+ * Threading: every call is synchronous (results are in the output buffers on return) except the
+ * *_device entry points, which enqueue on the given HIP stream.  One handle, one thread at a time.
+ * Errors: every function returns 0 or a CLB_E* code; codes 1..4 map 1:1 onto the Julia exception the
+ * reference throws in the same situation.  clb_last_error() returns a message for the calling thread.
+ * There is NO CPU fallback: without a GPU every compute entry point fails with CLB_EHIP.
+ */
+#ifndef COLBERT_HIP_H
+#define COLBERT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLB_OK 0
+#define CLB_EDIMENSION 1   /* DimensionMismatch */
+#define CLB_EDOMAIN 2      /* DomainError */
+#define CLB_EBOUNDS 3      /* BoundsError */
+#define CLB_EARGUMENT 4    /* ArgumentError */
+#define CLB_EHIP 10        /* HIP runtime failure / no device */
+#define CLB_EUNSUPPORTED 11/* valid for the reference, not implemented by the HIP path */
+#define CLB_ENOMEM 12
+
+typedef struct clb_searcher clb_searcher;
+
+const char* clb_version(void);
+const char* clb_last_error(void);
+/* number of visible HIP devices (0 without a GPU); never initialises a device */
+int clb_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Searcher: the resident index  (struct Searcher, src/searching.jl:1-16; Searcher(index_path) :18-80,
+ * _build_emb2pid :82-91).  The arrays are the fields the reference keeps on the host; here they are
+ * uploaded once into HBM.  `pid_offset` is added to every returned pid (0 for an unsharded index;
+ * for a passage shard, the number of passages in the shards before it).
+ * ---------------------------------------------------------------------------------------------- */
+int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K,
+                        const float* centroids /* (dim,K) */, const float* bucket_weights /* 2^nbits */,
+                        int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                        const uint32_t* codes /* n_emb, 1-based */,
+                        const uint8_t* residuals /* (dim/8*nbits, n_emb) */,
+                        const int64_t* ivf /* n_emb, 1-based embedding ids */,
+                        const int64_t* ivf_lengths /* K */, int64_t pid_offset,
+                        clb_searcher** out);
+int clb_searcher_destroy(clb_searcher* s);
+/* bytes of HBM held by the handle (index + workspace) */
+int64_t clb_searcher_device_bytes(const clb_searcher* s);
+
+/* search(searcher, query, k) after the encoder  (src/searching.jl:102-127):
+ * retrieve -> gather -> decompress -> maxsim -> stable sortperm(rev=true) -> first k.
+ * Q is (dim, T) for one query.  out_pids/out_scores have k entries.  Fewer than k candidates is the
+ * reference's BoundsError (searching.jl:127) -> CLB_EBOUNDS.  *n_cand receives the candidate count. */
+int clb_search(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t k,
+               int64_t* out_pids, float* out_scores, int64_t* n_cand);
+/* B queries at once: Q is (dim, T, B); out_pids/out_scores are (k, B); n_cand has B entries.
+ * pad_short != 0: a query with fewer than k candidates is not an error; its tail is filled with
+ * pid 0 and score -Inf (what a passage shard needs before the cross-shard merge). */
+int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                     int pad_short, int64_t* out_pids, float* out_scores, int64_t* n_cand);
+/* Same, device-resident: every pointer is a device pointer on the searcher's device; the work is
+ * enqueued on `hip_stream` (a hipStream_t; NULL = the searcher's own stream) and not waited for.
+ * Always pads short results (pid 0, -Inf).  Used by the multi-GPU driver and bench.py. */
+int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                            int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
+                            void* hip_stream);
+/* 0: exact single pass (every candidate scored with the canonical fp32 arithmetic);
+ * 1: two-pass (bf16-MFMA approximate pass with a proven error bound selects a superset of the top-k,
+ *    which is then re-scored exactly) -- results are identical by construction.  Default 1 when the
+ *    index shape supports it (dim 128, nbits 2), else 0. */
+int clb_searcher_set_mode(clb_searcher* s, int mode);
+int clb_searcher_get_mode(const clb_searcher* s);
+
+/* retrieve()  (src/search/ranking.jl:23-44) on its own -- test hook.  out_pids needs n_docs entries. */
+int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
+                 int64_t* n_out);
+
+/* Merge per-shard top-k lists (device pointers): `n_lists` lists of k (pid, score) records per query,
+ * each sorted by (score desc, pid asc) and padded with (0, -Inf).  Input layout [n_lists][B][k] (k
+ * fastest) -- what an all-gather of every rank's (k, B) result produces; output (k, B).  Replaces the
+ * final sortperm of search() across passage shards (searching.jl:125-127). */
+int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scores, int64_t k,
+                          int64_t n_lists, int64_t B, int64_t* d_out_pids, float* d_out_scores,
+                          void* hip_stream);
+
+/* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's roofline).
+ * enable, run searches, then read: names[i] (static strings), total milliseconds and launch counts.
+ * Returns the number of entries written (<= cap). */
+int clb_profile_enable(clb_searcher* s, int on);
+int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int64_t* launches, int cap);
+/* per-kernel work counters of the last batch: candidate passages / candidate embeddings summed over
+ * the batch, and embeddings re-scored by the exact pass */
+int clb_last_batch_stats(clb_searcher* s, int64_t* cand_docs, int64_t* cand_embs, int64_t* rescored_docs,
+                         int64_t* rescored_embs);
+
+/* ------------------------------------------------------------------------------------------------
+ * Codec and ranking pieces as stand-alone calls (host buffers, run on `device`).
+ * ---------------------------------------------------------------------------------------------- */
+/* decompress  (src/indexing/codecs/residual.jl:759-784) ; out is (dim, n) */
+int clb_decompress(int device, int64_t dim, int nbits, const float* centroids, int64_t K,
+                   const float* bucket_weights, int64_t n_weights, const uint32_t* codes, int64_t n_codes,
+                   const uint8_t* residuals, int64_t res_rows, int64_t res_cols, float* out);
+/* maxsim  (src/search/ranking.jl:69-86) ; D is (dim, n_D) */
+int clb_maxsim(int device, const float* Q, int64_t dim, int64_t T, const float* D, int64_t n_D,
+               const int64_t* pids, int64_t n_pids, const int64_t* doclens, int64_t n_docs, float* scores);
+/* compress_into_codes!  (residual.jl:67-81) */
+int clb_compress_into_codes(int device, uint32_t* codes, int64_t n_codes, const float* centroids,
+                            int64_t dim, int64_t K, const float* embs, int64_t n);
+/* compress  (residual.jl:586-604) : codes + packed residuals */
+int clb_compress(int device, const float* centroids, int64_t K, const float* bucket_cutoffs,
+                 int64_t n_cutoffs, int64_t dim, int nbits, const float* embs, int64_t n,
+                 uint32_t* codes, uint8_t* residuals);
+/* _normalize_array!(X, dims=1)  (src/utils.jl:320-325) */
+int clb_normalize_columns(int device, float* X, int64_t dim, int64_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index build  (src/utils.jl:253-318, src/indexing/collection_indexer.jl)
+ * ---------------------------------------------------------------------------------------------- */
+/* kmeans_gpu_onehot!  (utils.jl:253-318) with the random initial centroids (utils.jl:261) supplied by
+ * the caller in `centroids` (in/out, (dim,K)).  assignments: Int32[n], 1-based. */
+int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* centroids, int64_t K,
+               int64_t max_iters, float tol, int64_t point_bsize, int32_t* assignments,
+               int64_t* iters_done);
+/* _compute_avg_residuals!  (collection_indexer.jl:177-195) incl. _bucket_cutoffs_and_weights :141-152 */
+int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int64_t dim, int64_t K,
+                              const float* heldout, int64_t n, uint32_t* codes, int64_t n_codes,
+                              float* bucket_cutoffs, float* bucket_weights, float* avg_residual);
+/* _build_ivf  (collection_indexer.jl:349-353) */
+int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64_t* ivf,
+                  int64_t* ivf_lengths);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder epilogue  (src/modelling/checkpoint.jl:27-71, embedding_utils.jl:172-205)
+ * ---------------------------------------------------------------------------------------------- */
+/* _doc_embeddings_and_doclens after doc(): clear skiplist tokens, normalise, doclens, compaction.
+ * D (dim, L, N) is read only; out (dim, <= L*N); doclens Int64[N]; *n_out = kept columns. */
+int clb_doc_epilogue(int device, const float* D, int64_t dim, int64_t L, int64_t N,
+                     const int32_t* integer_ids, const int64_t* skiplist, int64_t n_skip, float* out,
+                     int64_t* doclens, int64_t* n_out);
+/* _query_embeddings after doc(): clear skiplist tokens, normalise (in place). */
+int clb_query_epilogue(int device, float* Q, int64_t dim, int64_t L, int64_t N,
+                       const int32_t* integer_ids, const int64_t* skiplist, int64_t n_skip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, refuses to compute without a GPU (no CPU fallback), and the host-side mirrors of the
+reference's planning helpers agree with the oracle.  No compute calls here."""
+import os
+
+import numpy as np
+import pytest
+
+import colbert_jl_amd as clb
+
+
+def test_library_exports_every_declared_symbol():
+    l = clb.lib()
+    syms = clb.declared_symbols()
+    assert len(syms) >= 20
+    assert [s for s in syms if not hasattr(l, s)] == []
+    assert b"gfx950" in l.clb_version()
+
+
+def test_no_cpu_fallback():
+    if clb.lib().clb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(clb.HipError):
+        clb.codec._normalize_array(np.ones((8, 2), np.float32))
+    idx = clb.synthetic.make_index(0, 20, K=8)
+    with pytest.raises(clb.HipError):
+        clb.Searcher(index=idx)
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.abspath(clb.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("from oracle", "import oracle", "libcolbert_oracle", '#include "colbert_oracle',
+                               "#include <colbert_oracle", "orc_"):
+                    assert needle not in text, (f, needle)
+
+
+def test_argument_contracts_without_gpu():
+    """Checks that run before any device work mirror the reference's exceptions."""
+    idx = clb.synthetic.make_index(0, 20, K=8)
+    bad = dict(idx); bad["ivf"] = idx["ivf"][:-1]; bad["ivf_lengths"] = idx["ivf_lengths"].copy()
+    bad["ivf_lengths"][0] += 0
+    with pytest.raises((clb.DimensionMismatch, clb.ColBERTError)):
+        # length(ivf) must equal sum(ivf_lengths)  (ranking.jl:11-12)
+        bad2 = dict(idx); bad2["ivf_lengths"] = idx["ivf_lengths"].copy(); bad2["ivf_lengths"][0] += 1
+        clb.Searcher(index=bad2)
+    with pytest.raises(clb.DomainError):                      # residual.jl:763-765
+        clb.codec.decompress(128, 2, idx["centroids"], idx["bucket_weights"], idx["codes"][:-1], idx["residuals"])
+    with pytest.raises(clb.DomainError):                      # residual.jl:766-768
+        c = idx["codes"].copy(); c[0] = 9
+        clb.codec.decompress(128, 2, idx["centroids"], idx["bucket_weights"], c, idx["residuals"])
+    with pytest.raises(clb.DomainError):                      # residual.jl:705-706
+        clb.codec.decompress(128, 2, idx["centroids"], idx["bucket_weights"][:3], idx["codes"], idx["residuals"])
+    with pytest.raises(clb.DimensionMismatch):                # residual.jl:72-74
+        clb.codec.compress_into_codes(idx["centroids"], np.zeros((128, 5), np.float32), n_codes=4)
+    with pytest.raises(clb.DimensionMismatch):                # ranking.jl:71-74
+        clb.codec.maxsim(np.eye(2, dtype=np.float32), np.array([[0.8, 0.3], [0.2, 0.7]], np.float32)[:, :1], [1, 2], [1, 2])
+    with pytest.raises(clb.DomainError):                      # residual.jl:520
+        clb.codec.compress(np.zeros((7, 2), np.float32), np.zeros(1, np.float32), 7, 1, np.zeros((7, 3), np.float32))
+
+
+def test_host_planning_helpers_match_oracle(oracle):
+    for n in (1, 10, 1000, 141431, 10 ** 6):
+        assert clb.codec.num_sampled_pids(n) == oracle.num_sampled_pids(n)
+    for n in (1, 3, 19, 1000, 10 ** 6, 10 ** 7):
+        assert clb.codec.heldout_size(n) == oracle.heldout_size(n)
+    for args in ((10, 178.28572, 10 ** 9, 25000, 1), (141431, 62.15259, 10 ** 9, 25000, 1), (100, 50.0, 37, None, 2),
+                 (10 ** 6, 80.0, 10 ** 9, None, 8)):
+        assert clb.codec.setup(*args) == oracle.setup(*args)
+    assert clb.codec.collect_embedding_id_offset([3, 5, 2])[0] == 10
+    assert np.array_equal(clb.codec.collect_embedding_id_offset([3, 5, 2])[1], [1, 4, 9])
+    assert clb.codec.collect_embedding_id_offset([])[0] == 0
+    assert clb.synthetic.num_partitions_for(10 ** 5, 80.0) == 32768
+    assert clb.synthetic.num_partitions_for(10 ** 6, 80.0) == 131072
+
+
+def test_config_defaults_and_roundtrip(tmp_path):
+    cfg = clb.ColBERTConfig()
+    assert (cfg.dim, cfg.doc_maxlen, cfg.query_maxlen, cfg.index_bsize, cfg.chunksize, cfg.nbits, cfg.kmeans_niters,
+            cfg.nprobe, cfg.ncandidates) == (128, 300, 32, 64, 25000, 2, 20, 2, 8192)
+    assert (cfg.query_token_id, cfg.doc_token_id, cfg.query_token, cfg.doc_token) == ("[unused0]", "[unused1]", "[Q]", "[D]")
+    assert len(cfg.__dataclass_fields__) == 22                 # src/infra/config.jl:54-90
+    cfg2 = clb.ColBERTConfig(index_path=str(tmp_path / "idx"), nbits=4, chunksize=None)
+    cfg2.save()
+    assert clb.ColBERTConfig.load(cfg2.index_path) == cfg2
+
+
+def test_synthetic_index_is_consistent(oracle):
+    idx = clb.synthetic.make_index(3, 500, K=128)
+    assert idx["codes"].min() >= 1 and idx["codes"].max() <= 128
+    ivf, lens = oracle.build_ivf(idx["codes"], 128)
+    assert np.array_equal(ivf, idx["ivf"]) and np.array_equal(lens, idx["ivf_lengths"])
+    assert idx["residuals"].shape == (32, idx["doclens"].sum()) and idx["residuals"].flags.f_contiguous
+    Q = clb.synthetic.make_queries(idx, 4, 3)
+    assert Q.shape == (128, 32, 3) and np.allclose(np.linalg.norm(Q, axis=0), 1, atol=1e-5)

@@ -1,0 +1,373 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libcolbert_hip.so), against the CPU
+oracle on the same seeded inputs, against the reference's golden vectors, and -- at BASELINE.json's
+sizes -- through size-independent properties.  Bar: pids bit-exact, fp32 scores bit-exact against the
+oracle's canonical arithmetic (tolerance 0; north_star allows 1e-4), bytes/indices bit-exact."""
+import numpy as np
+import pytest
+
+import colbert_jl_amd as clb
+from colbert_jl_amd import codec, synthetic
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 0.0   # fp32 scores are compared bit-for-bit; north_star's bound is 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_f32(a, b, what=""):
+    a = np.asarray(a, dtype=np.float32); b = np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if not np.array_equal(bits(a), bits(b)):
+        diff = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        raise AssertionError(f"{what}: {np.count_nonzero(bits(a) != bits(b))} of {a.size} differ, max |d| = {diff.max()}")
+
+
+def pad_dim(a, dim=128):
+    a = np.asarray(a, dtype=np.float32)
+    out = np.zeros((dim,) + a.shape[1:], dtype=np.float32, order="F")
+    out[: a.shape[0]] = a
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors of the reference's tests, through the C ABI
+# ---------------------------------------------------------------------------------------------------
+def test_golden_maxsim(kats):
+    k = kats["maxsim"]
+    got = codec.maxsim(np.array(k["Q"], np.float32), np.array(k["D"], np.float32), k["pids"], k["doclens"])
+    assert np.array_equal(got, np.array(k["expected_scores"], np.float32))
+
+
+def test_golden_retrieve(kats):
+    """test/search/ranking.jl:74-82, embedded in dim 128 by zero padding (dot products unchanged)."""
+    k = kats["retrieve"]
+    emb2pid = np.array(k["emb2pid"])
+    n_docs = int(emb2pid.max())
+    doclens = np.bincount(emb2pid, minlength=n_docs + 1)[1:]
+    n_emb = emb2pid.size
+    idx = {"dim": 128, "nbits": 2, "centroids": pad_dim(np.array(k["centroids"], np.float32)),
+           "bucket_weights": synthetic.README_BUCKET_WEIGHTS, "doclens": doclens,
+           "codes": np.ones(n_emb, np.uint32), "residuals": np.zeros((32, n_emb), np.uint8),
+           "ivf": np.array(k["ivf"]), "ivf_lengths": np.array(k["ivf_lengths"])}
+    s = clb.Searcher(index=idx)
+    got = s.retrieve(pad_dim(np.array(k["Q"], np.float32)), nprobe=k["nprobe"])
+    assert np.array_equal(got, k["expected_pids"])
+    s.close()
+
+
+def test_golden_build_ivf(kats):
+    k = kats["_build_ivf"]
+    ivf, lens = codec.build_ivf(k["codes"], k["num_partitions"])
+    assert np.array_equal(ivf, k["expected_ivf"]) and np.array_equal(lens, k["expected_ivf_lengths"])
+
+
+def test_golden_bucket_cutoffs(kats):
+    """_bucket_cutoffs_and_weights KAT via _compute_avg_residuals! with a zero centroid (residual = data)."""
+    k = kats["_bucket_cutoffs_and_weights"]
+    held = np.array(k["heldout_avg_residual"], np.float32).T.copy()      # (2, 3): same pooled values
+    cut, w, avg, codes = codec.compute_avg_residuals(k["nbits"], np.zeros((2, 1), np.float32), held)
+    assert np.allclose(cut, k["expected_cutoffs"]) and np.allclose(w, k["expected_weights"])
+    assert np.all(codes == 1) and np.isclose(avg, np.mean(held))
+
+
+# ---------------------------------------------------------------------------------------------------
+# codec pieces vs the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,nbits", [(128, 2), (128, 1), (128, 4), (64, 2), (24, 8), (128, 8)])
+def test_decompress_bit_exact(oracle, dim, nbits):
+    rng = np.random.default_rng(100 + dim + nbits)
+    n, K = 1037, 57
+    w = np.sort(rng.normal(0, 0.03, 1 << nbits).astype(np.float32))
+    cent = (rng.normal(size=(dim, K)) / np.sqrt(dim)).astype(np.float32)
+    codes = rng.integers(1, K + 1, size=n).astype(np.uint32)
+    res = rng.integers(0, 256, size=(dim // 8 * nbits, n)).astype(np.uint8)
+    assert_same_f32(codec.decompress(dim, nbits, cent, w, codes, res), oracle.decompress(dim, nbits, cent, w, codes, res),
+                    f"decompress dim={dim} nbits={nbits}")
+
+
+def test_normalize_bit_exact(oracle):
+    rng = np.random.default_rng(101)
+    for dim in (1, 3, 7, 128, 130):
+        X = rng.normal(size=(dim, 77)).astype(np.float32)
+        X[:, 5] = 0
+        assert_same_f32(codec._normalize_array(X), oracle.normalize_array(X), f"normalize dim={dim}")
+
+
+def test_maxsim_bit_exact(oracle):
+    rng = np.random.default_rng(102)
+    doclens = rng.integers(1, 12, size=150)
+    Q = rng.normal(size=(128, 32)).astype(np.float32); D = rng.normal(size=(128, int(doclens.sum()))).astype(np.float32)
+    pids = np.arange(1, 151)
+    assert_same_f32(codec.maxsim(Q, D, pids, doclens), oracle.maxsim(Q, D, pids, doclens), "maxsim")
+
+
+@pytest.mark.parametrize("dim,K,n", [(128, 300, 2100), (128, 1, 5), (128, 33, 31), (48, 20, 200)])
+def test_compress_bit_exact(oracle, dim, K, n):
+    rng = np.random.default_rng(103 + K)
+    cent = oracle.normalize_array(rng.normal(size=(dim, K)).astype(np.float32))
+    embs = oracle.normalize_array(rng.normal(size=(dim, n)).astype(np.float32))
+    embs[:, : min(K, n)] = cent[:, : min(K, n)]          # exact hits: residual bytes must be 0 there
+    for nbits in (1, 2, 4):
+        cut = np.sort(rng.normal(0, 0.05, (1 << nbits) - 1).astype(np.float32))
+        codes, res = codec.compress(cent, cut, dim, nbits, embs)
+        rc, rr = oracle.compress(cent, cut, dim, nbits, embs)
+        assert np.array_equal(codes, rc) and np.array_equal(res, rr)
+    assert np.array_equal(codec.compress_into_codes(cent, embs), oracle.compress_into_codes(cent, embs))
+
+
+def test_compress_ties_pick_first_centroid(oracle):
+    cent = np.zeros((128, 70), np.float32); cent[0, :] = 1.0       # all centroids identical
+    embs = np.zeros((128, 40), np.float32); embs[0, :] = 0.5
+    assert np.all(codec.compress_into_codes(cent, embs) == 1)
+    cent[0, 37] = 2.0
+    assert np.all(codec.compress_into_codes(cent, embs) == 38)
+
+
+@pytest.mark.parametrize("dim,n,K,bsize", [(128, 3000, 40, 1000), (128, 700, 64, 100), (16, 500, 9, 1000)])
+def test_kmeans_bit_exact(oracle, dim, n, K, bsize):
+    rng = np.random.default_rng(104 + K)
+    data = oracle.normalize_array(rng.normal(size=(dim, n)).astype(np.float32))
+    init = data[:, rng.permutation(n)[:K]]
+    c, a, it = codec.kmeans(data, init, max_iters=6, point_bsize=bsize)
+    rc, ra, rit = oracle.kmeans(data, init, max_iters=6, point_bsize=bsize)
+    assert it == rit
+    assert np.array_equal(a, ra)
+    assert_same_f32(c, rc, "kmeans centroids")
+
+
+def test_kmeans_fixed_point():
+    rng = np.random.default_rng(105)                               # test/utils.jl:138-145
+    data = rng.random((128, 90)).astype(np.float32)
+    c, ids, _ = codec.kmeans(data, data[:, rng.permutation(90)], max_iters=10)
+    assert np.array_equal(c[:, ids - 1], data)
+
+
+def test_codec_stats_match_oracle(oracle):
+    rng = np.random.default_rng(106)
+    cent = oracle.normalize_array(rng.normal(size=(128, 50)).astype(np.float32))
+    held = oracle.normalize_array(rng.normal(size=(128, 700)).astype(np.float32))
+    for nbits in (1, 2, 4):
+        cut, w, avg, codes = codec.compute_avg_residuals(nbits, cent, held)
+        rcut, rw, ravg, rcodes = oracle.compute_avg_residuals(nbits, cent, held)
+        assert np.array_equal(codes, rcodes)
+        assert_same_f32(cut, rcut, "cutoffs"); assert_same_f32(w, rw, "weights")
+        assert np.isclose(avg, ravg, rtol=1e-6)
+
+
+def test_build_ivf_matches_oracle(oracle):
+    rng = np.random.default_rng(107)
+    codes = rng.integers(1, 5001, size=200_000).astype(np.uint32)
+    ivf, lens = codec.build_ivf(codes, 5000)
+    rivf, rlens = oracle.build_ivf(codes, 5000)
+    assert np.array_equal(ivf, rivf) and np.array_equal(lens, rlens)
+    with pytest.raises(clb.BoundsError):
+        codec.build_ivf(np.array([1, 7], np.uint32), 5)
+
+
+def test_encoder_epilogue_bit_exact(oracle):
+    rng = np.random.default_rng(108)
+    dim, L, N = 128, 37, 9
+    D = rng.normal(size=(dim, L, N)).astype(np.float32)
+    ids = rng.integers(1, 40, size=(L, N)).astype(np.int32)
+    skip = [1, 3, 7, 11, 999]
+    out, doclens = codec.doc_epilogue(D, ids, skip)
+    rout, rdl = oracle.doc_epilogue(D, ids, skip)
+    assert np.array_equal(doclens, rdl)
+    assert_same_f32(out, rout, "doc epilogue")
+    assert_same_f32(codec.query_epilogue(D, ids, skip), oracle.query_epilogue(D, ids, skip), "query epilogue")
+
+
+# ---------------------------------------------------------------------------------------------------
+# search vs the oracle
+# ---------------------------------------------------------------------------------------------------
+def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0):
+    s = clb.Searcher(index=idx, pid_offset=pid_offset)
+    try:
+        for mode in modes:
+            if mode == 1 and s.mode != 1:
+                try:
+                    s.set_mode(1)
+                except clb.Unsupported:
+                    continue
+            s.set_mode(mode)
+            for j in range(Qs.shape[2]):
+                rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k)
+                pids, scores = s.search_embeddings(Qs[:, :, j], k, nprobe=nprobe)
+                assert s.last_num_candidates == rn
+                assert np.array_equal(pids, rp + pid_offset), (mode, j, np.nonzero(pids != rp + pid_offset)[0][:5])
+                assert_same_f32(scores, rs, f"scores mode={mode} q={j}")
+            # the batch entry point returns the same thing
+            bp, bs, bn = s.search_batch(Qs, k, nprobe=nprobe)
+            for j in range(Qs.shape[2]):
+                rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k)
+                assert np.array_equal(bp[:, j], rp + pid_offset) and bn[j] == rn
+                assert_same_f32(bs[:, j], rs, f"batch scores mode={mode} q={j}")
+    finally:
+        s.close()
+
+
+def test_search_small(oracle):
+    idx = synthetic.make_index(seed=1, n_docs=300, K=64)
+    check_search(oracle, idx, synthetic.make_queries(idx, 2, 3), k=10)
+
+
+def test_search_medium(oracle):
+    idx = synthetic.make_index(seed=3, n_docs=20_000, K=2048)
+    check_search(oracle, idx, synthetic.make_queries(idx, 4, 4), k=1000)
+
+
+def test_search_uniform_codes_and_nprobe(oracle):
+    idx = synthetic.make_index(seed=5, n_docs=5000, K=512, topical=False)
+    Qs = synthetic.make_queries(idx, 6, 2)
+    check_search(oracle, idx, Qs, k=100, nprobe=1)
+    check_search(oracle, idx, Qs, k=100, nprobe=4)
+    check_search(oracle, idx, Qs, k=100, nprobe=9)
+
+
+@pytest.mark.parametrize("nbits", [1, 4])
+def test_search_other_nbits(oracle, nbits):
+    idx = synthetic.make_index(seed=7 + nbits, n_docs=1500, K=128, nbits=nbits)
+    check_search(oracle, idx, synthetic.make_queries(idx, 8, 2), k=50)
+
+
+@pytest.mark.parametrize("T", [1, 5, 31, 40, 64, 100])
+def test_search_query_lengths(oracle, T):
+    idx = synthetic.make_index(seed=11, n_docs=1500, K=128)
+    check_search(oracle, idx, synthetic.make_queries(idx, 12, 2, T=T), k=25)
+
+
+def test_search_ragged_and_empty_passages(oracle):
+    idx = synthetic.make_index(seed=13, n_docs=800, K=64, doclen_mean=20, doclen_std=30)
+    # force zero-length passages (the reference tolerates them: _build_emb2pid test 3)
+    rng = np.random.default_rng(14)
+    dl = idx["doclens"].copy()
+    dl[rng.integers(0, 800, size=60)] = 0
+    dl[0] = 0; dl[-1] = 0
+    n_emb = int(dl.sum())
+    idx2 = dict(idx, doclens=dl, codes=idx["codes"][:n_emb], residuals=np.asfortranarray(idx["residuals"][:, :n_emb]))
+    idx2["ivf"], idx2["ivf_lengths"] = synthetic.build_ivf(idx2["codes"], 64)
+    check_search(oracle, idx2, synthetic.make_queries(idx2, 15, 3), k=20)
+
+
+def test_search_ties_keep_ascending_pid(oracle):
+    """Duplicate passages score identically; the stable sortperm keeps the lower pid first."""
+    idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
+    L = 16
+    for p in range(0, 400, 2):                                   # passage p+1 := copy of passage p
+        idx["codes"][(p + 1) * L:(p + 2) * L] = idx["codes"][p * L:(p + 1) * L]
+        idx["residuals"][:, (p + 1) * L:(p + 2) * L] = idx["residuals"][:, p * L:(p + 1) * L]
+    idx["ivf"], idx["ivf_lengths"] = synthetic.build_ivf(idx["codes"], 32)
+    check_search(oracle, idx, synthetic.make_queries(idx, 18, 2), k=60)
+
+
+def test_search_bounds_error_and_padding(oracle):
+    idx = synthetic.make_index(seed=19, n_docs=300, K=64)
+    Q = synthetic.make_queries(idx, 20, 1)
+    s = clb.Searcher(index=idx)
+    cand = s.retrieve(Q[:, :, 0])
+    assert np.array_equal(cand, oracle.retrieve(idx["ivf"], idx["ivf_lengths"], idx["centroids"],
+                                                oracle.build_emb2pid(idx["doclens"]), 2, Q[:, :, 0]))
+    with pytest.raises(clb.BoundsError):                         # searching.jl:127
+        s.search_embeddings(Q[:, :, 0], k=cand.size + 1)
+    pids, scores, n = s.search_batch(Q, cand.size + 5, pad_short=True)
+    rp, rs, _ = oracle.search(idx, Q[:, :, 0], 2, cand.size)
+    assert np.array_equal(pids[: cand.size, 0], rp) and np.all(pids[cand.size:, 0] == 0)
+    assert np.all(np.isneginf(scores[cand.size:, 0]))
+    with pytest.raises(clb.BoundsError):                         # partialsortperm(v, 1:nprobe) with nprobe > K
+        s.search_embeddings(Q[:, :, 0], k=1, nprobe=65)
+    s.close()
+
+
+def test_create_rejects_bad_codes():
+    idx = synthetic.make_index(seed=21, n_docs=50, K=16)
+    bad = dict(idx); bad["codes"] = idx["codes"].copy(); bad["codes"][3] = 17
+    with pytest.raises(clb.DomainError):
+        clb.Searcher(index=bad)
+    bad = dict(idx); bad["ivf"] = idx["ivf"].copy(); bad["ivf"][0] = idx["codes"].size + 1
+    with pytest.raises(clb.BoundsError):
+        clb.Searcher(index=bad)
+
+
+def test_sharded_search_merges_to_unsharded(oracle):
+    """contiguous pid shards + merge of per-shard top-k == unsharded result."""
+    idx = synthetic.make_index(seed=23, n_docs=6000, K=512)
+    Qs = synthetic.make_queries(idx, 24, 3)
+    k = 200
+    from colbert_jl_amd.sharding import merge_topk_host, shard_index
+    parts = [shard_index(idx, r, 4) for r in range(4)]
+    res = []
+    for sub, off in parts:
+        s = clb.Searcher(index=sub, pid_offset=off)
+        res.append(s.search_batch(Qs, k, pad_short=True)[:2])
+        s.close()
+    for j in range(Qs.shape[2]):
+        rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
+        mp, ms = merge_topk_host([r[0][:, j] for r in res], [r[1][:, j] for r in res], k)
+        assert np.array_equal(mp, rp)
+        assert_same_f32(ms, rs, "merged scores")
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json config 2 size (100k passages): size-independent properties + a sampled oracle check
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    idx = synthetic.make_index(seed=31, n_docs=100_000)           # K = 32768 by the reference's rule
+    assert idx["centroids"].shape[1] == 32768
+    Qs = synthetic.make_queries(idx, 32, 8)
+    s = clb.Searcher(index=idx)
+    yield idx, Qs, s
+    s.close()
+
+
+def test_full_size_properties(big, oracle):
+    idx, Qs, s = big
+    k = 1000
+    results = {}
+    for mode in (0, 1):
+        try:
+            s.set_mode(mode)
+        except clb.Unsupported:
+            continue
+        pids, scores, n = s.search_batch(Qs, k)
+        assert np.all(np.diff(scores, axis=0) <= 0)                               # sorted by score
+        ties = np.diff(scores, axis=0) == 0
+        assert np.all(np.diff(pids, axis=0)[ties] > 0)                            # ties by ascending pid
+        for j in range(Qs.shape[2]):
+            assert np.unique(pids[:, j]).size == k
+            assert set(pids[:, j]) <= set(s.retrieve(Qs[:, :, j]))                # top-k subset of candidates
+        p2, s2, _ = s.search_batch(Qs, k)                                         # idempotent
+        assert np.array_equal(pids, p2) and np.array_equal(bits(scores), bits(s2))
+        pk, sk, _ = s.search_batch(Qs, 10)                                        # top-10 is a prefix of top-1000
+        assert np.array_equal(pk, pids[:10]) and np.array_equal(bits(sk), bits(scores[:10]))
+        results[mode] = (pids, scores)
+    if len(results) == 2:                                                         # both modes: identical output
+        assert np.array_equal(results[0][0], results[1][0])
+        assert np.array_equal(bits(results[0][1]), bits(results[1][1]))
+    # the returned scores equal the oracle's maxsim of those passages (checks scoring at full size)
+    pids, scores = next(iter(results.values()))
+    emb_off = np.concatenate([[0], np.cumsum(idx["doclens"])])
+    for j in (0, 5):
+        sel = pids[:50, j]
+        cols = np.concatenate([np.arange(emb_off[p - 1], emb_off[p]) for p in sel])
+        D = oracle.decompress(128, 2, idx["centroids"], idx["bucket_weights"], idx["codes"][cols], idx["residuals"][:, cols])
+        ref = oracle.maxsim(Qs[:, :, j], D, np.arange(1, 51), idx["doclens"][sel - 1])
+        assert_same_f32(scores[:50, j], ref, "full-size score check")
+
+
+def test_full_size_against_oracle(big, oracle):
+    idx, Qs, s = big
+    for mode in (0, 1):
+        try:
+            s.set_mode(mode)
+        except clb.Unsupported:
+            continue
+        for j in (1, 6):
+            rp, rs, rn = oracle.search(idx, Qs[:, :, j], 2, 1000)
+            pids, scores = s.search_embeddings(Qs[:, :, j], 1000)
+            assert s.last_num_candidates == rn
+            assert np.array_equal(pids, rp)
+            assert_same_f32(scores, rs, f"100k scores mode={mode}")
