@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec (+ p50 latency) of top-1000 search on a synthetic 1M-passage corpus
+(BASELINE.json: dim 128, nbits 2, doclen ~80, query_maxlen 32, nprobe 2, k 1000) on N MI355X.
+
+A step = one pass of the search hot path (centroid scoring -> candidates -> fused decompress+MaxSim
+-> top-k, and for N > 1 the RCCL all-gather + merge of the per-shard top-k) over one batch of queries
+that are already resident in HBM.  The passage collection is sharded over the N ranks (strong scaling:
+the corpus is fixed).  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--batch B] [--mode {0,1}]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
+BYTES_PER_EMB = 36.0         # 4-B code + 32-B packed residual
+BYTES_PER_PID = 16.0
+FLOP_PER_EMB = 8192.0        # 2 * 32 * 128
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--nprobe", type=int, default=2)
+    ap.add_argument("--mode", type=int, default=-1, help="-1 library default, 0 exact, 1 two-pass")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import colbert_jl_amd as clb
+    from colbert_jl_amd import synthetic
+    from colbert_jl_amd.distributed import DeviceSearch, all_gather_topk, merge_gathered
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- this rank's passage shard (generated directly, identical to the same passages of the full index)
+    T, B, k = 32, args.batch, args.k
+    n_blocks = 8
+    assert n_blocks % world == 0, "shards are aligned to the 8 generation blocks: use 1, 2, 4 or 8 GPUs"
+    per = n_blocks // world
+    t0 = time.time()
+    K = synthetic.num_partitions_for(args.docs, 80.0)
+    shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks,
+                                 blocks=range(rank * per, (rank + 1) * per))
+    t_gen = time.time() - t0
+    t0 = time.time()
+    s = clb.Searcher(index=shard, device=local_rank, pid_offset=int(shard["pid_offset"]))
+    if args.mode >= 0:
+        s.set_mode(args.mode)
+    t_load = time.time() - t0
+    n_queries = max(B * 8, 256)
+    Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=n_queries, T=T)   # (dim, T, nq)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).to(dev)               # (nq, T, dim)
+    run = DeviceSearch(s, T, B, k, args.nprobe)
+    merged_p = torch.empty((B, k), dtype=torch.int64, device=dev)
+    merged_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+
+    def step(i):
+        off = (i * B) % (n_queries - B + 1)
+        p, sc = run(Qdev[off:off + B])
+        if world > 1:
+            gp, gs = all_gather_topk(p, sc)
+            return merge_gathered(gp, gs, k, out_p=merged_p, out_s=merged_s)
+        return p, sc
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    s.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = s.profile_read()
+    s.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    qps = B * args.steps / elapsed
+
+    # ---- work counters of one batch (for the roofline) and p50 latency, outside the timed region
+    s.profile_enable(True)
+    step(args.warmup)
+    torch.cuda.synchronize()
+    stats = s.last_batch_stats()
+    s.profile_read()
+    s.profile_enable(False)
+    lat = []
+    one = DeviceSearch(s, T, 1, k, args.nprobe)
+    for i in range(40):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        p, sc = one(Qdev[i:i + 1])
+        if world > 1:
+            gp, gs = all_gather_topk(p, sc)
+            merge_gathered(gp, gs, k)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    p50_ms = float(np.median(lat[5:]) * 1e3)
+
+    # ---- roofline of the dominant kernel (per launch = one batch on this rank's shard)
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
+    roof = None
+    if dom:
+        ms_launch = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
+        embs = stats["cand_embs"]; docs = stats["cand_docs"]
+        if dom == "score_exact" and s.mode == 1:
+            embs, docs = stats["rescored_embs"], stats["rescored_docs"]
+        if dom in ("score_exact",):
+            ach = FLOP_PER_EMB * embs / (ms_launch * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4), "traffic": None}
+        else:
+            if dom == "centroid_scores":
+                alg_bytes = K * 128 * 4.0 + B * K * T * 4.0
+            else:
+                alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
+            ach = alg_bytes / (ms_launch * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["ms_per_launch"] = round(ms_launch, 4)
+        roof["units_per_launch"] = {"cand_embeddings": embs, "cand_passages": docs}
+        roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(args.steps, 1), 4) for kname, v in prof.items()}
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N = 1
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+        orc.build()
+        emb2pid = orc.build_emb2pid(shard["doclens"])
+        idx = dict(shard, emb2pid=emb2pid)
+        nq_cpu, t_cpu, ok = 0, 0.0, True
+        p, sc = run(Qdev[0:B]); torch.cuda.synchronize()
+        gp_host = p.cpu().numpy(); gs_host = sc.cpu().numpy()
+        while nq_cpu < B and (t_cpu < args.cpu_seconds or nq_cpu == 0):
+            t1 = time.perf_counter()
+            rp, rs, _ = orc.search(idx, Q[:, :, nq_cpu], args.nprobe, k)
+            t_cpu += time.perf_counter() - t1
+            ok = ok and bool(np.array_equal(rp, gp_host[nq_cpu])) and bool(np.max(np.abs(rs - gs_host[nq_cpu])) <= 1e-4)
+            nq_cpu += 1
+        cpu = {"value": round(nq_cpu / t_cpu, 4), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
+               "sample": f"{nq_cpu} queries of the same workload, one at a time, OpenMP over the host cores",
+               "gpu_matches_cpu_top_k": ok}
+
+    if rank == 0:
+        out = {"metric": "queries/sec, top-1000 on 1M-passage corpus", "value": round(qps, 2), "unit": "queries/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}), "
+                                      f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
+                                      f"passages sharded over {world} GPU(s)",
+                          "search_mode": "two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass"},
+               "p50_latency_ms": round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
+               "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
+               "hbm_bytes": s.device_bytes}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

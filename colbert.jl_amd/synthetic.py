@@ -31,46 +31,86 @@ def build_ivf(codes: np.ndarray, K: int):
     return ivf, lens
 
 
-def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbits: int = 2,
-               doclen_mean: float = 80.0, doclen_std: float = 16.0, constant_doclen: bool = False,
-               topical: bool = True):
-    """A compressed index of `n_docs` passages.  `topical`: each passage draws 80 % of its tokens
-    from the 16 centroids nearest (by id, a cheap stand-in for similarity) to 4 per-passage topic
-    centroids, the rest uniformly -- uniform codes are the worst case for candidate counts."""
-    rng = np.random.default_rng(seed)
+def _centroids(seed: int, K: int, dim: int) -> np.ndarray:
+    rng = np.random.default_rng([seed, 0])
+    cent = rng.standard_normal((K, dim), dtype=np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cent *= rng.uniform(0.6, 1.0, size=(K, 1)).astype(np.float32)   # k-means means are sub-unit-norm
+    return np.asfortranarray(cent.T)                                 # (dim, K) column-major
+
+
+def _block(seed: int, block: int, n_docs: int, K: int, dim: int, nbits: int, doclen_mean: float,
+           doclen_std: float, constant_doclen: bool, topical: bool):
+    """Passages of one generation block: (doclens, codes, residuals as (n_emb, rows))."""
+    rng = np.random.default_rng([seed, 1000 + block])
     if constant_doclen:
         doclens = np.full(n_docs, int(doclen_mean), dtype=np.int64)
     else:
         doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, 220).astype(np.int64)
     n_emb = int(doclens.sum())
-    if K is None:
-        K = num_partitions_for(n_docs, float(doclens.mean()))
-    cent = rng.standard_normal((K, dim), dtype=np.float32)
-    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
-    cent *= rng.uniform(0.6, 1.0, size=(K, 1)).astype(np.float32)   # k-means means are sub-unit-norm
-    centroids = np.asfortranarray(cent.T)                            # (dim, K) column-major
     if topical:
-        doc_of = np.repeat(np.arange(n_docs), doclens)
-        topics = rng.integers(0, K, size=(n_docs, 4))
-        pick = rng.integers(0, 4, size=n_emb)
-        near = (topics[doc_of, pick] + rng.integers(-8, 8, size=n_emb)) % K
-        uni = rng.integers(0, K, size=n_emb)
-        codes = np.where(rng.random(n_emb) < 0.8, near, uni).astype(np.uint32) + 1
+        doc_of = np.repeat(np.arange(n_docs, dtype=np.int32), doclens)
+        topics = rng.integers(0, K, size=(n_docs, 4), dtype=np.int32)
+        pick = rng.integers(0, 4, size=n_emb, dtype=np.int32)
+        near = (topics[doc_of, pick] + rng.integers(-8, 8, size=n_emb, dtype=np.int32)) % K
+        uni = rng.integers(0, K, size=n_emb, dtype=np.int32)
+        codes = (np.where(rng.random(n_emb, dtype=np.float32) < 0.8, near, uni) + 1).astype(np.uint32)
     else:
         codes = rng.integers(1, K + 1, size=n_emb, dtype=np.uint32)
     rows = dim // 8 * nbits
-    residuals = np.asfortranarray(
-        rng.integers(0, 256, size=(n_emb, rows), dtype=np.uint8).T)   # (rows, n_emb) column-major
+    residuals = rng.integers(0, 256, size=(n_emb, rows), dtype=np.uint8)
+    return doclens, codes, residuals
+
+
+def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbits: int = 2,
+               doclen_mean: float = 80.0, doclen_std: float = 16.0, constant_doclen: bool = False,
+               topical: bool = True, n_blocks: int = 1, blocks=None):
+    """A compressed index of `n_docs` passages.  `topical`: each passage draws 80 % of its tokens
+    from the 16 centroids nearest (by id, a cheap stand-in for similarity) to 4 per-passage topic
+    centroids, the rest uniformly -- uniform codes are the worst case for candidate counts.
+
+    The collection is generated in `n_blocks` equal blocks of passages, each from its own RNG stream,
+    so a passage shard (`blocks` = the block ids it holds) can be generated without the rest and is
+    identical to the same passages of the full index.  Returns the Searcher's fields plus
+    `pid_offset` (passages before the first generated block)."""
+    if K is None:
+        K = num_partitions_for(n_docs, doclen_mean)
+    per = -(-n_docs // n_blocks)
+    blocks = list(range(n_blocks)) if blocks is None else list(blocks)
+    parts = []
+    for b in blocks:
+        lo, hi = b * per, min(n_docs, (b + 1) * per)
+        parts.append(_block(seed, b, hi - lo, K, dim, nbits, doclen_mean, doclen_std, constant_doclen, topical))
+    doclens = np.concatenate([p[0] for p in parts])
+    codes = np.concatenate([p[1] for p in parts])
+    residuals = np.asfortranarray(np.concatenate([p[2] for p in parts], axis=0).T)   # (rows, n_emb) col-major
     if nbits == 2:
         weights = README_BUCKET_WEIGHTS.copy()
         cutoffs = README_BUCKET_CUTOFFS.copy()
     else:
-        weights = np.sort(rng.normal(0, 0.03, 1 << nbits).astype(np.float32))
+        wr = np.random.default_rng([seed, 1])
+        weights = np.sort(wr.normal(0, 0.03, 1 << nbits).astype(np.float32))
         cutoffs = ((weights[1:] + weights[:-1]) / 2).astype(np.float32)
     ivf, ivf_lengths = build_ivf(codes, K)
-    return {"dim": dim, "nbits": nbits, "centroids": centroids, "bucket_weights": weights,
+    return {"dim": dim, "nbits": nbits, "centroids": _centroids(seed, K, dim), "bucket_weights": weights,
             "bucket_cutoffs": cutoffs, "doclens": doclens, "codes": codes, "residuals": residuals,
-            "ivf": ivf, "ivf_lengths": ivf_lengths}
+            "ivf": ivf, "ivf_lengths": ivf_lengths, "pid_offset": blocks[0] * per if blocks else 0}
+
+
+def make_topic_queries(centroids: np.ndarray, seed: int, n_queries: int, T: int = 32, noise: float = 0.3) -> np.ndarray:
+    """(dim, T, n_queries) unit query vectors that need only the (replicated) centroid table: every
+    query draws 4 topic centroids like a passage does, its tokens are centroids from their
+    neighbourhood plus Gaussian noise, renormalised.  Identical on every rank for a given seed."""
+    rng = np.random.default_rng([seed, 2])
+    dim, K = centroids.shape
+    topics = rng.integers(0, K, size=(n_queries, 4))
+    pick = rng.integers(0, 4, size=(n_queries, T))
+    cid = (np.take_along_axis(topics, pick, axis=1) + rng.integers(-8, 8, size=(n_queries, T))) % K
+    q = centroids[:, cid.ravel()].astype(np.float64)
+    q /= np.linalg.norm(q, axis=0, keepdims=True)
+    q += noise * rng.standard_normal(q.shape) / math.sqrt(dim)
+    q /= np.linalg.norm(q, axis=0, keepdims=True)
+    return np.asfortranarray(q.reshape(dim, n_queries, T).transpose(0, 2, 1).astype(np.float32))
 
 
 def decompress_numpy(index: dict, eids0: np.ndarray) -> np.ndarray:

@@ -62,7 +62,7 @@ static float sumsq_strided(const float* x, int64_t count, int64_t stride) {
 
 /* utils.jl:320-325  X ./= (sqrt.(sum(abs2, X, dims)) .+ eps(T)) */
 int orc_normalize_columns(float* X, int64_t dim, int64_t n) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 256)
     for (int64_t e = 0; e < n; ++e) {
         float* x = X + e * dim;
         float den = sqrtf(orc_sumsq(x, dim)) + FLT_EPSILON;
@@ -132,7 +132,7 @@ int orc_kmeans_distances(float* dist, int64_t dist_rows, int64_t dist_cols, cons
     int64_t dim = data_dim;
     float* c2 = (float*)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1));
     for (int64_t c = 0; c < K; ++c) c2[c] = orc_sumsq(centroids + c * dim, dim);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b * K > 4096)
     for (int64_t i = 0; i < b; ++i) {
         const float* x = data + i * dim;
         float x2 = orc_sumsq(x, dim);
@@ -214,7 +214,7 @@ int orc_kmeans(const float* data, int64_t dim, int64_t n, float* centroids, int6
         for (int64_t c = 0; c < K; ++c) c2[c] = orc_sumsq(centroids + c * dim, dim);
         for (int64_t start = 0; start < n; start += point_bsize) {
             int64_t end = start + point_bsize < n ? start + point_bsize : n;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((end - start) * K > 4096)
             for (int64_t i = start; i < end; ++i) {
                 const float* x = data + i * dim;
                 float x2 = orc_sumsq(x, dim);
@@ -278,7 +278,7 @@ int orc_compress_into_codes(uint32_t* codes, int64_t n_codes, const float* centr
                             int64_t K, const float* embs, int64_t n) {
     if (n_codes != n) return ORC_EDIMENSION; /* residual.jl:72-74 */
     if (K <= 0 && n > 0) return ORC_EARGUMENT;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * K > 4096)
     for (int64_t e = 0; e < n; ++e) {
         const float* x = embs + e * dim;
         int64_t best = 0;
@@ -355,7 +355,7 @@ int orc_binarize(int64_t dim, int nbits, const float* cutoffs, int64_t ncut, con
     if (dim % 8 != 0) return ORC_EDOMAIN;                          /* residual.jl:520 */
     if (ncut != ((int64_t)1 << nbits) - 1) return ORC_EDOMAIN;     /* residual.jl:521-522 */
     int64_t rows = dim / 8 * nbits;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b > 256)
     for (int64_t e = 0; e < b; ++e) {
         uint8_t* o = out + e * rows;
         memset(o, 0, (size_t)rows);
@@ -377,14 +377,13 @@ int orc_compress(const float* centroids, int64_t K, const float* cutoffs, int64_
     if (rc) return rc;
     if (dim % 8 != 0) return ORC_EDOMAIN;
     if (ncut != ((int64_t)1 << nbits) - 1) return ORC_EDOMAIN;
-    int64_t rows = dim / 8 * nbits;
-    float* r = (float*)malloc(sizeof(float) * (size_t)(dim > 0 ? dim : 1));
+    float* r = (float*)malloc(sizeof(float) * (size_t)(dim * n > 0 ? dim * n : 1));
+#pragma omp parallel for schedule(static) if (n > 256)
     for (int64_t e = 0; e < n; ++e) {
         const float* c = centroids + (int64_t)(codes[e] - 1) * dim;
-        for (int64_t d = 0; d < dim; ++d) r[d] = embs[d + e * dim] - c[d];
-        rc = orc_binarize(dim, nbits, cutoffs, ncut, r, 1, residuals + e * rows);
-        if (rc) break;
+        for (int64_t d = 0; d < dim; ++d) r[d + e * dim] = embs[d + e * dim] - c[d];
     }
+    rc = orc_binarize(dim, nbits, cutoffs, ncut, r, n, residuals);
     free(r);
     return rc;
 }
@@ -395,7 +394,7 @@ int orc_decompress_residuals(int64_t dim, int nbits, const float* weights, int64
     if (dim % 8 != 0) return ORC_EDOMAIN;                         /* residual.jl:701 */
     if (rows != dim / 8 * nbits) return ORC_EDOMAIN;              /* residual.jl:702-704 */
     if (nweights != ((int64_t)1 << nbits)) return ORC_EDOMAIN;    /* residual.jl:705-706 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b > 256)
     for (int64_t e = 0; e < b; ++e) {
         const uint8_t* r = packed + e * rows;
         for (int64_t d = 0; d < dim; ++d) {
@@ -419,7 +418,7 @@ int orc_decompress(int64_t dim, int nbits, const float* centroids, int64_t K, co
         if (codes[e] < 1 || (int64_t)codes[e] > K) return ORC_EDOMAIN; /* residual.jl:766-768 */
     int rc = orc_decompress_residuals(dim, nbits, weights, nweights, residuals, res_rows, res_cols, out);
     if (rc) return rc;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n_codes > 256)
     for (int64_t e = 0; e < n_codes; ++e) {
         float* x = out + e * dim;
         const float* c = centroids + (int64_t)(codes[e] - 1) * dim;
@@ -683,7 +682,7 @@ int orc_retrieve(const int64_t* ivf, int64_t n_ivf, const int64_t* ivf_lengths, 
     /* cells = Q' * centroids  (T, K)  ranking.jl:27 */
     float* cells = (float*)malloc(sizeof(float) * (size_t)(T * K > 0 ? T * K : 1));
     float* Qt = transpose_Q(Q, dim, T);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (K > 256)
     for (int64_t c = 0; c < K; ++c) dots_all_tokens(Qt, T, dim, centroids + c * dim, cells + c * T);
     free(Qt);
     /* _topk(cells, nprobe, dims=2) ; sort(unique(vec(.)))  ranking.jl:31-32 */
@@ -746,7 +745,7 @@ int orc_maxsim(const float* Q, int64_t dim, int64_t T, const float* D, int64_t n
     for (int64_t j = 0; j < n_pids; ++j) off[j + 1] = off[j] + doclens[pids[j] - 1];
     int rc = ORC_OK;
     float* Qt = transpose_Q(Q, dim, T);
-#pragma omp parallel
+#pragma omp parallel if (n_D > 2048)
     {
         float* s = (float*)malloc(sizeof(float) * (size_t)(T > 0 ? T : 1));
         float* m = (float*)malloc(sizeof(float) * (size_t)(T > 0 ? T : 1));
