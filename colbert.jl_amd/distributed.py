@@ -21,11 +21,12 @@ def all_gather_topk(pids, scores, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    gp = torch.empty((world,) + tuple(pids.shape), dtype=pids.dtype, device=pids.device)
-    gs = torch.empty((world,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
+    B, k = pids.shape
+    gp = torch.empty((world * B, k), dtype=pids.dtype, device=pids.device)      # concatenation along dim 0
+    gs = torch.empty((world * B, k), dtype=scores.dtype, device=scores.device)
     dist.all_gather_into_tensor(gp, pids.contiguous(), group=group)
     dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)
-    return gp, gs
+    return gp.view(world, B, k), gs.view(world, B, k)
 
 
 def merge_gathered(gp, gs, k: int, device_index=None, out_p=None, out_s=None):
