@@ -1,14 +1,382 @@
-// approx_kernels.hpp -- two-pass mode: bf16-MFMA approximate MaxSim with a proven error bound, used to
-// select a superset of the top-k that the exact kernel then re-scores.  (placeholder: not built yet)
+// approx_kernels.hpp -- two-pass search, pass 1: approximate MaxSim on the bf16 MFMA straight from the
+// packed index, plus the selection of the candidates that must be re-scored exactly.
+//
+// Why: an exact fp32 score costs 8 192 flop per 36 packed bytes (227 flop/B; the fp32-MFMA ridge is ~25), so
+// a single exact pass cannot come near the HBM roofline.  Pass 1 scores EVERY candidate passage approximately
+// with a proven bound eps on |approx - canonical fp32 score|; tau = k-th largest approximate score; every
+// candidate with approx >= tau - 2*eps is re-scored by score_exact_kernel.  Claim: that set contains the exact
+// top-k.  Proof: k candidates have approx >= tau, hence exact >= tau - eps, so the k-th largest exact score
+// theta >= tau - eps; a member of the exact top-k has exact >= theta, hence approx >= exact - eps >= tau - 2 eps.
+// The final topk_kernel then runs on exact scores only, so the output (pids AND fp32 scores) is identical
+// to the single-pass mode by construction; tests assert it bit-for-bit.
+//
+// The approximation (per query token t and embedding e, x = c + r the decompressed vector, den = ||x|| + eps32):
+//     S[t][e] = Q_t . x / den  =  ( Q_t . c  +  Q_t . r ) * inv_norm[e]
+//   * Q_t . c  = cells[t][code]  -- already computed exactly by centroid_scores_kernel (S1); stored for this
+//                pass as fp16 pairs [K][16]{t, t+16} (64 B per centroid) to halve the gather;
+//   * Q_t . r  -- r[d] = bucket_weight[idx[d]] takes only 2^nbits values: a 4-entry bf16 LUT applied with
+//                v_perm_b32 to 2 dims at a time (selector built from the packed nibble with one u24 multiply),
+//                fed as the A operand of v_mfma_f32_16x16x32_bf16 against bf16(Q) -- no centroid row is read,
+//                nothing is normalised per element;
+//   * inv_norm[e] = 1/(sqrtf(sumsq(c+r)) + eps32), precomputed once per index (fp32, canonical sumsq).
+// Per embedding this pass reads 32 B residual + 4 B code + 4 B inv_norm from HBM (streaming) and gathers one
+// 64-B fp16 cells row from L2/MALL.  Algorithmic bytes (roofline accounting): 36 B per embedding.
+//
+// Error bound (u = 2^-24; qn = max_t ||Q_t||2; cn = max ||c||2; rn = sqrt(dim) * max|w| >= ||r||2;
+// im = max inv_norm), per (t, e):
+//   cells:   fp32 chain vs exact Q.c                 <= 2*128*u*qn*cn          (safety 2x on gamma_128)
+//            fp16 storage                            <= 2^-11 * qn*cn          (|cells| <= qn*cn < 65504)
+//   Q.r:     bf16(Q), bf16(w) relative 2^-9 each     <= (2^-8 + 2^-18) * qn*rn
+//            fp32 accumulation in the MFMA           <= 2*128*u*qn*rn
+//   scaling: add, multiply, inv_norm rounding        <= 8*u*qn
+//   oracle:  canonical fp32 value vs real arithmetic <= 320*u*qn               (x, sumsq, sqrt, divide, chain)
+//   eps_t = im * (cells + Q.r terms) + 328*u*qn ;  eps = T * eps_t + 2*T*T*u*qn (the two token sums).
+// eps is evaluated per query on the device (select_margin_kernel) and multiplied by kEpsSafety.
 #pragma once
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+
 #include "common.hpp"
+#include "search_kernels.hpp"
 
 namespace clb {
 
-inline bool approx_supported(int /*dim*/, int /*nbits*/) { return false; }
-inline size_t approx_cells_bytes(int64_t, int64_t, int64_t) { return 16; }
-inline int build_inv_norms(hipStream_t, const float*, const float*, const uint32_t*, const uint8_t*, int64_t,
-                           float*) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr float kEpsSafety = 1.25f;
+
+inline bool approx_supported(int dim, int nbits) { return dim == kDim && nbits == 2; }
+inline size_t approx_cells_bytes(int64_t B, int64_t K, int64_t /*Tpad*/) { return (size_t)B * K * 16 * 4; }
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
+}
+
+// ---- index-load: inv_norm[e] = 1/(sqrtf(sumsq(c + r)) + eps32), canonical sumsq; running max -------------------
+static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ C,
+                                                             const float* __restrict__ weights,
+                                                             const uint32_t* __restrict__ codes0,
+                                                             const uint8_t* __restrict__ residuals, int64_t n,
+                                                             float* __restrict__ inv_norm,
+                                                             unsigned int* __restrict__ inv_max_bits) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = weights[j];
+    const int64_t groups = (n + 15) / 16;
+    float vmax = 0.f;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t el = grp * 16 + r;
+        const int64_t e = el < n ? el : n - 1;
+        uint32_t R[8];
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * 32);
+        uint4 v0 = *reinterpret_cast<const uint4*>(rp), v1 = *reinterpret_cast<const uint4*>(rp + 4);
+        R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w; R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w;
+        const float* cent = C + (size_t)codes0[e] * kDim + g;
+        float p = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int bitpos = 8 * s;
+            const uint32_t idx = (R[bitpos >> 5] >> ((bitpos & 31) + g * 2)) & 3u;
+            const float lo = (idx & 1) ? w[1] : w[0];
+            const float hi = (idx & 1) ? w[3] : w[2];
+            const float x = cent[4 * s] + ((idx & 2) ? hi : lo);
+            const float sq = x * x;
+            p = p + sq;
+        }
+        const float a = p + __shfl_xor(p, 16, 64);
+        const float n2 = a + __shfl_xor(a, 32, 64);
+        const float inv = 1.0f / (sqrtf(n2) + FLT_EPSILON);
+        if (g == 0 && el < n) inv_norm[e] = inv;
+        vmax = fmaxf(vmax, inv);
+    }
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, o, 64));
+    if (lane == 0) atomicMax(inv_max_bits, __float_as_uint(vmax));
+}
+
+// ---- cells fp32 [K][Tpad=32] -> fp16 pairs [K][16] {t, t+16}.  grid = (blocks, B), block = 256 -----------------
+static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* __restrict__ cells,
+                                                                  uint32_t* __restrict__ cells16, int K) {
+    const int b = blockIdx.y;
+    const float* src = cells + (size_t)b * K * 32;
+    uint32_t* dst = cells16 + (size_t)b * K * 16;
+    const int64_t total = (int64_t)K * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = i >> 4;
+        const int t = (int)(i & 15);
+        const float lo = src[c * 32 + t], hi = src[c * 32 + 16 + t];
+        const __half2 h = __floats2half2_rn(lo, hi);
+        dst[i] = *reinterpret_cast<const uint32_t*>(&h);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Pass 1.  One wave per candidate passage, 16 embeddings per step:
+//   A (16 x 32 per k-step) = bf16 bucket weights of the embeddings, built in registers from 8 packed bytes/lane;
+//   B (32 x 16)            = bf16 query tokens, resident in registers (2 token tiles x 4 k-steps x 4 VGPRs);
+//   lane (r = lane&15, g = lane>>4) owns dims [32g, 32g+32) of embedding r (bytes 8g..8g+7 of its residual) --
+//   the k index of the MFMA is a permutation of the dims, applied identically to both operands.
+//   Epilogue: lane (c = lane&15, g') holds rows 4g'+reg: (acc + cells16[code][c]) * inv_norm, running max.
+// Work-groups are dealt to queries by `blockIdx.x % 8` (the label of the XCD they share under round-robin
+// placement -- a speed heuristic only): all work-groups of one XCD gather from ONE query's cells table at a
+// time, which keeps that table in the XCD's L2.
+// grid = 8 * wg_per_group, block = 256.
+// -------------------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void score_approx_kernel(
+    const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
+    const float* __restrict__ inv_norm, const uint32_t* __restrict__ doc_off, const float* __restrict__ Q,
+    const uint32_t* __restrict__ cells16, const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
+    float* __restrict__ scores, int K, int T, int B, size_t cand_cap) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int x = blockIdx.x & 7;             // XCD group label
+    const int wg = blockIdx.x >> 3;           // index inside the group
+    const int wg_per_group = gridDim.x >> 3;
+    // bf16 LUT of the 4 bucket weights: bytes 0-3 = {w0, w1}, bytes 4-7 = {w2, w3}
+    const uint32_t lut_lo = pack_bf16(weights[0], weights[1]);
+    const uint32_t lut_hi = pack_bf16(weights[2], weights[3]);
+
+    int b_first, b_step, sub, nsub;
+    if (B >= 8) { b_first = x; b_step = 8; sub = 0; nsub = 1; }
+    else { b_first = x % B; b_step = B * 8 /* one query per group */; sub = x / B; nsub = (8 - b_first + B - 1) / B; }
+
+    for (int b = b_first; b < B; b += b_step) {
+        // B operand: Q[t][32g + 8s + j] for token tiles 0/1, k-steps s = 0..3
+        u32x4 qb[2][4];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int t = tl * 16 + r;
+            const float* qrow = Q + ((size_t)b * T + (t < T ? t : T - 1)) * kDim + 32 * g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 lo = *reinterpret_cast<const float4*>(qrow + 8 * s);
+                float4 hi = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
+                if (t >= T) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+                qb[tl][s] = u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
+            }
+        }
+        const uint32_t* cnd = cand + (size_t)b * cand_cap;
+        const uint32_t* c16 = cells16 + (size_t)b * K * 16 + r;
+        const int n = ncand[b];
+        const int stride = wg_per_group * 4 * nsub;
+        for (int j = (sub * wg_per_group + wg) * 4 + (threadIdx.x >> 6); j < n; j += stride) {
+            const uint32_t pid0 = cnd[j];
+            const uint32_t off = doc_off[pid0];
+            const int len = (int)(doc_off[pid0 + 1] - off);
+            float m0 = kNegInf, m1 = kNegInf;
+            for (int base = 0; base < len; base += 16) {
+                // ---- operand A: this lane's 8 residual bytes of embedding `base + r`
+                const int el = base + r;
+                const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
+                const uint2 rb = *reinterpret_cast<const uint2*>(residuals + (size_t)e * 32 + 8 * g);
+                // ---- epilogue inputs: codes / inv_norm of rows base + 4g .. +3 (clamped inside the passage)
+                const int row0 = base + 4 * g;
+                uint32_t code[4];
+                float inv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rr = row0 + q < len ? row0 + q : len - 1;
+                    code[q] = codes0[off + rr];
+                    inv[q] = inv_norm[off + rr];
+                }
+                uint32_t cell[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cell[q] = c16[(size_t)code[q] * 16];
+                // ---- build the bf16 A fragments: 16 nibbles -> 16 dwords of (w[i0], w[i1])
+                u32x4 a[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t word = (s & 2) ? rb.y : rb.x;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;
+                        const uint32_t sel = ((nib * 0x808202u) & 0x06060606u) | 0x01000100u;
+                        a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
+                    }
+                }
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                                   __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                                   __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __half2 h = *reinterpret_cast<const __half2*>(&cell[q]);
+                    const float2 cf = __half22float2(h);
+                    const float v0 = (acc0[q] + cf.x) * inv[q];
+                    const float v1 = (acc1[q] + cf.y) * inv[q];
+                    const bool ok = row0 + q < len;
+                    m0 = ok ? fmaxf(m0, v0) : m0;
+                    m1 = ok ? fmaxf(m1, v1) : m1;
+                }
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+            float sum = (r < T ? m0 : 0.f) + (16 + r < T ? m1 : 0.f);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            if (lane == 0) scores[(size_t)b * cand_cap + j] = sum;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Selection: tau = k-th largest approximate score; list = { slot : approx[slot] >= tau - 2 eps } in ascending slot
+// order.  One workgroup (1024 threads) per query.  thresh[b] = {tau, eps} is kept for inspection.
+// -------------------------------------------------------------------------------------------------------------
+struct ApproxConsts {
+    float cn_max;   // max ||centroid||
+    float rn_max;   // sqrt(dim) * max |bucket weight|
+    float inv_max;  // max inv_norm
+};
+
+static __global__ __launch_bounds__(1024) void select_margin_kernel(const float* __restrict__ scores,
+                                                                   const int* __restrict__ ncand,
+                                                                   const float* __restrict__ Q, int T, int k,
+                                                                   size_t cand_cap, ApproxConsts ac,
+                                                                   int* __restrict__ list, int* __restrict__ nlist,
+                                                                   float* __restrict__ thresh) {
+    __shared__ int hist[256];
+    __shared__ int sh_scan[16];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining, s_run;
+    __shared__ float s_qn;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = ncand[b];
+    const float* sc = scores + (size_t)b * cand_cap;
+    int* lst = list + (size_t)b * cand_cap;
+    // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
+    if (tid == 0) s_qn = 0.f;
+    __syncthreads();
+    if (tid < T) {
+        const float* q = Q + ((size_t)b * T + tid) * kDim;
+        float a = 0.f;
+        for (int d = 0; d < kDim; ++d) a = fmaf(q[d], q[d], a);
+        atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
+    }
+    if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
+    __syncthreads();
+    const int keff = n < k ? n : k;
+    float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
+    if (n > k) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < n; i += 1024) {
+                const uint32_t key = f32_order_key(sc[i]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining, d = 255;
+                for (; d > 0; --d) {
+                    if (hist[d] >= rem) break;
+                    rem -= hist[d];
+                }
+                s_prefix = prefix | ((uint32_t)d << shift);
+                s_remaining = rem;
+            }
+            __syncthreads();
+        }
+        const float u = 5.9604645e-08f;  // 2^-24
+        const float qn = s_qn;
+        const float e_cells = 2.f * 128.f * u * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
+        const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
+        const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
+        eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
+        tau_f = f32_from_order_key(s_prefix);
+        thr = tau_f - 2.f * eps;
+    }
+    (void)keff;
+    // ordered compaction of the slots with approx >= thr (all of them when n <= k)
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool take = i < n && sc[i] >= thr;
+        const int lane = tid & 63, wave = tid >> 6;
+        int xv = take ? 1 : 0;
+        const int v = xv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(xv, o, 64);
+            if (lane >= o) xv += y;
+        }
+        if (lane == 63) sh_scan[wave] = xv;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            const int s = sh_scan[w2];
+            if (w2 < wave) wbase += s;
+            tot += s;
+        }
+        if (take) lst[s_run + wbase + xv - v] = i;
+        __syncthreads();
+        if (tid == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nlist[b] = s_run;
+        thresh[2 * b] = tau_f;
+        thresh[2 * b + 1] = eps;
+    }
+}
+
+static __global__ void max_abs_kernel(const float* __restrict__ v, int n, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+static __global__ void max_row_norm_kernel(const float* __restrict__ C, int K, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int d = 0; d < kDim; ++d) a = fmaf(C[(size_t)c * kDim + d], C[(size_t)c * kDim + d], a);
+        m = fmaxf(m, sqrtf(a) * 1.001f);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
+// index-load: inv_norm array + the constants of the error bound
+inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW, const uint32_t* dCodes0,
+                               const uint8_t* dRes, int64_t n_emb, int K, float* d_inv_norm, ApproxConsts* out) {
+    DevBuf tmp;
+    CLB_TRY(tmp.alloc(3 * sizeof(unsigned int)));
+    CLB_HIP(hipMemsetAsync(tmp.p, 0, 3 * sizeof(unsigned int), st));
+    unsigned int* bits = tmp.as<unsigned int>();
+    if (n_emb > 0) {
+        const int grid = (int)std::min<int64_t>(4096, (n_emb + 63) / 64);
+        hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, d_inv_norm, bits);
+    }
+    hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, 4, bits + 1);
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
+    CLB_HIP(hipGetLastError());
+    unsigned int h[3];
+    CLB_HIP(hipMemcpyAsync(h, bits, sizeof h, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    float f[3];
+    memcpy(f, h, sizeof f);
+    out->inv_max = f[0] * 1.0001f;
+    out->rn_max = sqrtf((float)kDim) * f[1] * 1.0001f;
+    out->cn_max = f[2];
     return CLB_OK;
 }
 

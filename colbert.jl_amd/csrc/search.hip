@@ -61,6 +61,7 @@ struct clb_searcher {
     DevBuf ivf_off;     // u32 [K+1]
     DevBuf ivf_pid;     // u32 [n_emb] local passage ids grouped by centroid
     DevBuf inv_norm;    // fp32 [n_emb]  (two-pass mode)
+    ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
     // workspace, sized for (Bcap, Tcap, nprobe_cap, kcap)
     int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
@@ -221,6 +222,25 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
     if (s->prof.on) CLB_HIP(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * 8, st));
     const int* list = nullptr;
     const int* nlist = nullptr;
+    if (s->mode == 1 && s->approx_ok && T <= 32) {
+        {
+            Timed t(s, KID_SCORE_APPROX, st);
+            hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
+                               s->cells.as<float>(), s->cells_q.as<uint32_t>(), (int)s->K);
+            hipLaunchKernelGGL(score_approx_kernel, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
+                               s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(),
+                               s->doc_off.as<uint32_t>(), dQ, s->cells_q.as<uint32_t>(), s->cand.as<uint32_t>(),
+                               s->ncand.as<int>(), s->scores.as<float>(), (int)s->K, T, B, s->cand_cap);
+        }
+        {
+            Timed t(s, KID_SELECT, st);
+            hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, s->scores.as<float>(),
+                               s->ncand.as<int>(), dQ, T, k, s->cand_cap, s->approx_consts, s->list.as<int>(),
+                               s->nlist.as<int>(), s->thresh.as<float>());
+        }
+        list = s->list.as<int>();
+        nlist = s->nlist.as<int>();
+    }
     {
         Timed t(s, KID_SCORE_EXACT, st);
         const int gx = list ? std::max(1, 512 / B) : std::max(1, 2048 / B);
@@ -331,11 +351,10 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     s->approx_ok = approx_supported((int)dim, nbits);
     if (s->approx_ok) {
         if ((rc = s->inv_norm.alloc(sizeof(float) * std::max<int64_t>(n_emb, 1)))) return bail(rc);
-        if ((rc = build_inv_norms(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
-                                  s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb,
-                                  s->inv_norm.as<float>())))
+        if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
+                                      s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb, (int)K,
+                                      s->inv_norm.as<float>(), &s->approx_consts)))
             return bail(rc);
-        if (hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "inv-norm build failed"));
     }
     s->mode = s->approx_ok ? 1 : 0;
     s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
@@ -453,6 +472,50 @@ int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scor
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((n_lists * k + 255) / 256), (unsigned)B), dim3(256), 0, st,
                        d_pids, d_scores, (int)k, (int)n_lists, (int)B, d_out_pids, d_out_scores);
     CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t k, int64_t cap,
+                     int64_t* out_pids, float* out_approx, float* out_exact, int64_t* n_out, float* tau,
+                     float* eps, int64_t* n_rescore) {
+    CLB_TRY(check_search_args(s, T, 1, nprobe, k));
+    if (!s->approx_ok || T > 32) return fail(CLB_EUNSUPPORTED, "two-pass mode not available for this index/query");
+    CLB_TRY(use_device(s->device));
+    CLB_TRY(ensure_workspace(s, 1, T, nprobe, k));
+    hipStream_t st = s->stream;
+    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
+    const float* dQ = s->Qdev.as<float>();
+    CLB_TRY(run_retrieve(s, st, dQ, 1, (int)T, (int)nprobe));
+    hipLaunchKernelGGL(cells_to_half_kernel, dim3(1024, 1), dim3(256), 0, st, s->cells.as<float>(),
+                       s->cells_q.as<uint32_t>(), (int)s->K);
+    hipLaunchKernelGGL(score_approx_kernel, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
+                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(),
+                       s->doc_off.as<uint32_t>(), dQ, s->cells_q.as<uint32_t>(), s->cand.as<uint32_t>(),
+                       s->ncand.as<int>(), s->scores.as<float>(), (int)s->K, (int)T, 1, s->cand_cap);
+    hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, s->scores.as<float>(), s->ncand.as<int>(), dQ,
+                       (int)T, (int)k, s->cand_cap, s->approx_consts, s->list.as<int>(), s->nlist.as<int>(),
+                       s->thresh.as<float>());
+    int nc = 0, nl = 0;
+    float th[2];
+    CLB_HIP(hipMemcpyAsync(&nc, s->ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(&nl, s->nlist.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(th, s->thresh.p, sizeof th, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (nc > cap) return fail(CLB_EARGUMENT, "output capacity %lld < %d candidates", (long long)cap, nc);
+    std::vector<uint32_t> c((size_t)nc);
+    if (nc) {
+        CLB_HIP(hipMemcpy(c.data(), s->cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
+        CLB_HIP(hipMemcpy(out_approx, s->scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
+    }
+    switch (s->nbits) {
+        case 2: launch_score_exact<2>(s, st, dQ, 1, (int)T, nullptr, nullptr, 2048); break;
+        default: return fail(CLB_EUNSUPPORTED, "nbits");
+    }
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipStreamSynchronize(st));
+    if (nc) CLB_HIP(hipMemcpy(out_exact, s->scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nc; ++i) out_pids[i] = s->pid_offset + (int64_t)c[i] + 1;
+    *n_out = nc; *tau = th[0]; *eps = th[1]; *n_rescore = nl;
     return CLB_OK;
 }
 

@@ -107,6 +107,18 @@ class Searcher:
         check(lib().clb_retrieve(self._h, fptr(q), i64(q.shape[1]), i64(nprobe or self.config.nprobe), fptr(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def debug_scores(self, Q, k: int, nprobe: Optional[int] = None) -> dict:
+        """Two-pass test hook: candidates with approximate and exact scores, tau, eps, #re-scored."""
+        q = colmajor(Q, np.float32)
+        cap = max(self.num_docs, 1)
+        pids = np.zeros(cap, dtype=np.int64); ap = np.zeros(cap, dtype=np.float32); ex = np.zeros(cap, dtype=np.float32)
+        n = i64(0); nr = i64(0); tau = C.c_float(0); eps = C.c_float(0)
+        check(lib().clb_debug_scores(self._h, fptr(q), i64(q.shape[1]), i64(nprobe or self.config.nprobe), i64(k), i64(cap),
+                                     fptr(pids), fptr(ap), fptr(ex), C.byref(n), C.byref(tau), C.byref(eps), C.byref(nr)))
+        m = n.value
+        return {"pids": pids[:m].copy(), "approx": ap[:m].copy(), "exact": ex[:m].copy(), "tau": tau.value,
+                "eps": eps.value, "n_rescore": nr.value}
+
     def search(self, query: str, k: int):
         """search(searcher, query::String, k) (searching.jl:93-128)."""
         if self.encoder is None:

@@ -87,6 +87,13 @@ int clb_searcher_get_mode(const clb_searcher* s);
 int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
                  int64_t* n_out);
 
+/* Test hook for the two-pass mode: for one query returns every candidate pid with its approximate (pass 1) and
+ * exact score, the selection threshold tau (k-th largest approximate score), the proven error bound eps and the
+ * number of candidates with approx >= tau - 2 eps (those the exact pass re-scores). */
+int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t k, int64_t cap,
+                     int64_t* out_pids, float* out_approx, float* out_exact, int64_t* n_out, float* tau,
+                     float* eps, int64_t* n_rescore);
+
 /* Merge per-shard top-k lists (device pointers): `n_lists` lists of k (pid, score) records per query,
  * each sorted by (score desc, pid asc) and padded with (0, -Inf).  Input layout [n_lists][B][k] (k
  * fastest) -- what an all-gather of every rank's (k, B) result produces; output (k, B).  Replaces the

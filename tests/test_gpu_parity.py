@@ -291,6 +291,25 @@ def test_create_rejects_bad_codes():
         clb.Searcher(index=bad)
 
 
+def test_two_pass_error_bound_and_superset():
+    """The approximate pass stays within its proven bound eps of the exact (canonical fp32) score, the
+    observed error is far smaller than the bound, and {approx >= tau - 2 eps} contains the exact top-k."""
+    idx = synthetic.make_index(seed=27, n_docs=30_000, K=4096)
+    Qs = synthetic.make_queries(idx, 28, 4)
+    s = clb.Searcher(index=idx)
+    k = 500
+    for j in range(Qs.shape[2]):
+        d = s.debug_scores(Qs[:, :, j], k)
+        err = np.abs(d["approx"].astype(np.float64) - d["exact"].astype(np.float64))
+        assert d["eps"] > 0 and err.max() <= d["eps"], (err.max(), d["eps"])
+        assert err.max() <= d["eps"] / 4, ("bound unexpectedly tight", err.max(), d["eps"])
+        order = np.lexsort((d["pids"], -d["exact"].astype(np.float64)))[:k]
+        selected = d["approx"] >= np.float32(d["tau"]) - np.float32(2) * np.float32(d["eps"])
+        assert selected[order].all()
+        assert selected.sum() == d["n_rescore"] and k <= d["n_rescore"] <= max(4 * k, 2000)
+    s.close()
+
+
 def test_sharded_search_merges_to_unsharded(oracle):
     """contiguous pid shards + merge of per-shard top-k == unsharded result."""
     idx = synthetic.make_index(seed=23, n_docs=6000, K=512)
