@@ -130,19 +130,94 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 // time, which keeps that table in the XCD's L2.
 // grid = 8 * wg_per_group, block = 256.
 // -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// One 16-embedding step of pass 1.  rb = this lane's 8 residual bytes; code/inv = the 4 rows this lane
+// finishes.  No row masking: in the tail step rows past the end of the passage are clamped copies of its last
+// embedding, which cannot change a max.
+template <int VARIANT>
+__device__ __forceinline__ void approx_tile(const uint2 rb, const uint32_t (&code)[4], const float (&inv)[4],
+                                            const uint32_t* __restrict__ c16, const u32x4 (&qb)[2][4],
+                                            uint32_t lut_lo, uint32_t lut_hi, uint32_t kmask, uint32_t kbase,
+                                            float& m0, float& m1) {
+    uint32_t cell[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cell[q] = c16[code[q] * 16u];
+    // bf16 A fragments: 16 nibbles -> 16 dwords of (w[i0], w[i1]) via the 4-entry byte LUT
+    u32x4 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t word = (s & 2) ? rb.y : rb.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (VARIANT == 1) { a[s][q] = word + q; continue; }     // ablation: no LUT expansion
+            const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;
+            const uint32_t sel = ((nib * 0x808202u) & kmask) | kbase;
+            a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
+        }
+    }
+    // accumulators start from the centroid scores: acc = cells[t][code] + Q_t . r
+    f32x4 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2 cf = __half22float2(*reinterpret_cast<const __half2*>(&cell[q]));
+        acc0[q] = cf.x;
+        acc1[q] = cf.y;
+    }
+    if (VARIANT == 2) {                                             // ablation: no MFMA
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { acc0[s] += __uint_as_float(a[s][0] ^ a[s][2]); acc1[s] += __uint_as_float(a[s][1] ^ a[s][3]); }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                           __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                           __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0);
+        }
+    }
+    m0 = max3f(m0, acc0[0] * inv[0], acc0[1] * inv[1]);
+    m0 = max3f(m0, acc0[2] * inv[2], acc0[3] * inv[3]);
+    m1 = max3f(m1, acc1[0] * inv[0], acc1[1] * inv[1]);
+    m1 = max3f(m1, acc1[2] * inv[2], acc1[3] * inv[3]);
+}
+
+// Software pipeline, three 16-embedding steps in flight per wave (the code -> cells gather is a dependent
+// memory chain, and one step per wave leaves the kernel latency-bound):
+//   stage A(i+2): stream loads (8 residual bytes/lane, 4 codes, 4 inv_norms)
+//   stage G(i+1): gather the fp16 centroid scores of the 4 rows (needs A's codes)
+//   stage C(i)  : LUT expansion, 8 MFMAs, scale, running max; at a passage's last step reduce and store.
+// The loop body is branch-free apart from that store: steps past the end of the wave's work are redirected
+// to an always-valid dummy address and discarded, so the compiler can keep exact vmcnt counts.
+struct StepTag {      // wave-uniform description of a step
+    int j;            // candidate slot, -1 = dummy
+    int rows;         // valid rows (1..16)
+    int last;         // 1 = last step of its passage
+};
+
+template <int VARIANT>
 static __global__ __launch_bounds__(256) void score_approx_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
-    const float* __restrict__ inv_norm, const uint32_t* __restrict__ doc_off, const float* __restrict__ Q,
-    const uint32_t* __restrict__ cells16, const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
-    float* __restrict__ scores, int K, int T, int B, size_t cand_cap) {
+    const float* __restrict__ inv_norm, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
+    const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
+    int B, size_t cand_cap) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int x = blockIdx.x & 7;             // XCD group label
     const int wg = blockIdx.x >> 3;           // index inside the group
     const int wg_per_group = gridDim.x >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // bf16 LUT of the 4 bucket weights: bytes 0-3 = {w0, w1}, bytes 4-7 = {w2, w3}
     const uint32_t lut_lo = pack_bf16(weights[0], weights[1]);
     const uint32_t lut_hi = pack_bf16(weights[2], weights[3]);
+    uint32_t kmask = 0x06060606u, kbase = 0x01000100u;   // kept in VGPRs so that (x & m) | b is one v_and_or_b32
+    asm volatile("" : "+v"(kmask), "+v"(kbase));
+    const uint32_t lane_res = (uint32_t)(r * 32 + 8 * g);   // byte offset of this lane's residual bytes in a step
+    const uint32_t lane_row = (uint32_t)(4 * g);            // first of the 4 rows this lane finishes
 
     int b_first, b_step, sub, nsub;
     if (B >= 8) { b_first = x; b_step = 8; sub = 0; nsub = 1; }
@@ -163,75 +238,123 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
                 qb[tl][s] = u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
             }
         }
-        const uint32_t* cnd = cand + (size_t)b * cand_cap;
+        const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
         const uint32_t* c16 = cells16 + (size_t)b * K * 16 + r;
+        float* out = scores + (size_t)b * cand_cap;
         const int n = ncand[b];
         const int stride = wg_per_group * 4 * nsub;
-        for (int j = (sub * wg_per_group + wg) * 4 + (threadIdx.x >> 6); j < n; j += stride) {
-            const uint32_t pid0 = cnd[j];
-            const uint32_t off = doc_off[pid0];
-            const int len = (int)(doc_off[pid0 + 1] - off);
-            float m0 = kNegInf, m1 = kNegInf;
-            for (int base = 0; base < len; base += 16) {
-                // ---- operand A: this lane's 8 residual bytes of embedding `base + r`
-                const int el = base + r;
-                const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
-                const uint2 rb = *reinterpret_cast<const uint2*>(residuals + (size_t)e * 32 + 8 * g);
-                // ---- epilogue inputs: codes / inv_norm of rows base + 4g .. +3 (clamped inside the passage)
-                const int row0 = base + 4 * g;
-                uint32_t code[4];
-                float inv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rr = row0 + q < len ? row0 + q : len - 1;
-                    code[q] = codes0[off + rr];
-                    inv[q] = inv_norm[off + rr];
-                }
-                uint32_t cell[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cell[q] = c16[(size_t)code[q] * 16];
-                // ---- build the bf16 A fragments: 16 nibbles -> 16 dwords of (w[i0], w[i1])
-                u32x4 a[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint32_t word = (s & 2) ? rb.y : rb.x;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;
-                        const uint32_t sel = ((nib * 0x808202u) & 0x06060606u) | 0x01000100u;
-                        a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
-                    }
-                }
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                                   __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                                   __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const __half2 h = *reinterpret_cast<const __half2*>(&cell[q]);
-                    const float2 cf = __half22float2(h);
-                    const float v0 = (acc0[q] + cf.x) * inv[q];
-                    const float v1 = (acc1[q] + cf.y) * inv[q];
-                    const bool ok = row0 + q < len;
-                    m0 = ok ? fmaxf(m0, v0) : m0;
-                    m1 = ok ? fmaxf(m1, v1) : m1;
-                }
-            }
-            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
-            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
-            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
-            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
-            float sum = (r < T ? m0 : 0.f) + (16 + r < T ? m1 : 0.f);
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
-            sum += __shfl_xor(sum, 8, 64);
-            if (lane == 0) scores[(size_t)b * cand_cap + j] = sum;
+
+        // ---- wave-uniform iterator over the steps of passages j0, j0+stride, ... ------------------------------
+        // The headers {first embedding, length} of the wave's next 64 passages sit in one VGPR pair (lane k =
+        // k-th passage) and are extracted with v_readlane: no memory wait at a passage switch.
+        for (int j0 = (sub * wg_per_group + wg) * 4 + wave; j0 < n; j0 += 64 * stride) {
+        const int jl = j0 + lane * stride;
+        const uint2 hv = hdr[jl < n ? jl : j0];
+        const int nd = (n - j0 + stride - 1) / stride < 64 ? (n - j0 + stride - 1) / stride : 64;   // passages here
+        int it_k = 0;
+        uint32_t it_off = __builtin_amdgcn_readlane(hv.x, 0);
+        int it_len = (int)__builtin_amdgcn_readlane(hv.y, 0);
+        int it_base = 0;
+
+#define CLB_STAGE_A(RB, CV, IV, TAG)                                                                        \
+    {                                                                                                       \
+        const bool live = it_k < nd;                                                                        \
+        const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
+        RB = *reinterpret_cast<const uint2*>(residuals + (size_t)e0 * 32 + lane_res);                       \
+        CV = *reinterpret_cast<const u32x4_a4*>(codes0 + (size_t)e0 + lane_row);                            \
+        IV = *reinterpret_cast<const f32x4_a4*>(inv_norm + (size_t)e0 + lane_row);                          \
+        const int left = it_len - it_base;                                                                  \
+        TAG.j = live ? j0 + it_k * stride : -1;                                                             \
+        TAG.rows = left < 16 ? left : 16;                                                                   \
+        TAG.last = left <= 16;                                                                              \
+        it_base += 16;                                                                                      \
+        if (TAG.last) {                                                                                     \
+            it_k += 1;                                                                                      \
+            const int kk = it_k < 64 ? it_k : 63;                                                           \
+            it_off = __builtin_amdgcn_readlane(hv.x, kk);                                                   \
+            it_len = (int)__builtin_amdgcn_readlane(hv.y, kk);                                              \
+            it_base = 0;                                                                                    \
+        }                                                                                                   \
+    }
+#define CLB_STAGE_G(CV, CELL)                                                                               \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) CELL[q] = VARIANT == 3 ? CV[q] : c16[CV[q] * 16u];    \
+    }
+#define CLB_STAGE_C(RB, IV, CELL, TAG)                                                                      \
+    {                                                                                                       \
+        u32x4 a[4];                                                                                         \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
+            const uint32_t word = (s & 2) ? RB.y : RB.x;                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+                if (VARIANT == 1) { a[s][q] = word + q; continue; }                                         \
+                const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;                                \
+                const uint32_t sel = ((nib * 0x808202u) & kmask) | kbase;                                   \
+                a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);                                       \
+            }                                                                                               \
+        }                                                                                                   \
+        f32x4 acc0, acc1;                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+            const float2 cf = __half22float2(*reinterpret_cast<const __half2*>(&CELL[q]));                  \
+            acc0[q] = cf.x;                                                                                 \
+            acc1[q] = cf.y;                                                                                 \
+        }                                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
+            if (VARIANT == 2) { acc0[s] += __uint_as_float(a[s][0] ^ a[s][2]); acc1[s] += __uint_as_float(a[s][1] ^ a[s][3]); continue; } \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),                \
+                                                           __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),                \
+                                                           __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0); \
+        }                                                                                                   \
+        float v0[4], v1[4];                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+            const bool ok = (int)lane_row + q < TAG.rows;   /* rows past the passage belong to the next one */ \
+            v0[q] = ok ? acc0[q] * IV[q] : kNegInf;                                                         \
+            v1[q] = ok ? acc1[q] * IV[q] : kNegInf;                                                         \
+        }                                                                                                   \
+        m0 = max3f(m0, v0[0], v0[1]);                                                                       \
+        m0 = max3f(m0, v0[2], v0[3]);                                                                       \
+        m1 = max3f(m1, v1[0], v1[1]);                                                                       \
+        m1 = max3f(m1, v1[2], v1[3]);                                                                       \
+        if (TAG.last) {                                                                                     \
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));                                                         \
+            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));                                                         \
+            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));                                                         \
+            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));                                                         \
+            float sum = (r < T ? m0 : 0.f) + (16 + r < T ? m1 : 0.f);                                       \
+            sum += __shfl_xor(sum, 1, 64);                                                                  \
+            sum += __shfl_xor(sum, 2, 64);                                                                  \
+            sum += __shfl_xor(sum, 4, 64);                                                                  \
+            sum += __shfl_xor(sum, 8, 64);                                                                  \
+            if (lane == 0 && TAG.j >= 0) out[TAG.j] = sum;                                                  \
+            m0 = kNegInf;                                                                                   \
+            m1 = kNegInf;                                                                                   \
+        }                                                                                                   \
+    }
+
+        float m0 = kNegInf, m1 = kNegInf;
+        uint2 rb0, rb1, rb2;
+        u32x4 cv0, cv1, cv2;
+        f32x4 iv0, iv1, iv2;
+        uint32_t ce0[4], ce1[4], ce2[4];
+        StepTag t0, t1, t2;
+        CLB_STAGE_A(rb0, cv0, iv0, t0);
+        CLB_STAGE_A(rb1, cv1, iv1, t1);
+        CLB_STAGE_G(cv0, ce0);
+        while (t0.j >= 0) {
+            CLB_STAGE_A(rb2, cv2, iv2, t2);
+            CLB_STAGE_G(cv1, ce1);
+            CLB_STAGE_C(rb0, iv0, ce0, t0);
+            CLB_STAGE_A(rb0, cv0, iv0, t0);
+            CLB_STAGE_G(cv2, ce2);
+            CLB_STAGE_C(rb1, iv1, ce1, t1);
+            CLB_STAGE_A(rb1, cv1, iv1, t1);
+            CLB_STAGE_G(cv0, ce0);
+            CLB_STAGE_C(rb2, iv2, ce2, t2);
         }
+        }   // chunk of 64 passages
+#undef CLB_STAGE_A
+#undef CLB_STAGE_G
+#undef CLB_STAGE_C
     }
 }
 

@@ -68,15 +68,10 @@ static __global__ __launch_bounds__(256) void decompress_dim128_kernel(const flo
                                                                const uint8_t* __restrict__ residuals,
                                                                int64_t n, float* __restrict__ out) {
     constexpr int RD = NBITS * 4;
+    __shared__ float tbl[(8 / NBITS) * kWTblStride];
+    fill_weight_table<NBITS>(tbl, weights);
+    __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    float w[4] = {0.f, 0.f, 0.f, 0.f};
-    float wlane = 0.f;
-    if constexpr (NBITS <= 2) {
-#pragma unroll
-        for (int j = 0; j < (1 << NBITS); ++j) w[j] = weights[j];
-    } else {
-        wlane = lane < (1 << NBITS) ? weights[lane] : 0.f;
-    }
     const int64_t groups = (n + 15) / 16;
     for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t el = grp * 16 + r;
@@ -89,7 +84,7 @@ static __global__ __launch_bounds__(256) void decompress_dim128_kernel(const flo
             R[k4] = v.x; R[k4 + 1] = v.y; R[k4 + 2] = v.z; R[k4 + 3] = v.w;
         }
         float x[32];
-        decompress_lane_dims<NBITS>(C + (size_t)(codes[e] - 1) * kDim + g, R, g, w, wlane, x);
+        decompress_lane_dims_fast<NBITS>(C + (size_t)(codes[e] - 1) * kDim + g, R, g, tbl, x);
         if (el < n) {
 #pragma unroll
             for (int s = 0; s < 32; ++s) out[(size_t)e * kDim + 4 * s + g] = x[s];

@@ -67,7 +67,7 @@ struct clb_searcher {
     int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
-    DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, scores, list, nlist, thresh,
+    DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
         outp, outs, flags, stats;
     Prof prof;
     int64_t last_cand_docs = 0, last_cand_embs = 0, last_resc_docs = 0, last_resc_embs = 0;
@@ -133,6 +133,7 @@ int ensure_workspace(clb_searcher* s, int64_t B, int64_t T, int64_t nprobe, int6
     CLB_TRY(s->blocksum.ensure(sizeof(int) * B * s->nblk_bitmap));
     CLB_TRY(s->ncand.ensure(sizeof(int) * B));
     CLB_TRY(s->cand.ensure(sizeof(uint32_t) * B * s->cand_cap));
+    CLB_TRY(s->cand_hdr.ensure(sizeof(uint2) * B * s->cand_cap));
     CLB_TRY(s->scores.ensure(sizeof(float) * B * s->cand_cap));
     CLB_TRY(s->list.ensure(sizeof(int) * B * s->cand_cap));
     CLB_TRY(s->nlist.ensure(sizeof(int) * B));
@@ -158,10 +159,10 @@ void launch_topn(clb_searcher* s, hipStream_t st, int B, int Tpad) {
 template <int NBITS>
 void launch_score_exact(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, const int* list,
                         const int* nlist, int grid_x) {
-    hipLaunchKernelGGL(score_exact_kernel<NBITS>, dim3(grid_x, B), dim3(256), 0, st,
-                       s->centroids.as<float>(), s->weights.as<float>(), s->codes0.as<uint32_t>(),
-                       s->residuals.as<uint8_t>(), s->doc_off.as<uint32_t>(), dQ, s->cand.as<uint32_t>(),
-                       s->ncand.as<int>(), s->scores.as<float>(), T, s->cand_cap, list, nlist);
+    hipLaunchKernelGGL(score_exact_kernel<NBITS>, dim3(grid_x, B), dim3(256), 0, st, s->centroids.as<float>(),
+                       s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
+                       s->cand_hdr.as<uint2>(), dQ, s->ncand.as<int>(), s->scores.as<float>(), T, s->cand_cap, list,
+                       nlist);
 }
 
 // Candidate generation S1-S3 for B queries on stream st; leaves cand/ncand on the device.
@@ -195,8 +196,8 @@ int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T,
         hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, s->blocksum.as<int>(),
                            s->ncand.as<int>(), s->nblk_bitmap);
         hipLaunchKernelGGL(bitmap_emit_kernel, dim3(s->nblk_bitmap, B), dim3(kScanBlock), 0, st,
-                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->cand.as<uint32_t>(), s->W,
-                           s->cand_cap);
+                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->cand.as<uint32_t>(),
+                           s->doc_off.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->W, s->cand_cap);
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
@@ -227,10 +228,17 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
             Timed t(s, KID_SCORE_APPROX, st);
             hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
                                s->cells.as<float>(), s->cells_q.as<uint32_t>(), (int)s->K);
-            hipLaunchKernelGGL(score_approx_kernel, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
-                               s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(),
-                               s->doc_off.as<uint32_t>(), dQ, s->cells_q.as<uint32_t>(), s->cand.as<uint32_t>(),
-                               s->ncand.as<int>(), s->scores.as<float>(), (int)s->K, T, B, s->cand_cap);
+            static const int variant = getenv("CLB_DEBUG_APPROX_VARIANT") ? atoi(getenv("CLB_DEBUG_APPROX_VARIANT")) : 0;
+#define CLB_LAUNCH_APPROX(V)                                                                                         \
+    hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),              \
+                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
+                       s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(), \
+                       (int)s->K, T, B, s->cand_cap)
+            if (variant == 1) CLB_LAUNCH_APPROX(1);
+            else if (variant == 2) CLB_LAUNCH_APPROX(2);
+            else if (variant == 3) CLB_LAUNCH_APPROX(3);
+            else CLB_LAUNCH_APPROX(0);
+#undef CLB_LAUNCH_APPROX
         }
         {
             Timed t(s, KID_SELECT, st);
@@ -243,7 +251,7 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
-        const int gx = list ? std::max(1, 512 / B) : std::max(1, 2048 / B);
+        const int gx = list ? std::max(1, 1024 / B) : std::max(1, 2048 / B);
         switch (s->nbits) {
             case 1: launch_score_exact<1>(s, st, dQ, B, T, list, nlist, gx); break;
             case 2: launch_score_exact<2>(s, st, dQ, B, T, list, nlist, gx); break;
@@ -325,8 +333,15 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     int rc;
     if ((rc = upload(s->centroids, centroids, sizeof(float) * dim * K, s->stream))) return bail(rc);
     if ((rc = upload(s->weights, bucket_weights, sizeof(float) * ((size_t)1 << nbits), s->stream))) return bail(rc);
-    if ((rc = upload(s->codes0, codes, sizeof(uint32_t) * n_emb, s->stream))) return bail(rc);
-    if ((rc = upload(s->residuals, residuals, rows * n_emb, s->stream))) return bail(rc);
+    // steps of 16 embeddings are loaded unclamped: pad the per-embedding arrays by one step
+    constexpr int64_t kPad = 16;
+    if ((rc = s->codes0.alloc(sizeof(uint32_t) * (n_emb + kPad)))) return bail(rc);
+    if ((rc = s->residuals.alloc(rows * (n_emb + kPad)))) return bail(rc);
+    if (hipMemsetAsync(s->codes0.p, 0, s->codes0.bytes, s->stream) != hipSuccess ||
+        hipMemsetAsync(s->residuals.p, 0, s->residuals.bytes, s->stream) != hipSuccess ||
+        hipMemcpyAsync(s->codes0.p, codes, sizeof(uint32_t) * n_emb, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+        hipMemcpyAsync(s->residuals.p, residuals, rows * n_emb, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+        return bail(fail(CLB_EHIP, "index upload failed"));
     if ((rc = upload(s->doc_off, doc_off.data(), sizeof(uint32_t) * doc_off.size(), s->stream))) return bail(rc);
     if ((rc = upload(s->ivf_off, ivf_off.data(), sizeof(uint32_t) * ivf_off.size(), s->stream))) return bail(rc);
     if ((rc = s->ivf_pid.alloc(sizeof(uint32_t) * n_emb))) return bail(rc);
@@ -350,7 +365,8 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
 
     s->approx_ok = approx_supported((int)dim, nbits);
     if (s->approx_ok) {
-        if ((rc = s->inv_norm.alloc(sizeof(float) * std::max<int64_t>(n_emb, 1)))) return bail(rc);
+        if ((rc = s->inv_norm.alloc(sizeof(float) * (n_emb + 16)))) return bail(rc);
+        if (hipMemsetAsync(s->inv_norm.p, 0, s->inv_norm.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
         if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
                                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb, (int)K,
                                       s->inv_norm.as<float>(), &s->approx_consts)))
@@ -488,10 +504,10 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_TRY(run_retrieve(s, st, dQ, 1, (int)T, (int)nprobe));
     hipLaunchKernelGGL(cells_to_half_kernel, dim3(1024, 1), dim3(256), 0, st, s->cells.as<float>(),
                        s->cells_q.as<uint32_t>(), (int)s->K);
-    hipLaunchKernelGGL(score_approx_kernel, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
-                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(),
-                       s->doc_off.as<uint32_t>(), dQ, s->cells_q.as<uint32_t>(), s->cand.as<uint32_t>(),
-                       s->ncand.as<int>(), s->scores.as<float>(), (int)s->K, (int)T, 1, s->cand_cap);
+    hipLaunchKernelGGL(score_approx_kernel<0>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
+                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
+                       s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(),
+                       (int)s->K, (int)T, 1, s->cand_cap);
     hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, s->scores.as<float>(), s->ncand.as<int>(), dQ,
                        (int)T, (int)k, s->cand_cap, s->approx_consts, s->list.as<int>(), s->nlist.as<int>(),
                        s->thresh.as<float>());

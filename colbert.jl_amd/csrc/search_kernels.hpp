@@ -254,7 +254,9 @@ static __global__ __launch_bounds__(kScanBlock) void bitmap_scan_kernel(int* __r
 // grid = (nblk, B): emit ascending local pids (0-based) and clear the bitmap for the next query
 static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t* __restrict__ bitmap,
                                                                  const int* __restrict__ blockoff,
-                                                                 uint32_t* __restrict__ cand, int W,
+                                                                 uint32_t* __restrict__ cand,
+                                                                 const uint32_t* __restrict__ doc_off,
+                                                                 uint2* __restrict__ cand_hdr, int W,
                                                                  size_t cand_cap) {
     __shared__ int sh[8];
     const int b = blockIdx.y;
@@ -270,6 +272,7 @@ static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t
     int total;
     int pos = block_exclusive_scan_256(cnt, sh, total) + blockoff[(size_t)b * gridDim.x + blockIdx.x];
     uint32_t* out = cand + (size_t)b * cand_cap;
+    uint2* hdr = cand_hdr + (size_t)b * cand_cap;   // {first embedding, length} of every candidate passage
 #pragma unroll
     for (int j = 0; j < kWordsPerThread; ++j) {
         uint32_t x = w[j];
@@ -277,7 +280,12 @@ static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t
         while (x) {
             const int bit = __ffs((int)x) - 1;
             x &= x - 1;
-            if ((size_t)pos < cand_cap) out[pos] = (uint32_t)((w0 + j) * 32 + bit);
+            if ((size_t)pos < cand_cap) {
+                const uint32_t pid = (uint32_t)((w0 + j) * 32 + bit);
+                out[pos] = pid;
+                const uint32_t o = doc_off[pid];
+                hdr[pos] = make_uint2(o, doc_off[pid + 1] - o);
+            }
             ++pos;
         }
     }
@@ -330,14 +338,82 @@ __device__ __forceinline__ void decompress_lane_dims(const float* __restrict__ c
     for (int s = 0; s < 32; ++s) x[s] = x[s] / den;
 }
 
+// Correctly rounded x / den from a correctly rounded reciprocal y = RN(1/den) (Markstein): q0 = RN(x*y),
+// r = x - den*q0 (exact in the fma), q = RN(q0 + r*y).  Checked against IEEE division on 4.5e8 cases including
+// every 24-bit significand of den; valid away from the over/underflow ranges (the caller guards den).
+__device__ __forceinline__ float div_by_reciprocal(float x, float den, float y) {
+    const float q0 = x * y;
+    const float r = fmaf(-den, q0, x);
+    return fmaf(r, y, q0);
+}
+
+// Bucket-weight table in LDS, one copy per position of a field inside its byte: tbl[v][byte] =
+// w[(byte >> (NBITS*v)) & mask].  Row stride 264 floats staggers the copies over the banks.
+constexpr int kWTblStride = 264;
 template <int NBITS>
-static __global__ __launch_bounds__(256) void score_exact_kernel(
+__device__ __forceinline__ void fill_weight_table(float* tbl, const float* __restrict__ weights) {
+    constexpr int V = 8 / NBITS;
+    for (int i = threadIdx.x; i < V * 256; i += blockDim.x) {
+        const int v = i >> 8, byte = i & 255;
+        tbl[v * kWTblStride + byte] = weights[(byte >> (NBITS * v)) & ((1 << NBITS) - 1)];
+    }
+}
+
+// Decompresses the 32 dims {4s+g} of one embedding (canonical order, see decompress_lane_dims) using the LDS
+// table and the reciprocal division.  R = packed residual dwords; returns normalised values in x[].
+template <int NBITS>
+__device__ __forceinline__ void decompress_lane_dims_fast(const float* __restrict__ cent_row /*+g*/,
+                                                          const uint32_t (&R)[NBITS * 4], int g,
+                                                          const float* __restrict__ tbl, float (&x)[32]) {
+    float p = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        // dim d = 4s+g starts at bit d*NBITS: byte (4s*NBITS)/8 (+ g*NBITS/8), field v inside the byte
+        int byte_idx, v;
+        if constexpr (NBITS == 2) { byte_idx = s; v = g; }
+        else if constexpr (NBITS == 1) { byte_idx = s >> 1; v = 4 * (s & 1) + g; }
+        else { byte_idx = 2 * s + (g >> 1); v = g & 1; }
+        uint32_t byte;
+        if constexpr (NBITS == 4) {
+            const uint32_t w0 = R[(2 * s) >> 2], sh0 = ((2 * s) & 3) * 8;       // byte 2s and 2s+1 share a dword
+            byte = (w0 >> (sh0 + 8 * (g >> 1))) & 255u;
+            (void)byte_idx;
+        } else {
+            byte = (R[byte_idx >> 2] >> ((byte_idx & 3) * 8)) & 255u;
+        }
+        const float val = cent_row[4 * s] + tbl[v * kWTblStride + byte];
+        x[s] = val;
+        const float sq = val * val;
+        p = p + sq;
+    }
+    const float a = p + __shfl_xor(p, 16, 64);
+    const float n2 = a + __shfl_xor(a, 32, 64);
+    const float den = sqrtf(n2) + FLT_EPSILON;
+    if (__builtin_expect(den > 1e-18f && den < 1e18f, 1)) {
+        const float y = 1.0f / den;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) x[s] = div_by_reciprocal(x[s], den, y);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) x[s] = x[s] / den;
+    }
+}
+
+// grid = (G, B), block = 256 (4 waves).  `list` (optional) restricts the work to the listed candidate slots
+// (two-pass mode).  LDS: the bucket-weight table and the query operand of the current 32-token group, laid out
+// [chunk k][lane][4 floats] = {Q[t0][8k+g'], Q[t1][8k+g'], Q[t0][8k+4+g'], Q[t1][8k+4+g']} (g' = 4-dim stride,
+// i.e. MFMA steps 2k and 2k+1 for token tiles 0/1) so that one conflict-free ds_read_b128 feeds four MFMAs and
+// the operand costs no resident registers (occupancy 2 -> 4+ waves per SIMD).
+template <int NBITS>
+static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
-    const uint8_t* __restrict__ residuals, const uint32_t* __restrict__ doc_off,
-    const float* __restrict__ Q, const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
-    float* __restrict__ scores, int T, size_t cand_cap, const int* __restrict__ list /*optional*/,
-    const int* __restrict__ nlist) {
+    const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const float* __restrict__ Q,
+    const int* __restrict__ ncand, float* __restrict__ scores, int T, size_t cand_cap,
+    const int* __restrict__ list /*optional*/, const int* __restrict__ nlist) {
     constexpr int RD = NBITS * 4;  // residual dwords per embedding
+    __shared__ float tbl[(8 / NBITS) * kWTblStride];
+    __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];   // 16 KB
+    fill_weight_table<NBITS>(tbl, weights);
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -345,77 +421,90 @@ static __global__ __launch_bounds__(256) void score_exact_kernel(
     const int nwaves = gridDim.x * 4;
     const int n = list ? nlist[b] : ncand[b];
     const int TT = (T + 31) >> 5;
-
-    float w[4] = {0.f, 0.f, 0.f, 0.f};
-    float wlane = 0.f;
-    if constexpr (NBITS <= 2) {
-#pragma unroll
-        for (int j = 0; j < (1 << NBITS); ++j) w[j] = weights[j];
-    } else {
-        wlane = lane < (1 << NBITS) ? weights[lane] : 0.f;
-    }
-    const uint32_t* cnd = cand + (size_t)b * cand_cap;
+    const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
 
-    for (int j = wave_global; j < n; j += nwaves) {
-        const int slot = lst ? lst[j] : j;  // index into the candidate array
-        const uint32_t pid0 = cnd[slot];
-        const uint32_t off = doc_off[pid0];
-        const int len = (int)(doc_off[pid0 + 1] - off);
-        float total = 0.f;
-        for (int tt = 0; tt < TT; ++tt) {
-            // B operands: lane (token r, k = g) holds Q[t][4s+g] for t = 32tt + r and 32tt + 16 + r
-            float q0[32], q1[32];
-            {
-                const int t0 = tt * 32 + r, t1 = t0 + 16;
-                const float* qa = Q + ((size_t)b * T + (t0 < T ? t0 : T - 1)) * kDim + g;
-                const float* qb = Q + ((size_t)b * T + (t1 < T ? t1 : T - 1)) * kDim + g;
-#pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    q0[s] = t0 < T ? qa[4 * s] : 0.f;
-                    q1[s] = t1 < T ? qb[4 * s] : 0.f;
-                }
-            }
+    // stage the query operand of token group tt: every wave uses the same lane -> (token, k) map
+    auto stage_q = [&](int tt) {
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+            const int k = i >> 6, l = i & 63;
+            const int rr = l & 15, gg = l >> 4;
+            const int t0 = tt * 32 + rr, t1 = t0 + 16;
+            const float* qa = Q + ((size_t)b * T + (t0 < T ? t0 : T - 1)) * kDim + gg;
+            const float* qb = Q + ((size_t)b * T + (t1 < T ? t1 : T - 1)) * kDim + gg;
+            float4 v;
+            v.x = t0 < T ? qa[8 * k] : 0.f;
+            v.y = t1 < T ? qb[8 * k] : 0.f;
+            v.z = t0 < T ? qa[8 * k + 4] : 0.f;
+            v.w = t1 < T ? qb[8 * k + 4] : 0.f;
+            *reinterpret_cast<float4*>(qlds + (size_t)i * 4) = v;
+        }
+    };
+    const float4* qv = reinterpret_cast<const float4*>(qlds) + lane;
+
+    // with one token group the passage loop runs per wave; with several, all waves of the workgroup walk the
+    // groups together (the staged operand is shared), so the loop order is group-major
+    for (int tt = 0; tt < TT; ++tt) {
+        __syncthreads();
+        stage_q(tt);
+        __syncthreads();
+        for (int j = wave_global; j < n; j += nwaves) {
+            const int slot = lst ? lst[j] : j;  // index into the candidate array
+            const uint2 h = hdr[slot];
+            const uint32_t off = __builtin_amdgcn_readfirstlane(h.x);
+            const int len = (int)__builtin_amdgcn_readfirstlane(h.y);
             float m0 = kNegInf, m1 = kNegInf;
-            for (int base = 0; base < len; base += 16) {
+            // software prefetch: code + packed residual of the next step are loaded during the current one
+            uint32_t code_n;
+            uint32_t Rn[RD];
+            auto load_step = [&](int base) {
                 const int el = base + r;
                 const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
-                const uint32_t code = codes0[e];
-                uint32_t R[RD];
+                code_n = codes0[e];
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * (RD * 4));
 #pragma unroll
                 for (int k4 = 0; k4 < RD; k4 += 4) {
                     uint4 v = *reinterpret_cast<const uint4*>(rp + k4);
-                    R[k4] = v.x; R[k4 + 1] = v.y; R[k4 + 2] = v.z; R[k4 + 3] = v.w;
+                    Rn[k4] = v.x; Rn[k4 + 1] = v.y; Rn[k4 + 2] = v.z; Rn[k4 + 3] = v.w;
                 }
+            };
+            load_step(0);
+            for (int base = 0; base < len; base += 16) {
+                const uint32_t code = code_n;
+                uint32_t R[RD];
+#pragma unroll
+                for (int k4 = 0; k4 < RD; ++k4) R[k4] = Rn[k4];
+                if (base + 16 < len) load_step(base + 16);
                 float x[32];
-                decompress_lane_dims<NBITS>(C + (size_t)code * kDim + g, R, g, w, wlane, x);
+                decompress_lane_dims_fast<NBITS>(C + (size_t)code * kDim + g, R, g, tbl, x);
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], q0[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], q1[s], a1, 0, 0, 0);
+                for (int k = 0; k < 16; ++k) {
+                    const float4 q = qv[k * 64];
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.x, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.y, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.z, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.w, a1, 0, 0, 0);
                 }
-                // accumulator rows: embedding base + 4*g + reg ; cols: token r
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool ok = base + 4 * g + q < len;
-                    m0 = ok ? fmaxf(m0, a0[q]) : m0;
-                    m1 = ok ? fmaxf(m1, a1[q]) : m1;
-                }
+                // accumulator rows: embedding base + 4*g + reg ; cols: token r.  Rows past the passage are
+                // clamped copies of its last embedding: they cannot change the max.
+                m0 = fmaxf(fmaxf(m0, fmaxf(a0[0], a0[1])), fmaxf(a0[2], a0[3]));
+                m1 = fmaxf(fmaxf(m1, fmaxf(a1[0], a1[1])), fmaxf(a1[2], a1[3]));
             }
             m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
             m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
             m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));
             m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
-            // sequential sum over tokens (ranking.jl:83 `sum(maximum(..., dims=2))`)
+            // sequential sum over tokens (ranking.jl:83 `sum(maximum(..., dims=2))`); token groups are added in
+            // order, so the running total lives in scores[] between groups
+            float total = tt == 0 ? 0.f : scores[(size_t)b * cand_cap + slot];
 #pragma unroll
             for (int t = 0; t < 32; ++t) {
                 const float v = __shfl(t < 16 ? m0 : m1, t & 15, 64);
                 if (tt * 32 + t < T) total = total + v;
             }
+            if (lane == 0) scores[(size_t)b * cand_cap + slot] = total;
         }
-        if (lane == 0) scores[(size_t)b * cand_cap + slot] = total;
     }
 }
 
