@@ -170,18 +170,45 @@ int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T,
     const int TT = token_tiles(T), Tpad = TT * 32;
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
     const int n_tiles = (int)((s->K + 31) / 32);
-    {
-        Timed t(s, KID_CENTROID_SCORES, st);
-        const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B * TT)));
-        hipLaunchKernelGGL(centroid_scores_kernel, dim3(gx, B * TT), dim3(128),
-                           2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
-                           s->cells.as<float>(), (int)s->K, T, TT, n_tiles);
-    }
-    {
-        Timed t(s, KID_TOPN, st);
-        if (NPs == 2) launch_topn<2>(s, st, B, Tpad);
-        else if (NPs == 8) launch_topn<8>(s, st, B, Tpad);
-        else launch_topn<32>(s, st, B, Tpad);
+    const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
+    if (nprobe <= 2 && T <= 32) {
+        // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
+        const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B)));
+        const int nslots = gx * 4;
+        CLB_TRY(s->partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * 2));
+        {
+            Timed t(s, KID_CENTROID_SCORES, st);
+            if (want_half)
+                hipLaunchKernelGGL(centroid_top2_kernel<true>, dim3(gx, B), dim3(128),
+                                   2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
+                                   s->partial.as<ValIdx>(), s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
+            else
+                hipLaunchKernelGGL(centroid_top2_kernel<false>, dim3(gx, B), dim3(128),
+                                   2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
+                                   s->partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, n_tiles);
+        }
+        {
+            Timed t(s, KID_TOPN, st);
+            hipLaunchKernelGGL(top2_merge_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
+                               s->sel.as<int>(), nslots);
+        }
+    } else {
+        {
+            Timed t(s, KID_CENTROID_SCORES, st);
+            const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B * TT)));
+            hipLaunchKernelGGL(centroid_scores_kernel, dim3(gx, B * TT), dim3(128),
+                               2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
+                               s->cells.as<float>(), (int)s->K, T, TT, n_tiles);
+        }
+        {
+            Timed t(s, KID_TOPN, st);
+            if (NPs == 2) launch_topn<2>(s, st, B, Tpad);
+            else if (NPs == 8) launch_topn<8>(s, st, B, Tpad);
+            else launch_topn<32>(s, st, B, Tpad);
+        }
+        if (want_half)
+            hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
+                               s->cells.as<float>(), s->cells_q.as<uint32_t>(), (int)s->K);
     }
     {
         Timed t(s, KID_MARK, st);
@@ -226,8 +253,6 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
     if (s->mode == 1 && s->approx_ok && T <= 32) {
         {
             Timed t(s, KID_SCORE_APPROX, st);
-            hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
-                               s->cells.as<float>(), s->cells_q.as<uint32_t>(), (int)s->K);
             static const int variant = getenv("CLB_DEBUG_APPROX_VARIANT") ? atoi(getenv("CLB_DEBUG_APPROX_VARIANT")) : 0;
 #define CLB_LAUNCH_APPROX(V)                                                                                         \
     hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),              \
@@ -502,8 +527,6 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = s->Qdev.as<float>();
     CLB_TRY(run_retrieve(s, st, dQ, 1, (int)T, (int)nprobe));
-    hipLaunchKernelGGL(cells_to_half_kernel, dim3(1024, 1), dim3(256), 0, st, s->cells.as<float>(),
-                       s->cells_q.as<uint32_t>(), (int)s->K);
     hipLaunchKernelGGL(score_approx_kernel<0>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                        s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(),

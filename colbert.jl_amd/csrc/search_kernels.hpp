@@ -13,6 +13,8 @@
 //   maxsim        = per-token max over the passage, sequential sum over tokens.
 // Built with -ffp-contract=off so that no other multiply-add is fused behind our back.
 #pragma once
+#include <hip/hip_fp16.h>
+
 #include "common.hpp"
 
 namespace clb {
@@ -162,6 +164,127 @@ static __global__ void topn_final_kernel(const ValIdx* __restrict__ partial, int
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) sel[((size_t)b * Tpad + t) * NP + p] = bi[p];
+}
+
+// -------------------------------------------------------------------------------------------------
+// S1 + S2 fused (T <= 32, nprobe <= 2): the same MFMA tiling as centroid_scores_kernel, but
+//   * the next tile's centroid rows are prefetched into registers while the current tile is on the MFMA;
+//   * each lane keeps the running top-2 (score desc, index asc) of its token over the centroids it sees, so the
+//     T x K score matrix is never re-read (the reference moves it to the host and sorts every row, ranking.jl:30-31);
+//   * in two-pass mode the scores are written once, as fp16 pairs {t, t+16} (the layout pass 1 gathers), and the
+//     fp32 matrix is not written at all.
+// partial: [B][nslots][32][2] with nslots = waves * 2 halves.  grid = (gx, B), block = 128, LDS = 2*32*132*4.
+// -------------------------------------------------------------------------------------------------
+template <bool WRITE_HALF>
+static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top2_kernel(const float* __restrict__ C,
+                                                                    const float* __restrict__ Q,
+                                                                    ValIdx* __restrict__ partial,
+                                                                    uint32_t* __restrict__ cells16, int K, int T,
+                                                                    int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    float* my = lds + wave * (32 * kCentTileStride);
+    float qf[64];
+    {
+        const float* qrow = Q + ((size_t)b * T + (i < T ? i : T - 1)) * kDim;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 v = *reinterpret_cast<const float4*>(qrow + 4 * m);
+            if (i >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[2 * m] = h ? v.y : v.x;
+            qf[2 * m + 1] = h ? v.w : v.z;
+        }
+    }
+    float bv[2] = {kNegInf, kNegInf};
+    int bi[2] = {0x7fffffff, 0x7fffffff};
+    const int waves_total = gridDim.x * 2;
+    int tile = blockIdx.x * 2 + wave;
+    // prefetch registers: 16 named float4 (a loop-carried array ends up in scratch)
+#define CLB_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define CLB_PF_DECL(m) float4 pf##m;
+#define CLB_PF_LOAD(m)                                                                   \
+    {                                                                                    \
+        int c = tl * 32 + 2 * m + h;                                                     \
+        c = c < K ? c : K - 1;                                                           \
+        pf##m = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 4 * i);          \
+    }
+#define CLB_PF_STORE(m) *reinterpret_cast<float4*>(my + (2 * m + h) * kCentTileStride + 4 * i) = pf##m;
+    CLB_REP16(CLB_PF_DECL)
+    {
+        const int tl = tile < n_tiles ? tile : n_tiles - 1;
+        CLB_REP16(CLB_PF_LOAD)
+    }
+    while (tile < n_tiles) {
+        const int c0 = tile * 32;
+        CLB_REP16(CLB_PF_STORE)
+        const int next = tile + waves_total;
+        {
+            const int tl = next < n_tiles ? next : n_tiles - 1;   // the last prefetch is redundant, never wrong
+            CLB_REP16(CLB_PF_LOAD)
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 a4 = *reinterpret_cast<const float4*>(my + i * kCentTileStride + 4 * m);
+            const float a0 = h ? a4.y : a4.x;
+            const float a1 = h ? a4.w : a4.z;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qf[2 * m], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qf[2 * m + 1], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;   // ascending in r for a fixed half
+            if (c < K) topn_insert<2>(bv, bi, acc[r], c);
+            if (WRITE_HALF) {
+                const float other = __shfl_xor(acc[r], 16, 64);  // token i ^ 16, same centroid row
+                if ((i & 16) == 0 && c < K) {
+                    const __half2 hv = __floats2half2_rn(acc[r], other);
+                    cells16[((size_t)b * K + c) * 16 + i] = *reinterpret_cast<const uint32_t*>(&hv);
+                }
+            }
+        }
+        tile = next;
+    }
+#undef CLB_PF_DECL
+#undef CLB_PF_LOAD
+#undef CLB_PF_STORE
+#undef CLB_REP16
+    const int slot = (blockIdx.x * 2 + wave) * 2 + h;
+    const int nslots = gridDim.x * 4;
+    ValIdx* out = partial + (((size_t)b * nslots + slot) * 32 + i) * 2;
+    out[0] = ValIdx{bv[0], bi[0]};
+    out[1] = ValIdx{bv[1], bi[1]};
+}
+
+// Merge of the per-slot top-2 lists: one wave per (token, query).  grid = (32, B), block = 64.
+// sel layout as topn_final_kernel<2>: [B][32][2].
+static __global__ __launch_bounds__(64) void top2_merge_kernel(const ValIdx* __restrict__ partial,
+                                                              int* __restrict__ sel, int nslots) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float bv[2] = {kNegInf, kNegInf};
+    int bi[2] = {0x7fffffff, 0x7fffffff};
+    for (int sl = lane; sl < nslots; sl += 64) {
+        const ValIdx* in = partial + (((size_t)b * nslots + sl) * 32 + t) * 2;
+        topn_insert<2>(bv, bi, in[0].v, in[0].i);
+        topn_insert<2>(bv, bi, in[1].v, in[1].i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v0 = __shfl_xor(bv[0], o, 64), v1 = __shfl_xor(bv[1], o, 64);
+        const int i0 = __shfl_xor(bi[0], o, 64), i1 = __shfl_xor(bi[1], o, 64);
+        topn_insert<2>(bv, bi, v0, i0);
+        topn_insert<2>(bv, bi, v1, i1);
+    }
+    if (lane == 0) {
+        sel[((size_t)b * 32 + t) * 2] = bi[0];
+        sel[((size_t)b * 32 + t) * 2 + 1] = bi[1];
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
