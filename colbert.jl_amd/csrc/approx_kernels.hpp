@@ -211,11 +211,15 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
     const int wg = blockIdx.x >> 3;           // index inside the group
     const int wg_per_group = gridDim.x >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // bf16 LUT of the 4 bucket weights: bytes 0-3 = {w0, w1}, bytes 4-7 = {w2, w3}
-    const uint32_t lut_lo = pack_bf16(weights[0], weights[1]);
-    const uint32_t lut_hi = pack_bf16(weights[2], weights[3]);
-    uint32_t kmask = 0x06060606u, kbase = 0x01000100u;   // kept in VGPRs so that (x & m) | b is one v_and_or_b32
-    asm volatile("" : "+v"(kmask), "+v"(kbase));
+    // byte LUT in LDS: blut[v] = bf16 bucket weights of the 4 dims packed in byte v (LSB-first 2-bit fields)
+    __shared__ uint2 blut[256];
+    {
+        const int v = threadIdx.x;
+        blut[v] = make_uint2(pack_bf16(weights[v & 3], weights[(v >> 2) & 3]),
+                             pack_bf16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
+    }
+    __syncthreads();
+    uint32_t kmask = 0x06060606u;
     const uint32_t lane_res = (uint32_t)(r * 32 + 8 * g);   // byte offset of this lane's residual bytes in a step
     const uint32_t lane_row = (uint32_t)(4 * g);            // first of the 4 rows this lane finishes
 
@@ -283,14 +287,33 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
 #define CLB_STAGE_C(RB, IV, CELL, TAG)                                                                      \
     {                                                                                                       \
         u32x4 a[4];                                                                                         \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
-            const uint32_t word = (s & 2) ? RB.y : RB.x;                                                    \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
-                if (VARIANT == 1) { a[s][q] = word + q; continue; }                                         \
-                const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;                                \
-                const uint32_t sel = ((nib * 0x808202u) & kmask) | kbase;                                   \
-                a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);                                       \
-            }                                                                                               \
+        /* byte -> 4 bf16 bucket weights through the 2-KB LDS table: 8 ds_read_b64 replace 64 VALU ops.   */ \
+        /* (byte << 3) is one v_bfe_u32 on a word whose other bytes are masked out.                      */ \
+        {                                                                                                   \
+            const uint32_t e0 = RB.x & 0x00ff00ffu, o0 = RB.x & 0xff00ff00u;                                \
+            const uint32_t e1 = RB.y & 0x00ff00ffu, o1 = RB.y & 0xff00ff00u;                                \
+            const uint2 t0 = blut[e0 & 0xffu];                                                  \
+            const uint2 t1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o0, 5, 11));  \
+            const uint2 t2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(e0, 13, 11)); \
+            const uint2 t3 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o0, 21, 11)); \
+            const uint2 t4 = blut[e1 & 0xffu];                                                              \
+            const uint2 t5 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o1, 5, 11));  \
+            const uint2 t6 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(e1, 13, 11)); \
+            const uint2 t7 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o1, 21, 11)); \
+            a[0] = u32x4{t0.x, t0.y, t1.x, t1.y};                                                           \
+            a[1] = u32x4{t2.x, t2.y, t3.x, t3.y};                                                           \
+            a[2] = u32x4{t4.x, t4.y, t5.x, t5.y};                                                           \
+            a[3] = u32x4{t6.x, t6.y, t7.x, t7.y};                                                           \
+        }                                                                                                   \
+        if (VARIANT == 4) {   /* ablation: 64 extra independent VALU ops per step */                        \
+            uint32_t junk = 0;                                                                              \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+                    uint32_t t = a[s][q];                                                                   \
+                    asm volatile("v_xor_b32 %0, %1, %2\n\tv_add_u32 %0, %0, %1\n\tv_xor_b32 %0, %0, %2\n\tv_add_u32 %0, %0, %2" : "=&v"(t) : "v"(a[s][q]), "v"(kmask)); \
+                    junk ^= t;                                                                              \
+                }                                                                                           \
+            asm volatile("" :: "v"(junk));                                                                  \
         }                                                                                                   \
         f32x4 acc0, acc1;                                                                                   \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
@@ -307,9 +330,15 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         }                                                                                                   \
         float v0[4], v1[4];                                                                                 \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-            const bool ok = (int)lane_row + q < TAG.rows;   /* rows past the passage belong to the next one */ \
-            v0[q] = ok ? acc0[q] * IV[q] : kNegInf;                                                         \
-            v1[q] = ok ? acc1[q] * IV[q] : kNegInf;                                                         \
+            v0[q] = acc0[q] * IV[q];                                                                        \
+            v1[q] = acc1[q] * IV[q];                                                                        \
+        }                                                                                                   \
+        if (TAG.rows < 16) {   /* tail step: rows past the passage belong to the next one */               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+                const bool ok = (int)lane_row + q < TAG.rows;                                               \
+                v0[q] = ok ? v0[q] : kNegInf;                                                               \
+                v1[q] = ok ? v1[q] : kNegInf;                                                               \
+            }                                                                                               \
         }                                                                                                   \
         m0 = max3f(m0, v0[0], v0[1]);                                                                       \
         m0 = max3f(m0, v0[2], v0[3]);                                                                       \

@@ -254,14 +254,16 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
         {
             Timed t(s, KID_SCORE_APPROX, st);
             static const int variant = getenv("CLB_DEBUG_APPROX_VARIANT") ? atoi(getenv("CLB_DEBUG_APPROX_VARIANT")) : 0;
+            static const int wgpg = getenv("CLB_DEBUG_APPROX_WGPG") ? atoi(getenv("CLB_DEBUG_APPROX_WGPG")) : 128;
 #define CLB_LAUNCH_APPROX(V)                                                                                         \
-    hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),              \
+    hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * wgpg), dim3(256), 0, st, s->weights.as<float>(),              \
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
                        s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(), \
                        (int)s->K, T, B, s->cand_cap)
             if (variant == 1) CLB_LAUNCH_APPROX(1);
             else if (variant == 2) CLB_LAUNCH_APPROX(2);
             else if (variant == 3) CLB_LAUNCH_APPROX(3);
+            else if (variant == 4) CLB_LAUNCH_APPROX(4);
             else CLB_LAUNCH_APPROX(0);
 #undef CLB_LAUNCH_APPROX
         }
@@ -276,7 +278,8 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
-        const int gx = list ? std::max(1, 1024 / B) : std::max(1, 2048 / B);
+        static const int gxl = getenv("CLB_DEBUG_EXACT_GX") ? atoi(getenv("CLB_DEBUG_EXACT_GX")) : 1024;
+        const int gx = list ? std::max(1, gxl / B) : std::max(1, 2048 / B);
         switch (s->nbits) {
             case 1: launch_score_exact<1>(s, st, dQ, B, T, list, nlist, gx); break;
             case 2: launch_score_exact<2>(s, st, dQ, B, T, list, nlist, gx); break;

@@ -483,11 +483,14 @@ __device__ __forceinline__ void fill_weight_table(float* tbl, const float* __res
 }
 
 // Decompresses the 32 dims {4s+g} of one embedding (canonical order, see decompress_lane_dims) using the LDS
-// table and the reciprocal division.  R = packed residual dwords; returns normalised values in x[].
+// weight table and the reciprocal division.  R = packed residual dwords.  The centroid values come either
+// straight from global memory (cent_row, used by the stand-alone decompress kernel) or from a staged LDS tile
+// (ctile != nullptr: slot(s, r) = s*16 + (r ^ (s & 15)), 16 B per slot -- see score_exact_kernel).
 template <int NBITS>
 __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restrict__ cent_row /*+g*/,
                                                           const uint32_t (&R)[NBITS * 4], int g,
-                                                          const float* __restrict__ tbl, float (&x)[32]) {
+                                                          const float* __restrict__ tbl, float (&x)[32],
+                                                          const float* ctile = nullptr, int r = 0) {
     float p = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
@@ -504,7 +507,8 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
         } else {
             byte = (R[byte_idx >> 2] >> ((byte_idx & 3) * 8)) & 255u;
         }
-        const float val = cent_row[4 * s] + tbl[v * kWTblStride + byte];
+        const float c = ctile ? ctile[(s * 16 + (r ^ (s & 15))) * 4 + g] : cent_row[4 * s];
+        const float val = c + tbl[v * kWTblStride + byte];
         x[s] = val;
         const float sq = val * val;
         p = p + sq;
@@ -523,10 +527,15 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
 }
 
 // grid = (G, B), block = 256 (4 waves).  `list` (optional) restricts the work to the listed candidate slots
-// (two-pass mode).  LDS: the bucket-weight table and the query operand of the current 32-token group, laid out
-// [chunk k][lane][4 floats] = {Q[t0][8k+g'], Q[t1][8k+g'], Q[t0][8k+4+g'], Q[t1][8k+4+g']} (g' = 4-dim stride,
-// i.e. MFMA steps 2k and 2k+1 for token tiles 0/1) so that one conflict-free ds_read_b128 feeds four MFMAs and
-// the operand costs no resident registers (occupancy 2 -> 4+ waves per SIMD).
+// (two-pass mode).  LDS:
+//   * the bucket-weight table;
+//   * the query operand of the current 32-token group, [chunk k][lane][4 floats] = {Q[t0][8k+g'], Q[t1][8k+g'],
+//     Q[t0][8k+4+g'], Q[t1][8k+4+g']}: one conflict-free ds_read_b128 feeds four MFMAs, no resident registers;
+//   * per wave an 8-KB tile of the step's 16 centroid rows.  The rows are fetched as whole 512-B rows (8
+//     coalesced dwordx4 loads, issued one step ahead so that they fly during the MFMA phase) instead of 32
+//     strided dword gathers per lane -- the gathers alone held the kernel at 0.9 ms for 3.4 M embeddings (TA
+//     bound); 16-B chunk c of row r sits at slot c*16 + (r ^ (c & 15)), which makes both the b128 writes and
+//     the stride-4 b32 reads of lane (r, g) at most 2-way bank conflicted.
 template <int NBITS>
 static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
@@ -535,17 +544,22 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const int* __restrict__ list /*optional*/, const int* __restrict__ nlist) {
     constexpr int RD = NBITS * 4;  // residual dwords per embedding
     __shared__ float tbl[(8 / NBITS) * kWTblStride];
-    __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];   // 16 KB
+    __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];    // 16 KB
+    __shared__ __attribute__((aligned(16))) float ctiles[4 * 512 * 4];  // 4 waves x 8 KB
     fill_weight_table<NBITS>(tbl, weights);
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int wave_global = blockIdx.x * 4 + wave;
     const int nwaves = gridDim.x * 4;
     const int n = list ? nlist[b] : ncand[b];
     const int TT = (T + 31) >> 5;
     const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
+    float* ctile = ctiles + wave * 2048;
+    // row loader: instruction m covers rows 2m and 2m+1; this lane moves chunk c4 of row 2m + (lane >> 5)
+    const int c4 = lane & 31, rhalf = lane >> 5;
 
     // stage the query operand of token group tt: every wave uses the same lane -> (token, k) map
     auto stage_q = [&](int tt) {
@@ -565,6 +579,16 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     };
     const float4* qv = reinterpret_cast<const float4*>(qlds) + lane;
 
+#define CLB_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define CLB_ROW_DECL(m) float4 row##m;
+#define CLB_ROW_LOAD(m)                                                                                        \
+    {                                                                                                          \
+        const uint32_t ca = __builtin_amdgcn_readlane(code_rows, 2 * m), cb = __builtin_amdgcn_readlane(code_rows, 2 * m + 1); \
+        row##m = *reinterpret_cast<const float4*>(C + (size_t)(rhalf ? cb : ca) * kDim + 4 * c4);              \
+    }
+#define CLB_ROW_STORE(m)                                                                                       \
+    *reinterpret_cast<float4*>(ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4) = row##m;
+
     // with one token group the passage loop runs per wave; with several, all waves of the workgroup walk the
     // groups together (the staged operand is shared), so the loop order is group-major
     for (int tt = 0; tt < TT; ++tt) {
@@ -577,13 +601,15 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
             const uint32_t off = __builtin_amdgcn_readfirstlane(h.x);
             const int len = (int)__builtin_amdgcn_readfirstlane(h.y);
             float m0 = kNegInf, m1 = kNegInf;
-            // software prefetch: code + packed residual of the next step are loaded during the current one
-            uint32_t code_n;
+            // software prefetch, two steps deep for the codes (the row loads of step i+1 need code(i+1) early)
+            auto code_at = [&](int base) {
+                const int el = base + r;
+                return codes0[off + (uint32_t)(el < len ? el : len - 1)];
+            };
             uint32_t Rn[RD];
-            auto load_step = [&](int base) {
+            auto load_res = [&](int base) {
                 const int el = base + r;
                 const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
-                code_n = codes0[e];
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * (RD * 4));
 #pragma unroll
                 for (int k4 = 0; k4 < RD; k4 += 4) {
@@ -591,17 +617,27 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
                     Rn[k4] = v.x; Rn[k4 + 1] = v.y; Rn[k4 + 2] = v.z; Rn[k4 + 3] = v.w;
                 }
             };
-            load_step(0);
+            uint32_t code_rows = code_at(0);      // code of embedding r in the step whose rows are being fetched
+            uint32_t code_next = code_at(16);     // ... and one step further
+            load_res(0);
+            CLB_REP8(CLB_ROW_DECL)
+            CLB_REP8(CLB_ROW_LOAD)                // rows of step 0
             for (int base = 0; base < len; base += 16) {
-                const uint32_t code = code_n;
                 uint32_t R[RD];
 #pragma unroll
                 for (int k4 = 0; k4 < RD; ++k4) R[k4] = Rn[k4];
-                if (base + 16 < len) load_step(base + 16);
+                CLB_REP8(CLB_ROW_STORE)
+                __builtin_amdgcn_wave_barrier();
+                if (base + 16 < len) load_res(base + 16);
                 float x[32];
-                decompress_lane_dims_fast<NBITS>(C + (size_t)code * kDim + g, R, g, tbl, x);
+                decompress_lane_dims_fast<NBITS>(nullptr, R, g, tbl, x, ctile, r);
+                __builtin_amdgcn_wave_barrier();
+                // rows of the next step fly during the MFMA phase; its codes were requested a step ago
+                code_rows = code_next;
+                if (base + 16 < len) { CLB_REP8(CLB_ROW_LOAD) }
+                code_next = code_at(base + 32);
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 4
                 for (int k = 0; k < 16; ++k) {
                     const float4 q = qv[k * 64];
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.x, a0, 0, 0, 0);
@@ -629,6 +665,10 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
             if (lane == 0) scores[(size_t)b * cand_cap + slot] = total;
         }
     }
+#undef CLB_REP8
+#undef CLB_ROW_DECL
+#undef CLB_ROW_LOAD
+#undef CLB_ROW_STORE
 }
 
 // -------------------------------------------------------------------------------------------------
