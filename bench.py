@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--mode", type=int, default=-1, help="-1 library default, 0 exact, 1 two-pass")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-query-at-a-time latency loop (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -121,7 +122,7 @@ def main():
     s.profile_enable(False)
     lat = []
     one = DeviceSearch(s, T, 1, k, args.nprobe)
-    for i in range(40):
+    for i in range(0 if args.no_latency else 40):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         p, sc = one(Qdev[i:i + 1])
@@ -130,31 +131,47 @@ def main():
             merge_gathered(gp, gs, k)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
-    p50_ms = float(np.median(lat[5:]) * 1e3)
+    p50_ms = float(np.median(lat[5:]) * 1e3) if lat else None
 
     # ---- roofline of the dominant kernel (per launch = one batch on this rank's shard)
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
     roof = None
     if dom:
-        ms_launch = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
-        embs = stats["cand_embs"]; docs = stats["cand_docs"]
-        if dom == "score_exact" and s.mode == 1:
-            embs, docs = stats["rescored_embs"], stats["rescored_docs"]
-        if dom in ("score_exact",):
-            ach = FLOP_PER_EMB * embs / (ms_launch * 1e-3) / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4), "traffic": None}
-        else:
-            if dom == "centroid_scores":
-                alg_bytes = K * 128 * 4.0 + B * K * T * 4.0
+        def roof_of(kname):
+            ms_launch = prof[kname]["ms"] / max(prof[kname]["launches"], 1)
+            embs = stats["cand_embs"]; docs = stats["cand_docs"]
+            if kname == "score_exact" and s.mode == 1:
+                embs, docs = stats["rescored_embs"], stats["rescored_docs"]
+            if kname == "score_exact":
+                ach = FLOP_PER_EMB * embs / (ms_launch * 1e-3) / 1e12
+                r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
+            elif kname == "centroid_scores":
+                ach = 2.0 * 128 * T * K * B / (ms_launch * 1e-3) / 1e12
+                r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
+                embs, docs = K * B, 0
             else:
                 alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
-            ach = alg_bytes / (ms_launch * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        roof["ms_per_launch"] = round(ms_launch, 4)
-        roof["units_per_launch"] = {"cand_embeddings": embs, "cand_passages": docs}
+                ach = alg_bytes / (ms_launch * 1e-3) / 1e9
+                r = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBS, 4)}
+            r["ms_per_launch"] = round(ms_launch, 4)
+            r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
+            return r
+        roof = roof_of(dom)
+        roof["traffic"] = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        kmap = {"score_approx": "score_approx_kernel<0>", "score_exact": "score_exact_kernel<2>",
+                "centroid_scores": "centroid_top2_kernel<true>"}
+        if world == 1 and os.path.exists(pmc_file):      # HBM bytes per launch from the committed PMC passes
+            pmc = json.load(open(pmc_file)).get(kmap.get(dom, dom), {})
+            if "hbm_read_bytes" in pmc:
+                roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
+                roof["traffic_source"] = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(args.steps, 1), 4) for kname, v in prof.items()}
+        roof["other_kernels"] = [roof_of(kn) for kn in ("score_approx", "score_exact", "centroid_scores")
+                                 if kn in prof and kn != dom and prof[kn]["launches"]]
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N = 1
     cpu = None
@@ -185,7 +202,7 @@ def main():
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
                           "search_mode": "two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass"},
-               "p50_latency_ms": round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
+               "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
                "hbm_bytes": s.device_bytes}
         print(json.dumps(out))

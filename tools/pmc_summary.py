@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 output directories into one JSON for profiles/.
+
+    python tools/pmc_summary.py <out.json> <dir> [<dir> ...]
+
+Each <dir> is a `rocprofv3 -d` output (kernel-trace/stats CSVs and/or PMC counter_collection CSVs of
+`bench.py --no-latency --no-cpu`, so every launch is a full batch).  Per kernel: launches, average
+duration, and the average of every collected counter.  FETCH_SIZE / WRITE_SIZE are reported in KB by
+rocprofv3; `hbm_read_bytes` applies the gfx950 correction for wide streaming reads (FETCH_SIZE counts
+128-B requests as 64 B: x2, MI355X_MICROARCH.md section HBM) -- an upper estimate for gather-heavy kernels."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name: str) -> str:
+    n = name.split("(")[0]
+    return n.replace("void ", "").replace("clb::", "").strip()
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    kern = collections.defaultdict(lambda: {"launches": 0, "dur_ns": 0.0, "counters": collections.defaultdict(list)})
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            seen = set()
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                kern[k]["counters"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                key = (f, r["Dispatch_Id"])
+                if key not in seen:
+                    seen.add(key)
+                    kern[k]["launches"] += 1
+                    kern[k]["dur_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Name"])
+                kern[k].setdefault("trace", {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                              "pct": float(r["Percentage"])})
+    res = {}
+    for k, v in kern.items():
+        e = {}
+        if v["launches"]:
+            e["pmc_launches"] = v["launches"]
+            e["pmc_avg_us"] = round(v["dur_ns"] / v["launches"] / 1e3, 2)
+        for c, vals in v["counters"].items():
+            e[c] = round(sum(vals) / len(vals), 2)
+        if "FETCH_SIZE" in e:
+            e["hbm_read_bytes_uncorrected"] = int(e["FETCH_SIZE"] * 1024)
+            e["hbm_read_bytes"] = int(e["FETCH_SIZE"] * 1024 * 2)
+        if "WRITE_SIZE" in e:
+            e["hbm_write_bytes"] = int(e["WRITE_SIZE"] * 1024)
+        if "trace" in v:
+            e["trace"] = v["trace"]
+        res[k] = e
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out, len(res), "kernels")
+
+
+if __name__ == "__main__":
+    main()
