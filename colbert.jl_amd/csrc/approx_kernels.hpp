@@ -24,7 +24,7 @@
 //
 // Error bound (u = 2^-24; qn = max_t ||Q_t||2; cn = max ||c||2; rn = sqrt(dim) * max|w| >= ||r||2;
 // im = max inv_norm), per (t, e):
-//   cells:   fp32 chain vs exact Q.c                 <= 2*128*u*qn*cn          (safety 2x on gamma_128)
+//   cells:   bf16x3 MFMA value vs canonical fp32 chain <= 1.25*7.4e-5*qn*cn       (centroid_top_bf16x3_kernel)
 //            fp16 storage                            <= 2^-11 * qn*cn          (|cells| <= qn*cn < 65504)
 //   Q.r:     bf16(Q), bf16(w) relative 2^-9 each     <= (2^-8 + 2^-18) * qn*rn
 //            fp32 accumulation in the MFMA           <= 2*128*u*qn*rn
@@ -100,6 +100,236 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, o, 64));
     if (lane == 0) atomicMax(inv_max_bits, __float_as_uint(vmax));
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// S1 + S2 at the bf16-MFMA rate with exact selection ("bf16x3"): every fp32 operand is split x = hi + lo + d,
+// |d| <= 2^-18 |x| (hi, lo bf16), and Q.c ~= Qh.Ch + Qh.Cl + Ql.Ch on v_mfma_f32_32x32x16_bf16 (24 MFMAs of 32
+// cycles per 32x32 tile instead of 64 fp32 MFMAs of 64 cycles).  Bound on |approx - canonical fp32 chain|:
+//   split (3 dropped terms)  3 * 2^-18 * qn*cn ;  fp32 accumulation of 384 products  2*384*u*qn*cn ;
+//   canonical chain vs real arithmetic  2*128*u*qn*cn      =>  eps_c = kEpsSafety * 7.4e-5 * qn * cn.
+// Per token the 8 best approximate centroids are kept; with a2 = 2nd best approximate score every centroid whose
+// approximate score is >= a2 - 2 eps_c is re-scored with the canonical fp32 fmaf chain (top_refine_kernel) and the
+// exact top-nprobe by (score desc, index asc) comes out -- the same ids as the fp32 kernel, bit for bit.  If more
+// than 8 centroids could qualify the query is flagged and redone by the fp32 kernel (never seen in practice).
+// -------------------------------------------------------------------------------------------------------------
+constexpr int kRowBytes16 = 272;   // staged bf16 row: 256 B + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
+constexpr int kTopPartial = 4;     // per-lane list length in the bf16x3 kernel
+constexpr int kTopRefine = 8;      // candidates re-scored exactly per token
+
+static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                         uint16_t* __restrict__ lo, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const uint32_t h = f32_to_bf16_rne(v);
+    const float rem = v - __uint_as_float(h << 16);
+    hi[i] = (uint16_t)h;
+    lo[i] = (uint16_t)f32_to_bf16_rne(rem);
+}
+
+template <int NP>
+__device__ __forceinline__ void topn_insert_lazy(float (&bv)[NP], int (&bi)[NP], float v, int idx) {
+    // wave-level fast reject: after the first few tiles almost no value beats a lane's NP-th best
+    if (__builtin_amdgcn_ballot_w64(v > bv[NP - 1]) != 0) topn_insert<NP>(bv, bi, v, idx);
+}
+
+// grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * 2 arrays * 32 rows * 272 B.
+// partial: [B][nslots][32][kTopPartial], nslots = waves * 2 halves.
+template <bool WRITE_HALF>
+static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_kernel(
+    const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
+    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    unsigned char* my = lds16 + wave * (2 * 32 * kRowBytes16);
+    // B operand: token i, dims 64h + 8s + j (the k index is a permutation of the dims, same for A)
+    u32x4 qh[8], ql[8];
+    {
+        const float* qrow = Q + ((size_t)b * T + (i < T ? i : T - 1)) * kDim + 64 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 8 * s);
+            const float4 c = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            uint32_t hh[8], ll[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = i < T ? v[j] : 0.f;
+                hh[j] = f32_to_bf16_rne(x);
+                ll[j] = f32_to_bf16_rne(x - __uint_as_float(hh[j] << 16));
+            }
+            qh[s] = u32x4{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+            ql[s] = u32x4{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+        }
+    }
+    float bv[kTopPartial];
+    int bi[kTopPartial];
+#pragma unroll
+    for (int p = 0; p < kTopPartial; ++p) { bv[p] = kNegInf; bi[p] = 0x7fffffff; }
+    const int waves_total = gridDim.x * 2;
+    int tile = blockIdx.x * 2 + wave;
+    const int prow = lane >> 4, pchunk = lane & 15;   // loader: instruction m covers rows 4m..4m+3, 16 chunks each
+#define CLB_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define CLB_PF_DECL(m) uint4 ph##m, pl##m;
+#define CLB_PF_LOAD(m)                                                                        \
+    {                                                                                         \
+        int c = tl * 32 + 4 * m + prow;                                                       \
+        c = c < K ? c : K - 1;                                                                \
+        ph##m = *reinterpret_cast<const uint4*>(Chi + (size_t)c * kDim + 8 * pchunk);          \
+        pl##m = *reinterpret_cast<const uint4*>(Clo + (size_t)c * kDim + 8 * pchunk);          \
+    }
+#define CLB_PF_STORE(m)                                                                                          \
+    *reinterpret_cast<uint4*>(my + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = ph##m;                          \
+    *reinterpret_cast<uint4*>(my + 32 * kRowBytes16 + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = pl##m;
+    CLB_REP8(CLB_PF_DECL)
+    {
+        const int tl = tile < n_tiles ? tile : n_tiles - 1;
+        CLB_REP8(CLB_PF_LOAD)
+    }
+    while (tile < n_tiles) {
+        const int c0 = tile * 32;
+        CLB_REP8(CLB_PF_STORE)
+        const int next = tile + waves_total;
+        {
+            const int tl = next < n_tiles ? next : n_tiles - 1;
+            CLB_REP8(CLB_PF_LOAD)
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(my + i * kRowBytes16 + 16 * (8 * h + s));
+            const u32x4 al = *reinterpret_cast<const u32x4*>(my + 32 * kRowBytes16 + i * kRowBytes16 + 16 * (8 * h + s));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, qh[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, ql[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, qh[s]), acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            topn_insert_lazy<kTopPartial>(bv, bi, c < K ? acc[r] : kNegInf, c);
+            if (WRITE_HALF) {
+                const float other = __shfl_xor(acc[r], 16, 64);
+                if ((i & 16) == 0 && c < K) {
+                    const __half2 hv = __floats2half2_rn(acc[r], other);
+                    cells16[((size_t)b * K + c) * 16 + i] = *reinterpret_cast<const uint32_t*>(&hv);
+                }
+            }
+        }
+        tile = next;
+    }
+#undef CLB_REP8
+#undef CLB_PF_DECL
+#undef CLB_PF_LOAD
+#undef CLB_PF_STORE
+    const int slot = (blockIdx.x * 2 + wave) * 2 + h;
+    const int nslots = gridDim.x * 4;
+    ValIdx* out = partial + (((size_t)b * nslots + slot) * 32 + i) * kTopPartial;
+#pragma unroll
+    for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv[p], bi[p]};
+}
+
+// One wave per (token, query): merge the partial lists to the 8 best approximate centroids, re-score with the
+// canonical fp32 chain those within 2 eps_c of the 2nd best, emit the exact top-2.  grid = (32, B), block = 64.
+static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __restrict__ partial,
+                                                              const float* __restrict__ C,
+                                                              const float* __restrict__ Q, int T, int K,
+                                                              int nslots, float cn_max, int* __restrict__ sel,
+                                                              int* __restrict__ redo_flag) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (t >= T) {
+        if (lane == 0) { sel[((size_t)b * 32 + t) * 2] = 0; sel[((size_t)b * 32 + t) * 2 + 1] = 0; }
+        return;
+    }
+    float bv[kTopRefine];
+    int bi[kTopRefine];
+#pragma unroll
+    for (int p = 0; p < kTopRefine; ++p) { bv[p] = kNegInf; bi[p] = 0x7fffffff; }
+    float fourth_max = kNegInf;   // largest "last entry" of any partial list this lane saw
+    for (int sl = lane; sl < nslots; sl += 64) {
+        const ValIdx* in = partial + (((size_t)b * nslots + sl) * 32 + t) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) topn_insert_lazy<kTopRefine>(bv, bi, in[p].v, in[p].i);
+        fourth_max = fmaxf(fourth_max, in[kTopPartial - 1].v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov[kTopRefine];
+        int oi[kTopRefine];
+#pragma unroll
+        for (int p = 0; p < kTopRefine; ++p) { ov[p] = __shfl_xor(bv[p], o, 64); oi[p] = __shfl_xor(bi[p], o, 64); }
+#pragma unroll
+        for (int p = 0; p < kTopRefine; ++p) topn_insert<kTopRefine>(bv, bi, ov[p], oi[p]);
+        fourth_max = fmaxf(fourth_max, __shfl_xor(fourth_max, o, 64));
+    }
+    // every lane now holds the same top-8; error bound of the approximate scores for this token
+    const float* q = Q + ((size_t)b * T + t) * kDim;
+    __shared__ float qs[kDim];
+    qs[lane] = q[lane];
+    qs[lane + 64] = q[lane + 64];
+    __syncthreads();
+    float qq = qs[lane] * qs[lane] + qs[lane + 64] * qs[lane + 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float eps_c = kEpsSafety * 7.4e-5f * (sqrtf(qq) * 1.001f) * cn_max;
+    const float thr = bv[1] - 2.f * eps_c;
+    // a partial list that is full down to its last entry above thr may have dropped a qualifying centroid;
+    // so may the merged list -- flag the query for the fp32 kernel
+    const bool overflow = (K > kTopRefine && bv[kTopRefine - 1] >= thr) || (K > kTopPartial && fourth_max >= thr);
+    float tv[2] = {kNegInf, kNegInf};
+    int ti[2] = {0x7fffffff, 0x7fffffff};
+    if (!overflow) {
+        // lanes 0..7 re-score candidate `lane` exactly
+        float ex = kNegInf;
+        int id = 0x7fffffff;
+#pragma unroll
+        for (int p = 0; p < kTopRefine; ++p)
+            if (lane == p) { ex = bv[p]; id = bi[p]; }
+        const bool valid = lane < kTopRefine && id != 0x7fffffff && ex >= thr;
+        if (valid) {
+            const float4* c4 = reinterpret_cast<const float4*>(C + (size_t)id * kDim);
+            float4 cr[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) cr[m] = c4[m];               // all loads in flight, then the ordered chain
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {                            // the chain the fp32 MFMA kernel performs
+                a = fmaf(cr[m].x, qs[4 * m], a);
+                a = fmaf(cr[m].y, qs[4 * m + 1], a);
+                a = fmaf(cr[m].z, qs[4 * m + 2], a);
+                a = fmaf(cr[m].w, qs[4 * m + 3], a);
+            }
+            topn_insert<2>(tv, ti, a, id);
+        }
+    } else {
+        // too many near-ties for the candidate lists (never seen in practice): this wave scores every centroid
+        // for its token with the canonical chain
+        for (int c = lane; c < K; c += 64) {
+            const float* cr = C + (size_t)c * kDim;
+            float a = 0.f;
+            for (int d = 0; d < kDim; ++d) a = fmaf(cr[d], qs[d], a);
+            topn_insert<2>(tv, ti, a, c);
+        }
+        if (lane == 0) atomicAdd(&redo_flag[b], 1);   // statistics only
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v0 = __shfl_xor(tv[0], o, 64), v1 = __shfl_xor(tv[1], o, 64);
+        const int i0 = __shfl_xor(ti[0], o, 64), i1 = __shfl_xor(ti[1], o, 64);
+        topn_insert<2>(tv, ti, v0, i0);
+        topn_insert<2>(tv, ti, v1, i1);
+    }
+    if (lane == 0) {
+        sel[((size_t)b * 32 + t) * 2] = ti[0];
+        sel[((size_t)b * 32 + t) * 2 + 1] = ti[1] == 0x7fffffff ? ti[0] : ti[1];
+    }
 }
 
 // ---- cells fp32 [K][Tpad=32] -> fp16 pairs [K][16] {t, t+16}.  grid = (blocks, B), block = 256 -----------------
@@ -450,7 +680,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         }
         const float u = 5.9604645e-08f;  // 2^-24
         const float qn = s_qn;
-        const float e_cells = 2.f * 128.f * u * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
+        const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
         const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
         const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
@@ -509,16 +739,17 @@ static __global__ void max_row_norm_kernel(const float* __restrict__ C, int K, u
 
 // index-load: inv_norm array + the constants of the error bound
 inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW, const uint32_t* dCodes0,
-                               const uint8_t* dRes, int64_t n_emb, int K, float* d_inv_norm, ApproxConsts* out) {
+                               const uint8_t* dRes, int64_t n_emb, int K, float* d_inv_norm /*null: constants only*/,
+                               int n_weights, ApproxConsts* out) {
     DevBuf tmp;
     CLB_TRY(tmp.alloc(3 * sizeof(unsigned int)));
     CLB_HIP(hipMemsetAsync(tmp.p, 0, 3 * sizeof(unsigned int), st));
     unsigned int* bits = tmp.as<unsigned int>();
-    if (n_emb > 0) {
+    if (n_emb > 0 && d_inv_norm) {
         const int grid = (int)std::min<int64_t>(4096, (n_emb + 63) / 64);
         hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, d_inv_norm, bits);
     }
-    hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, 4, bits + 1);
+    hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 1);
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
     CLB_HIP(hipGetLastError());
     unsigned int h[3];

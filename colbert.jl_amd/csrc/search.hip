@@ -61,6 +61,9 @@ struct clb_searcher {
     DevBuf ivf_off;     // u32 [K+1]
     DevBuf ivf_pid;     // u32 [n_emb] local passage ids grouped by centroid
     DevBuf inv_norm;    // fp32 [n_emb]  (two-pass mode)
+    DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
+    DevBuf redo;        // int [B] queries whose centroid selection must be redone in fp32
+    int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
     // workspace, sized for (Bcap, Tcap, nprobe_cap, kcap)
@@ -173,24 +176,48 @@ int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T,
     const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
     if (nprobe <= 2 && T <= 32) {
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
-        const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B)));
+        const int gx = std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
         const int nslots = gx * 4;
-        CLB_TRY(s->partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * 2));
-        {
-            Timed t(s, KID_CENTROID_SCORES, st);
-            if (want_half)
-                hipLaunchKernelGGL(centroid_top2_kernel<true>, dim3(gx, B), dim3(128),
-                                   2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
-                                   s->partial.as<ValIdx>(), s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
-            else
-                hipLaunchKernelGGL(centroid_top2_kernel<false>, dim3(gx, B), dim3(128),
-                                   2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
-                                   s->partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, n_tiles);
-        }
-        {
-            Timed t(s, KID_TOPN, st);
-            hipLaunchKernelGGL(top2_merge_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
-                               s->sel.as<int>(), nslots);
+        CLB_TRY(s->partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
+        const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
+        if (s->s1_mode == 1 && s->cent_hi.p) {
+            CLB_TRY(s->redo.ensure(sizeof(int) * B));
+            CLB_HIP(hipMemsetAsync(s->redo.p, 0, sizeof(int) * B, st));
+            {
+                Timed t(s, KID_CENTROID_SCORES, st);
+                const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
+                if (want_half)
+                    hipLaunchKernelGGL(centroid_top_bf16x3_kernel<true>, dim3(gx, B), dim3(128), lds_b16, st,
+                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
+                                       s->partial.as<ValIdx>(), s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
+                else
+                    hipLaunchKernelGGL(centroid_top_bf16x3_kernel<false>, dim3(gx, B), dim3(128), lds_b16, st,
+                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
+                                       s->partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, n_tiles);
+            }
+            {
+                Timed t(s, KID_TOPN, st);
+                hipLaunchKernelGGL(top_refine_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
+                                   s->centroids.as<float>(), dQ, T, (int)s->K, nslots, s->approx_consts.cn_max,
+                                   s->sel.as<int>(), s->redo.as<int>());
+            }
+        } else {
+            {
+                Timed t(s, KID_CENTROID_SCORES, st);
+                if (want_half)
+                    hipLaunchKernelGGL(centroid_top2_kernel<true>, dim3(gx, B), dim3(128), lds_f32, st,
+                                       s->centroids.as<float>(), dQ, s->partial.as<ValIdx>(),
+                                       s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles, (const int*)nullptr);
+                else
+                    hipLaunchKernelGGL(centroid_top2_kernel<false>, dim3(gx, B), dim3(128), lds_f32, st,
+                                       s->centroids.as<float>(), dQ, s->partial.as<ValIdx>(), (uint32_t*)nullptr,
+                                       (int)s->K, T, n_tiles, (const int*)nullptr);
+            }
+            {
+                Timed t(s, KID_TOPN, st);
+                hipLaunchKernelGGL(top2_merge_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
+                                   s->sel.as<int>(), nslots, (const int*)nullptr);
+            }
         }
     } else {
         {
@@ -391,15 +418,22 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     if (herr & 1) return bail(fail(CLB_EBOUNDS, "ivf holds embedding ids outside 1..n_emb"));
     if (herr & 2) return bail(fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!"));
 
+    {   // bf16 hi/lo split of the centroids for the bf16x3 centroid scoring
+        if ((rc = s->cent_hi.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
+        if ((rc = s->cent_lo.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
+        const int64_t nel = dim * K;
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s->stream,
+                           s->centroids.as<float>(), s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), nel);
+    }
     s->approx_ok = approx_supported((int)dim, nbits);
     if (s->approx_ok) {
         if ((rc = s->inv_norm.alloc(sizeof(float) * (n_emb + 16)))) return bail(rc);
         if (hipMemsetAsync(s->inv_norm.p, 0, s->inv_norm.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
-        if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
-                                      s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb, (int)K,
-                                      s->inv_norm.as<float>(), &s->approx_consts)))
-            return bail(rc);
     }
+    if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
+                                  s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb, (int)K,
+                                  s->approx_ok ? s->inv_norm.as<float>() : nullptr, 1 << nbits, &s->approx_consts)))
+        return bail(rc);
     s->mode = s->approx_ok ? 1 : 0;
     s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
                                s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes + s->inv_norm.bytes);

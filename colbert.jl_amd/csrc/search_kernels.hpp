@@ -180,11 +180,12 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                     const float* __restrict__ Q,
                                                                     ValIdx* __restrict__ partial,
                                                                     uint32_t* __restrict__ cells16, int K, int T,
-                                                                    int n_tiles) {
+                                                                    int n_tiles, const int* __restrict__ only_flagged) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    if (only_flagged && only_flagged[b] == 0) return;
     float* my = lds + wave * (32 * kCentTileStride);
     float qf[64];
     {
@@ -265,8 +266,10 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
 // Merge of the per-slot top-2 lists: one wave per (token, query).  grid = (32, B), block = 64.
 // sel layout as topn_final_kernel<2>: [B][32][2].
 static __global__ __launch_bounds__(64) void top2_merge_kernel(const ValIdx* __restrict__ partial,
-                                                              int* __restrict__ sel, int nslots) {
+                                                              int* __restrict__ sel, int nslots,
+                                                              const int* __restrict__ only_flagged) {
     const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (only_flagged && only_flagged[b] == 0) return;
     float bv[2] = {kNegInf, kNegInf};
     int bi[2] = {0x7fffffff, 0x7fffffff};
     for (int sl = lane; sl < nslots; sl += 64) {
