@@ -40,7 +40,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-at-a-time latency loop (profiling runs)")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the all-gather + merge path even with one rank (testing)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): anything libraries print while we run (RCCL prints a version
+    # banner on communicator creation) is sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import colbert_jl_amd as clb
@@ -50,9 +57,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
@@ -82,17 +90,19 @@ def main():
     merged_p = torch.empty((B, k), dtype=torch.int64, device=dev)
     merged_s = torch.empty((B, k), dtype=torch.float32, device=dev)
 
+    gather = world > 1 or args.force_gather
+
     def step(i):
         off = (i * B) % (n_queries - B + 1)
         p, sc = run(Qdev[off:off + B])
-        if world > 1:
+        if gather:
             gp, gs = all_gather_topk(p, sc)
             return merge_gathered(gp, gs, k, out_p=merged_p, out_s=merged_s)
         return p, sc
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,7 +136,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         p, sc = one(Qdev[i:i + 1])
-        if world > 1:
+        if gather:
             gp, gs = all_gather_topk(p, sc)
             merge_gathered(gp, gs, k)
         torch.cuda.synchronize()
@@ -205,10 +215,13 @@ def main():
                "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
                "hbm_bytes": s.device_bytes}
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     s.close()
+    if gather:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

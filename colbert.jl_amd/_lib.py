@@ -77,6 +77,14 @@ def lib() -> C.CDLL:
             raise ColBERTError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 (same SONAME as the
+        # system one this library links against).  Whichever is loaded first serves both; torch cannot
+        # initialise on top of the system copy, so when torch is installed it is imported first.
+        if os.environ.get("COLBERT_HIP_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         l.clb_version.restype = C.c_char_p
         l.clb_last_error.restype = C.c_char_p

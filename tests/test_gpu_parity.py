@@ -263,6 +263,55 @@ def test_search_ties_keep_ascending_pid(oracle):
     check_search(oracle, idx, synthetic.make_queries(idx, 18, 2), k=60)
 
 
+def test_search_tied_centroids(oracle):
+    """Many identical centroids: every score ties, the bf16x3 candidate lists overflow and the refine kernel must
+    fall back to the exhaustive canonical scan -- the selected centroids are still the lowest indices
+    (partialsortperm's tie rule), so candidates and results equal the oracle's."""
+    idx = synthetic.make_index(seed=29, n_docs=600, K=96)
+    C = idx["centroids"].copy(order="F")
+    C[:, 10:70] = C[:, [10]]                                       # 60 identical centroids
+    C[:, 80:90] = C[:, [10]] * np.float32(1.0)                     # and 10 more copies further up
+    idx["centroids"] = C
+    Qs = synthetic.make_queries(idx, 30, 2)
+    Qs[:, :8, 0] = (C[:, [10]] / np.linalg.norm(C[:, 10])).astype(np.float32)   # tokens aligned with the tied group
+    check_search(oracle, idx, Qs, k=40)
+    s = clb.Searcher(index=idx)
+    for j in range(2):
+        assert np.array_equal(s.retrieve(Qs[:, :, j]),
+                              oracle.retrieve(idx["ivf"], idx["ivf_lengths"], idx["centroids"],
+                                              oracle.build_emb2pid(idx["doclens"]), 2, Qs[:, :, j]))
+    s.close()
+
+
+def test_device_merge_kernel_matches_unsharded(oracle):
+    """The multi-GPU data path on one GPU: per-shard device search -> stacked (world, B, k) records (what
+    all_gather_into_tensor produces) -> clb_merge_topk_device == unsharded oracle result."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch, merge_gathered
+    from colbert_jl_amd.sharding import shard_index
+    idx = synthetic.make_index(seed=33, n_docs=5000, K=512)
+    Qs = synthetic.make_queries(idx, 34, 4)
+    k, world = 300, 4
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    gp, gs, keep = [], [], []
+    for rnk in range(world):
+        sub, off = shard_index(idx, rnk, world)
+        s = clb.Searcher(index=sub, pid_offset=off)
+        run = DeviceSearch(s, 32, Qs.shape[2], k, 2)
+        p, sc = run(Qdev)
+        torch.cuda.synchronize()
+        gp.append(p.clone()); gs.append(sc.clone()); keep.append(s)
+    mp, ms = merge_gathered(torch.stack(gp), torch.stack(gs), k)
+    torch.cuda.synchronize()
+    mp = mp.cpu().numpy(); ms = ms.cpu().numpy()
+    for j in range(Qs.shape[2]):
+        rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
+        assert np.array_equal(mp[j], rp)
+        assert_same_f32(ms[j], rs, "device-merged scores")
+    for s in keep:
+        s.close()
+
+
 def test_search_bounds_error_and_padding(oracle):
     idx = synthetic.make_index(seed=19, n_docs=300, K=64)
     Q = synthetic.make_queries(idx, 20, 1)
