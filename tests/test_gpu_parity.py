@@ -439,3 +439,45 @@ def test_full_size_against_oracle(big, oracle):
             assert s.last_num_candidates == rn
             assert np.array_equal(pids, rp)
             assert_same_f32(scores, rs, f"100k scores mode={mode}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# index() end to end on the device, then Searcher(index_path) + search (BASELINE config 2, scaled down)
+# ---------------------------------------------------------------------------------------------------
+def test_index_then_search_end_to_end(oracle, tmp_path):
+    embs, doclens = synthetic.make_embeddings(seed=51, n_docs=3000, n_components=256)
+    enc = clb.PrecomputedEncoder(embs, doclens)
+    cfg = clb.ColBERTConfig(index_path=str(tmp_path / "idx"), chunksize=1000, kmeans_niters=4, nbits=2)
+    idxr = clb.Indexer(cfg, encoder=enc, collection=list(range(3000)), seed=3)
+    assert clb.index(idxr) == cfg.index_path
+    assert clb.index(idxr) is None                                  # indexing.jl:64-67: directory exists -> skip
+    from colbert_jl_amd import storage
+    assert storage.check_all_files_are_saved(cfg.index_path)
+    plan = storage.load_json(cfg.index_path, "plan.json")
+    assert plan["num_chunks"] == 3 and plan["num_embeddings"] == int(doclens.sum())
+    assert plan["embeddings_offsets"][0] == 1
+    idx = storage.load_index(cfg.index_path)
+    K = plan["num_partitions"]
+    assert idx["centroids"].shape == (128, K) and np.array_equal(idx["doclens"], doclens)
+    # every stage's output equals the oracle's on the same inputs (stage-wise parity)
+    rc, rr = oracle.compress(idx["centroids"], idx["bucket_cutoffs"], 128, 2, embs)
+    assert np.array_equal(idx["codes"], rc) and np.array_equal(idx["residuals"], rr)
+    rivf, rlens = oracle.build_ivf(idx["codes"], K)
+    assert np.array_equal(idx["ivf"], rivf) and np.array_equal(idx["ivf_lengths"], rlens)
+    sample = storage._load(cfg.index_path + "/sample"); held = storage._load(cfg.index_path + "/sample_heldout")
+    rcut, rw, ravg, _ = oracle.compute_avg_residuals(2, idx["centroids"], held)
+    assert_same_f32(idx["bucket_cutoffs"], rcut, "cutoffs"); assert_same_f32(idx["bucket_weights"], rw, "weights")
+    assert np.isclose(float(idx["avg_residual"]), ravg, rtol=1e-5)
+    assert sample.shape[0] == 128 and held.shape[1] == codec.heldout_size(sample.shape[1] + held.shape[1])
+    # search through Searcher(index_path): queries near passages of the collection
+    s = clb.Searcher(cfg.index_path)
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    rng = np.random.default_rng(52)
+    for p in (5, 1234, 2999):
+        cols = off[p] + rng.integers(0, doclens[p], size=32)
+        Q = np.asfortranarray(embs[:, cols])
+        pids, scores = clb.search(s, Q, 20)
+        rp, rs, _ = oracle.search(idx, Q, nprobe=cfg.nprobe, k=20)
+        assert np.array_equal(pids, rp) and pids[0] == p + 1       # the passage itself wins
+        assert_same_f32(scores, rs, "end-to-end scores")
+    s.close()
