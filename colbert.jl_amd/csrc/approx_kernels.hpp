@@ -494,9 +494,16 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
     {                                                                                                       \
         const bool live = it_k < nd;                                                                        \
         const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
+        if (VARIANT == 5) {   /* ablation: no streaming loads */                                           \
+            RB = make_uint2(e0 * 2654435761u + lane_res, e0 ^ lane_res);                                    \
+            CV = u32x4{(e0 + lane_row) & 131071u, (e0 * 7u + lane_row) & 131071u, (e0 * 13u) & 131071u, (e0 * 29u) & 131071u}; \
+            IV = f32x4{1.f, 1.f, 1.f, 1.f};                                                                 \
+        } else {                                                                                            \
+        /* plain loads: non-temporal hints on these once-read streams were measured 7 % slower */          \
         RB = *reinterpret_cast<const uint2*>(residuals + (size_t)e0 * 32 + lane_res);                       \
         CV = *reinterpret_cast<const u32x4_a4*>(codes0 + (size_t)e0 + lane_row);                            \
         IV = *reinterpret_cast<const f32x4_a4*>(inv_norm + (size_t)e0 + lane_row);                          \
+        }                                                                                                   \
         const int left = it_len - it_base;                                                                  \
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \
         TAG.rows = left < 16 ? left : 16;                                                                   \

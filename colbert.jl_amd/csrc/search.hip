@@ -291,6 +291,7 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
             else if (variant == 2) CLB_LAUNCH_APPROX(2);
             else if (variant == 3) CLB_LAUNCH_APPROX(3);
             else if (variant == 4) CLB_LAUNCH_APPROX(4);
+            else if (variant == 5) CLB_LAUNCH_APPROX(5);
             else CLB_LAUNCH_APPROX(0);
 #undef CLB_LAUNCH_APPROX
         }
