@@ -1,0 +1,228 @@
+// encoder.hip -- the Checkpoint encoder entry points of the C ABI: BERT forward + ColBERT projection
+// (`doc`, src/modelling/checkpoint.jl:21-25) and the two encode paths with their epilogues
+// (`_doc_embeddings_and_doclens` :27-52, `_query_embeddings` :54-71).
+#include <algorithm>
+#include <cmath>
+
+#include "codec_kernels.hpp"
+#include "encoder_kernels.hpp"
+
+using namespace clb;
+
+struct clb_encoder {
+    int device = 0;
+    int64_t vocab = 0, H = 0, layers = 0, heads = 0, I = 0, max_pos = 0, type_vocab = 0, dim = 0;
+    float eps = 1e-12f;
+    hipStream_t stream = nullptr;
+    DevBuf weights;
+    // offsets (in floats) into the blob
+    int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
+    // per-layer relative offsets
+    int64_t r_wqkv = 0, r_bqkv = 0, r_wo = 0, r_bo = 0, r_g1 = 0, r_b1n = 0, r_w1 = 0, r_b1 = 0, r_w2 = 0, r_b2 = 0, r_g2 = 0, r_b2n = 0;
+    // workspace
+    DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err;
+};
+
+namespace {
+
+inline int blocks_for(int64_t n, int bs = 256) { return (int)std::max<int64_t>(1, (n + bs - 1) / bs); }
+
+int64_t expected_weights(const clb_encoder* e) {
+    const int64_t H = e->H, I = e->I;
+    const int64_t per_layer = 3 * H * H + 3 * H + H * H + H + 2 * H + I * H + I + H * I + H + 2 * H;
+    return e->vocab * H + e->max_pos * H + e->type_vocab * H + 2 * H + e->layers * per_layer + e->dim * H + e->dim;
+}
+
+void gemm(hipStream_t st, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N, int K,
+          int64_t lda, int64_t ldb_n, int64_t ldb_k, int64_t ldc, int epi, float scale = 1.0f, int zo = 1, int zi = 1,
+          int64_t a_so = 0, int64_t a_si = 0, int64_t b_so = 0, int64_t b_si = 0, int64_t c_so = 0, int64_t c_si = 0) {
+    GemmArgs g{A, B, C, bias, R, M, N, K, lda, ldb_n, ldb_k, ldc, zi, a_so, a_si, b_so, b_si, c_so, c_si, scale, epi};
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, zo * zi), dim3(256), 0, st, g);
+}
+
+// forward for N sequences of length L already uploaded to e->ids / e->mask; result in e->out ((N*L) x dim)
+int forward(clb_encoder* e, int64_t L, int64_t N) {
+    const int64_t T = L * N, H = e->H, I = e->I, heads = e->heads, dh = H / heads;
+    hipStream_t st = e->stream;
+    const float* W = e->weights.as<float>();
+    CLB_TRY(e->x.ensure(sizeof(float) * T * H));
+    CLB_TRY(e->qkv.ensure(sizeof(float) * T * 3 * H));
+    CLB_TRY(e->scores.ensure(sizeof(float) * N * heads * L * L));
+    CLB_TRY(e->ctx.ensure(sizeof(float) * T * H));
+    CLB_TRY(e->hbuf.ensure(sizeof(float) * T * I));
+    CLB_TRY(e->tmp.ensure(sizeof(float) * T * H));
+    CLB_TRY(e->out.ensure(sizeof(float) * T * e->dim));
+    CLB_TRY(e->err.ensure(sizeof(int)));
+    CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, e->ids.as<int32_t>(), T, (int)L,
+                       (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
+                       e->x.as<float>(), e->err.as<int>());
+    float* x = e->x.as<float>();
+    float* qkv = e->qkv.as<float>();
+    float* sc = e->scores.as<float>();
+    float* ctx = e->ctx.as<float>();
+    float* hb = e->hbuf.as<float>();
+    float* tmp = e->tmp.as<float>();
+    const float inv_sqrt = 1.0f / std::sqrt((float)dh);
+    for (int64_t l = 0; l < e->layers; ++l) {
+        const float* P = W + e->o_layer0 + l * e->layer_stride;
+        // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
+        gemm(st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, H, H, 1, 3 * H, EPI_BIAS);
+        // scores[n, head] = Q K^T / sqrt(dh)
+        gemm(st, qkv, qkv + H, sc, nullptr, nullptr, (int)L, (int)L, (int)dh, 3 * H, 3 * H, 1, L, 0, inv_sqrt, (int)N, (int)heads,
+             L * 3 * H, dh, L * 3 * H, dh, heads * L * L, L * L);
+        hipLaunchKernelGGL(masked_softmax_kernel, dim3(blocks_for(N * heads * L, 4)), dim3(256), 0, st, sc, N * heads * L, (int)L,
+                           (int)heads, e->mask.as<uint8_t>());
+        // context[n, head] = P V   (B(k = key, n = dim) = V[key][dim]: ldb_k = 3H, ldb_n = 1)
+        gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
+             heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
+        // attention output + residual, LayerNorm
+        gemm(st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, H, H, 1, H, EPI_BIAS | EPI_RESID);
+        hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, tmp, T, (int)H, P + e->r_g1, P + e->r_b1n, e->eps);
+        // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
+        gemm(st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, H, H, 1, I, EPI_BIAS | EPI_GELU);
+        gemm(st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, I, I, 1, H, EPI_BIAS | EPI_RESID);
+        hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, x, T, (int)H, P + e->r_g2, P + e->r_b2n, e->eps);
+    }
+    // ColBERT projection: Layers.Dense(hidden -> dim)
+    gemm(st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, H, H, 1, e->dim, EPI_BIAS);
+    CLB_HIP(hipGetLastError());
+    int herr = 0;
+    CLB_HIP(hipMemcpyAsync(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (herr) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    return CLB_OK;
+}
+
+int upload_inputs(clb_encoder* e, const int32_t* ids, const uint8_t* mask, int64_t L, int64_t N) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (L < 1 || N < 1) return fail(CLB_EARGUMENT, "empty batch");
+    if (L > e->max_pos) return fail(CLB_EBOUNDS, "sequence length %lld exceeds max_position_embeddings %lld", (long long)L, (long long)e->max_pos);
+    CLB_TRY(use_device(e->device));
+    CLB_TRY(e->ids.ensure(sizeof(int32_t) * L * N));
+    CLB_TRY(e->mask.ensure((size_t)L * N));
+    CLB_HIP(hipMemcpyAsync(e->ids.p, ids, sizeof(int32_t) * L * N, hipMemcpyHostToDevice, e->stream));
+    CLB_HIP(hipMemcpyAsync(e->mask.p, mask, (size_t)L * N, hipMemcpyHostToDevice, e->stream));
+    return CLB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers, int64_t heads, int64_t intermediate,
+                       int64_t max_pos, int64_t type_vocab, int64_t dim, float ln_eps, const float* weights,
+                       int64_t n_weights, clb_encoder** out) {
+    if (!out) return fail(CLB_EARGUMENT, "out is null");
+    *out = nullptr;
+    if (vocab < 1 || hidden < 1 || layers < 0 || heads < 1 || hidden % heads || intermediate < 1 || max_pos < 1 ||
+        type_vocab < 1 || dim < 1)
+        return fail(CLB_EARGUMENT, "invalid encoder shape");
+    clb_encoder* e = new clb_encoder();
+    e->device = device; e->vocab = vocab; e->H = hidden; e->layers = layers; e->heads = heads; e->I = intermediate;
+    e->max_pos = max_pos; e->type_vocab = type_vocab; e->dim = dim; e->eps = ln_eps;
+    if (expected_weights(e) != n_weights) {
+        const long long want = (long long)expected_weights(e);
+        delete e;
+        return fail(CLB_EDIMENSION, "weight blob has %lld floats, this architecture needs %lld", (long long)n_weights, want);
+    }
+    const int64_t H = hidden, I = intermediate;
+    int64_t o = 0;
+    e->o_word = o; o += vocab * H;
+    e->o_pos = o; o += max_pos * H;
+    e->o_type = o; o += type_vocab * H;
+    e->o_eg = o; o += H;
+    e->o_eb = o; o += H;
+    e->o_layer0 = o;
+    int64_t r = 0;
+    e->r_wqkv = r; r += 3 * H * H;
+    e->r_bqkv = r; r += 3 * H;
+    e->r_wo = r; r += H * H;
+    e->r_bo = r; r += H;
+    e->r_g1 = r; r += H;
+    e->r_b1n = r; r += H;
+    e->r_w1 = r; r += I * H;
+    e->r_b1 = r; r += I;
+    e->r_w2 = r; r += H * I;
+    e->r_b2 = r; r += H;
+    e->r_g2 = r; r += H;
+    e->r_b2n = r; r += H;
+    e->layer_stride = r;
+    o += layers * r;
+    e->o_lin_w = o; o += dim * H;
+    e->o_lin_b = o; o += dim;
+    int rc = use_device(device);
+    if (rc) { delete e; return rc; }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(CLB_EHIP, "hipStreamCreate failed"); }
+    if ((rc = upload(e->weights, weights, sizeof(float) * n_weights, e->stream)) || hipStreamSynchronize(e->stream) != hipSuccess) {
+        clb_encoder_destroy(e);
+        return rc ? rc : fail(CLB_EHIP, "weight upload failed");
+    }
+    *out = e;
+    return CLB_OK;
+}
+
+int clb_encoder_destroy(clb_encoder* e) {
+    if (!e) return CLB_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    delete e;
+    return CLB_OK;
+}
+
+int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out) {
+    CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
+    CLB_TRY(forward(e, L, N));
+    CLB_HIP(hipMemcpy(out, e->out.p, sizeof(float) * L * N * e->dim, hipMemcpyDeviceToHost));
+    return CLB_OK;
+}
+
+int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
+                    const int64_t* skiplist, int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out) {
+    CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
+    CLB_TRY(forward(e, L, N));
+    hipStream_t st = e->stream;
+    DevBuf dSkip, dMask, dLens, dStart, dOut;
+    CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), st));
+    CLB_TRY(dMask.alloc((size_t)L * N));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
+    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->ids.as<int32_t>(), (int)L, (int)N,
+                       dSkip.as<int64_t>(), (int)n_skip, dMask.as<uint8_t>(), dLens.as<int64_t>());
+    CLB_HIP(hipMemcpyAsync(doclens, dLens.p, sizeof(int64_t) * N, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> start((size_t)N);
+    int64_t run = 0;
+    for (int64_t i = 0; i < N; ++i) { start[i] = run; run += doclens[i]; }
+    *n_out = run;
+    if (run == 0) return CLB_OK;
+    CLB_TRY(upload(dStart, start.data(), sizeof(int64_t) * N, st));
+    CLB_TRY(dOut.alloc(sizeof(float) * e->dim * run));
+    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                       (int)L, (int)N, dMask.as<uint8_t>(), dStart.as<int64_t>(), dOut.as<float>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(out_embs, dOut.p, sizeof(float) * e->dim * run, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
+                       const int64_t* skiplist, int64_t n_skip, float* out) {
+    CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
+    CLB_TRY(forward(e, L, N));
+    hipStream_t st = e->stream;
+    DevBuf dSkip, dMask, dLens, dOut;
+    CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), st));
+    CLB_TRY(dMask.alloc((size_t)L * N));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
+    CLB_TRY(dOut.alloc(sizeof(float) * e->dim * L * N));
+    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->ids.as<int32_t>(), (int)L, (int)N,
+                       dSkip.as<int64_t>(), (int)n_skip, dMask.as<uint8_t>(), dLens.as<int64_t>());
+    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                       (int)L, (int)N, dMask.as<uint8_t>(), (const int64_t*)nullptr, dOut.as<float>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(out, dOut.p, sizeof(float) * e->dim * L * N, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+}  // extern "C"

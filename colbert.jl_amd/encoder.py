@@ -1,0 +1,137 @@
+"""Checkpoint encoder -- the reference's src/modelling/checkpoint.jl over the C ABI.
+
+`BertEncoder` holds the BERT + Dense weights of a ColBERT checkpoint on the device and mirrors
+`encode_passages` (checkpoint.jl:159-189) and `encode_queries` (:271-301): tokenise on the host
+(tokenization.py), run the forward + epilogue on the device in batches of `index_bsize`, concatenate."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from . import tokenization
+from ._lib import check, colmajor, fptr, i64, lib
+from .config import ColBERTConfig
+
+# order of the flat weight blob (include/colbert_hip.h); names follow the HuggingFace BERT state dict
+EMB_KEYS = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+            "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+
+
+def layer_keys(l: int):
+    p = f"encoder.layer.{l}."
+    return ([p + f"attention.self.{n}.weight" for n in ("query", "key", "value")] +
+            [p + f"attention.self.{n}.bias" for n in ("query", "key", "value")] +
+            [p + "attention.output.dense.weight", p + "attention.output.dense.bias",
+             p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+             p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+             p + "output.dense.weight", p + "output.dense.bias",
+             p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"])
+
+
+def pack_weights(state: dict, bert_cfg: dict, dim: int) -> np.ndarray:
+    """state: name -> array with the `bert.` prefix stripped, plus `linear.weight` (dim, H) and optionally
+    `linear.bias` (zeros when absent, as local_loading.jl:97-99 loads the Dense with bias)."""
+    H = bert_cfg["hidden_size"]
+    parts = [np.asarray(state[k], dtype=np.float32).ravel() for k in EMB_KEYS]
+    for l in range(bert_cfg["num_hidden_layers"]):
+        parts += [np.asarray(state[k], dtype=np.float32).ravel() for k in layer_keys(l)]
+    parts.append(np.asarray(state["linear.weight"], dtype=np.float32).reshape(dim, H).ravel())
+    parts.append(np.asarray(state.get("linear.bias", np.zeros(dim, np.float32)), dtype=np.float32).ravel())
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+class BertEncoder:
+    def __init__(self, weights: np.ndarray, bert_cfg: dict, dim: int = 128, device: int = 0,
+                 tokenizer=None, config: Optional[ColBERTConfig] = None):
+        self.cfg = dict(bert_cfg); self.dim = dim; self.device = device
+        self.tokenizer = tokenizer
+        self.config = config or ColBERTConfig(dim=dim)
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        self._h = C.c_void_p()
+        check(lib().clb_encoder_create(device, i64(bert_cfg["vocab_size"]), i64(bert_cfg["hidden_size"]),
+                                       i64(bert_cfg["num_hidden_layers"]), i64(bert_cfg["num_attention_heads"]),
+                                       i64(bert_cfg["intermediate_size"]), i64(bert_cfg["max_position_embeddings"]),
+                                       i64(bert_cfg.get("type_vocab_size", 2)), i64(dim),
+                                       C.c_float(bert_cfg.get("layer_norm_eps", 1e-12)), fptr(w), i64(w.size),
+                                       C.byref(self._h)))
+
+    @classmethod
+    def from_export(cls, path: str, **kw) -> "BertEncoder":
+        """Load what tools/export_checkpoint.py wrote: <path>/encoder.json + <path>/encoder.f32."""
+        meta = json.load(open(os.path.join(path, "encoder.json")))
+        w = np.fromfile(os.path.join(path, "encoder.f32"), dtype=np.float32)
+        return cls(w, meta["bert"], dim=meta["dim"], **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().clb_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- device calls -----------------------------------------------------------------------------
+    def doc(self, integer_ids, bitmask):
+        """doc(bert, linear, integer_ids, bitmask) (checkpoint.jl:21-25) -> (dim, L, N) Float32."""
+        ids = colmajor(integer_ids, np.int32); m = colmajor(np.asarray(bitmask).astype(np.uint8), np.uint8)
+        L, N = ids.shape
+        out = np.zeros((self.dim, L, N), dtype=np.float32, order="F")
+        check(lib().clb_encode(self._h, fptr(ids), fptr(m), i64(L), i64(N), fptr(out)))
+        return out
+
+    def doc_embeddings_and_doclens(self, skiplist, integer_ids, bitmask):
+        """_doc_embeddings_and_doclens (checkpoint.jl:27-52)."""
+        ids = colmajor(integer_ids, np.int32); m = colmajor(np.asarray(bitmask).astype(np.uint8), np.uint8)
+        sk = np.ascontiguousarray(skiplist, dtype=np.int64)
+        L, N = ids.shape
+        out = np.zeros((self.dim, L * N), dtype=np.float32, order="F")
+        doclens = np.zeros(N, dtype=np.int64)
+        n_out = i64(0)
+        check(lib().clb_encode_docs(self._h, fptr(ids), fptr(m), i64(L), i64(N), fptr(sk), i64(sk.size), fptr(out),
+                                    fptr(doclens), C.byref(n_out)))
+        return np.asfortranarray(out[:, : n_out.value]), doclens
+
+    def query_embeddings(self, skiplist, integer_ids, bitmask):
+        """_query_embeddings (checkpoint.jl:54-71)."""
+        ids = colmajor(integer_ids, np.int32); m = colmajor(np.asarray(bitmask).astype(np.uint8), np.uint8)
+        sk = np.ascontiguousarray(skiplist, dtype=np.int64)
+        L, N = ids.shape
+        out = np.zeros((self.dim, L, N), dtype=np.float32, order="F")
+        check(lib().clb_encode_queries(self._h, fptr(ids), fptr(m), i64(L), i64(N), fptr(sk), i64(sk.size), fptr(out)))
+        return out
+
+    # -- the reference's batching loops -----------------------------------------------------------------
+    def encode_passages(self, passages: List[str], skiplist=None, doc_token: Optional[str] = None):
+        """encode_passages (checkpoint.jl:159-189) -> (embs (dim, sum(doclens)), doclens)."""
+        cfg = self.config
+        if len(passages) == 0:
+            return np.zeros((self.dim, 0), np.float32, order="F"), np.zeros(0, np.int64)
+        skiplist = self.tokenizer.doc_skiplist(cfg.mask_punctuation) if skiplist is None else skiplist
+        embs, doclens = [], []
+        for off in range(0, len(passages), cfg.index_bsize):
+            ids, mask = tokenization.tensorize_docs(doc_token or cfg.doc_token_id, self.tokenizer,
+                                                    passages[off:off + cfg.index_bsize], cfg.doc_maxlen)
+            D, dl = self.doc_embeddings_and_doclens(skiplist, ids, mask)
+            embs.append(D); doclens.append(dl)
+        return np.asfortranarray(np.concatenate(embs, axis=1)), np.concatenate(doclens)
+
+    def encode_queries(self, queries: List[str], skiplist=None, query_token: Optional[str] = None):
+        """encode_queries (checkpoint.jl:271-301) -> (dim, query_maxlen, n)."""
+        cfg = self.config
+        if len(queries) == 0:
+            return np.zeros((self.dim, 0), np.float32, order="F")
+        skiplist = [self.tokenizer.pad_id] if skiplist is None else skiplist      # searching.jl:62
+        out = []
+        for off in range(0, len(queries), cfg.index_bsize):
+            ids, mask = tokenization.tensorize_queries(query_token or cfg.query_token, cfg.attend_to_mask_tokens,
+                                                       self.tokenizer, queries[off:off + cfg.index_bsize],
+                                                       cfg.query_maxlen)
+            out.append(self.query_embeddings(skiplist, ids, mask))
+        return np.asfortranarray(np.concatenate(out, axis=2))

@@ -1,0 +1,80 @@
+"""Host-side tokenisation mirrors of src/modelling/tokenization/*.jl.  Ids are 1-based, as in the reference
+(Julia): [PAD]=1, [unused0]=2, [unused1]=3, [UNK]=101, [CLS]=102, [SEP]=103, [MASK]=104 for bert-base-uncased.
+
+`WordPieceTokenizer` wraps the HuggingFace `tokenizers` WordPiece model over a vocab.txt and reproduces the
+reference's pipelines: documents are truncated AND padded to doc_maxlen-1 tokens (src/indexing.jl:37-46),
+queries truncated OR padded to query_maxlen-1 (src/searching.jl:32-40); the marker token is then inserted as
+the second row (_add_marker_row, tokenizer_utils.jl:140-143)."""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+
+PUNCTUATION = list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")      # src/indexing.jl:30-31
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab_file: str, lowercase: bool = True):
+        from tokenizers import BertWordPieceTokenizer
+        self.tok = BertWordPieceTokenizer(vocab_file, lowercase=lowercase)
+        self.vocab = self.tok.get_vocab()
+
+    # 1-based ids ------------------------------------------------------------------------------------
+    def lookup(self, token: str) -> int:
+        """lookup(tokenizer.vocab, token): unknown tokens map to [UNK] -- the reference passes "[Q]"
+        (config.query_token) for queries, which is not in the vocabulary."""
+        return self.vocab.get(token, self.vocab["[UNK]"]) + 1
+
+    @property
+    def pad_id(self) -> int:
+        return self.lookup("[PAD]")
+
+    def doc_skiplist(self, mask_punctuation: bool = True) -> List[int]:
+        syms = PUNCTUATION + ["[PAD]"] if mask_punctuation else ["[PAD]"]
+        return [self.lookup(s) for s in syms]
+
+    def encode(self, batch_text: List[str], max_tokens: int, pad_to_max: bool):
+        """TextEncoders.encode after the truncation/padding pipe: [CLS] w1 .. wn [SEP] truncated to
+        `max_tokens` (:tail), padded with [PAD] to max_tokens (documents: trunc_and_pad) or to the longest
+        sequence of the batch (queries: trunc_or_pad).  Returns (integer_ids Int32 (len, batch) 1-based,
+        bitmask Bool (len, batch))."""
+        seqs = []
+        for t in batch_text:
+            e = self.tok.encode(t, add_special_tokens=True).ids
+            seqs.append(e[:max_tokens])
+        width = max_tokens if pad_to_max else max(len(e) for e in seqs)
+        ids = np.full((width, len(seqs)), self.pad_id, dtype=np.int32, order="F")
+        mask = np.zeros((width, len(seqs)), dtype=bool, order="F")
+        for j, e in enumerate(seqs):
+            ids[: len(e), j] = np.asarray(e, dtype=np.int32) + 1
+            mask[: len(e), j] = True
+        return ids, mask
+
+
+def _add_marker_row(data: np.ndarray, marker):
+    """_add_marker_row (tokenizer_utils.jl:140-143): the marker becomes row 2."""
+    head = data[: min(1, data.shape[0]), :]
+    row = np.full((1, data.shape[1]), marker, dtype=data.dtype)
+    return np.asfortranarray(np.concatenate([head, row, data[1:, :]], axis=0))
+
+
+def tensorize_docs(doc_token: str, tokenizer, batch_text: List[str], doc_maxlen: int = 300):
+    """tensorize_docs (doc_tokenization.jl:143-156)."""
+    ids, mask = tokenizer.encode(batch_text, doc_maxlen - 1, pad_to_max=True)
+    ids = _add_marker_row(ids, np.int32(tokenizer.lookup(doc_token)))
+    mask = _add_marker_row(mask, True)
+    return ids, mask
+
+
+def tensorize_queries(query_token: str, attend_to_mask_tokens: bool, tokenizer, batch_text: List[str],
+                      query_maxlen: int = 32):
+    """tensorize_queries (query_tokenization.jl:174-197): [PAD] -> [MASK] augmentation."""
+    ids, mask = tokenizer.encode(batch_text, query_maxlen - 1, pad_to_max=True)
+    ids = _add_marker_row(ids, np.int32(tokenizer.lookup(query_token)))
+    mask = _add_marker_row(mask, True)
+    mask_id = tokenizer.lookup("[MASK]")
+    ids[ids == tokenizer.pad_id] = mask_id
+    if attend_to_mask_tokens:
+        mask[ids == mask_id] = True
+    return ids, mask

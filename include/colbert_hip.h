@@ -149,8 +149,32 @@ int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64
                   int64_t* ivf_lengths);
 
 /* ------------------------------------------------------------------------------------------------
- * Encoder epilogue  (src/modelling/checkpoint.jl:27-71, embedding_utils.jl:172-205)
+ * Encoder  (src/modelling/checkpoint.jl)
  * ---------------------------------------------------------------------------------------------- */
+typedef struct clb_encoder clb_encoder;
+/* The BERT + Dense weights of a ColBERT checkpoint (what load_hgf_pretrained_local returns,
+ * src/local_loading.jl:139-209) as ONE flat fp32 blob, torch Linear layout [out][in]:
+ *   word_emb [vocab][H], pos_emb [max_pos][H], type_emb [type_vocab][H], emb_ln_gamma [H], emb_ln_beta [H],
+ *   per layer: Wq,Wk,Wv [3H][H], bq,bk,bv [3H], Wo [H][H], bo [H], ln1_gamma, ln1_beta [H],
+ *              W1 [I][H], b1 [I], W2 [H][I], b2 [H], ln2_gamma, ln2_beta [H],
+ *   linear_W [dim][H], linear_b [dim].
+ * tools/export_checkpoint.py writes it from a HuggingFace directory. */
+int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers, int64_t heads,
+                       int64_t intermediate, int64_t max_pos, int64_t type_vocab, int64_t dim, float ln_eps,
+                       const float* weights, int64_t n_weights, clb_encoder** out);
+int clb_encoder_destroy(clb_encoder* e);
+/* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
+ * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
+int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out);
+/* _doc_embeddings_and_doclens  (checkpoint.jl:27-52): forward, clear skiplist tokens, normalise, doclens,
+ * compaction.  out_embs (dim, <= L*N); doclens Int64[N]; *n_out = kept columns. */
+int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
+                    const int64_t* skiplist, int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out);
+/* _query_embeddings  (checkpoint.jl:54-71): forward, clear skiplist tokens, normalise.  out (dim, L, N). */
+int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
+                       const int64_t* skiplist, int64_t n_skip, float* out);
+
+/* Encoder epilogue as stand-alone calls  (src/modelling/checkpoint.jl:27-71, embedding_utils.jl:172-205) */
 /* _doc_embeddings_and_doclens after doc(): clear skiplist tokens, normalise, doclens, compaction.
  * D (dim, L, N) is read only; out (dim, <= L*N); doclens Int64[N]; *n_out = kept columns. */
 int clb_doc_epilogue(int device, const float* D, int64_t dim, int64_t L, int64_t N,

@@ -170,6 +170,59 @@ function _build_ivf(codes::Vector{UInt32}, num_partitions::Int; device::Int = 0)
     ivf, ivf_lengths
 end
 
+# ---- encoder: the BERT + Dense weights live on the device (reference: src/modelling/checkpoint.jl) ---------------
+mutable struct Checkpoint
+    handle::Ptr{Cvoid}
+    dim::Int
+    function Checkpoint(weights::Vector{Float32}; vocab::Int, hidden::Int, layers::Int, heads::Int,
+            intermediate::Int, max_pos::Int, type_vocab::Int = 2, dim::Int = 128, ln_eps::Float32 = 1.0f-12,
+            device::Int = 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve weights _check(ccall((:clb_encoder_create, libcolbert), Cint,
+            (Cint, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Float32, Ptr{Float32}, Int64, Ref{Ptr{Cvoid}}),
+            device, vocab, hidden, layers, heads, intermediate, max_pos, type_vocab, dim, ln_eps, weights,
+            length(weights), h))
+        c = new(h[], dim)
+        finalizer(c -> ccall((:clb_encoder_destroy, libcolbert), Cint, (Ptr{Cvoid},), c.handle), c)
+    end
+end
+
+"doc(bert, linear, integer_ids, bitmask) (src/modelling/checkpoint.jl:21-25)"
+function doc(ckpt::Checkpoint, integer_ids::Matrix{Int32}, bitmask::AbstractMatrix{Bool})
+    L, N = size(integer_ids)
+    mask = Matrix{UInt8}(bitmask)
+    out = Array{Float32, 3}(undef, ckpt.dim, L, N)
+    GC.@preserve integer_ids mask out _check(ccall((:clb_encode, libcolbert), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Float32}), ckpt.handle, integer_ids, mask, L, N, out))
+    out
+end
+
+"_doc_embeddings_and_doclens (checkpoint.jl:27-52)"
+function _doc_embeddings_and_doclens(ckpt::Checkpoint, skiplist::Vector{Int}, integer_ids::Matrix{Int32},
+        bitmask::AbstractMatrix{Bool})
+    L, N = size(integer_ids)
+    mask = Matrix{UInt8}(bitmask)
+    out = Matrix{Float32}(undef, ckpt.dim, L * N)
+    doclens = Vector{Int}(undef, N)
+    n_out = Ref{Int64}(0)
+    GC.@preserve integer_ids mask skiplist out doclens _check(ccall((:clb_encode_docs, libcolbert), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32}, Ptr{Int64}, Ref{Int64}),
+        ckpt.handle, integer_ids, mask, L, N, skiplist, length(skiplist), out, doclens, n_out))
+    out[:, 1:n_out[]], doclens
+end
+
+"_query_embeddings (checkpoint.jl:54-71)"
+function _query_embeddings(ckpt::Checkpoint, skiplist::Vector{Int}, integer_ids::Matrix{Int32},
+        bitmask::AbstractMatrix{Bool})
+    L, N = size(integer_ids)
+    mask = Matrix{UInt8}(bitmask)
+    out = Array{Float32, 3}(undef, ckpt.dim, L, N)
+    GC.@preserve integer_ids mask skiplist out _check(ccall((:clb_encode_queries, libcolbert), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32}),
+        ckpt.handle, integer_ids, mask, L, N, skiplist, length(skiplist), out))
+    out
+end
+
 # Indexer / index: the reference's orchestration (src/indexing.jl:63-147) is unchanged host glue; only the
 # calls above (train -> kmeans_gpu_onehot! + _compute_avg_residuals!, compress, _build_ivf) change body.
 struct Indexer

@@ -1,0 +1,181 @@
+"""Encoder: host tokenisation mirrors (CPU) and the HIP BERT forward against an independent fp32 reference of
+the same architecture (HuggingFace `BertModel`, randomly initialised -- no checkpoint exists on disk; the
+reference's own arithmetic lives in un-vendored Transformers.jl, so encoder parity is *unpinned*)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import colbert_jl_amd as clb
+from colbert_jl_amd import tokenization
+
+VOCAB = (["[PAD]", "[unused0]", "[unused1]"] + [f"[unused{i}]" for i in range(2, 20)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] +
+         list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~") +
+         ["hello", "world", "this", "is", "a", "test", "of", "the", "token", "##izer", "##s", "longer", "passage",
+          "with", "many", "words", "query", "what", "col", "##bert"])
+
+
+@pytest.fixture(scope="module")
+def tok(tmp_path_factory):
+    d = tmp_path_factory.mktemp("vocab")
+    f = d / "vocab.txt"
+    f.write_text("\n".join(VOCAB) + "\n")
+    return tokenization.WordPieceTokenizer(str(f))
+
+
+def test_add_marker_row():
+    """test/modelling/tokenization/tokenizer_utils.jl:3-19"""
+    x = np.arange(12, dtype=np.int32).reshape(3, 4)
+    y = tokenization._add_marker_row(x, np.int32(99))
+    assert y.shape == (4, 4) and np.array_equal(y[0], x[0]) and np.all(y[1] == 99) and np.array_equal(y[2:], x[1:])
+    m = tokenization._add_marker_row(np.ones((5, 2), bool), True)
+    assert m.shape == (6, 2) and m.all()
+    e = tokenization._add_marker_row(np.zeros((0, 3), np.int32), np.int32(7))
+    assert e.shape == (1, 3) and np.all(e == 7)
+
+
+def test_tensorize_docs(tok):
+    ids, mask = tokenization.tensorize_docs("[unused1]", tok, ["hello world!", "this is a longer passage with many words"], 12)
+    assert ids.shape == mask.shape == (12, 2) and ids.dtype == np.int32
+    one = lambda t: tok.lookup(t)
+    assert ids[0, 0] == one("[CLS]") and ids[1, 0] == one("[unused1]") == 3          # marker is row 2, 1-based id 3
+    assert list(ids[2:6, 0]) == [one("hello"), one("world"), one("!"), one("[SEP]")]
+    assert np.all(ids[6:, 0] == one("[PAD]")) and one("[PAD]") == 1
+    assert mask[:6, 0].all() and not mask[6:, 0].any()
+    assert mask[:, 1].sum() == 10 + 1                                              # [CLS] + 8 words + [SEP] + marker
+    # truncation to doc_maxlen - 1 tokens before the marker
+    ids, mask = tokenization.tensorize_docs("[unused1]", tok, ["this is a longer passage with many words"], 6)
+    assert ids.shape == (6, 1) and mask.all()
+    sk = tok.doc_skiplist(True)
+    assert len(sk) == 33 and sk[-1] == 1 and len(tok.doc_skiplist(False)) == 1    # embedding_utils.jl:37-72
+
+
+def test_tensorize_queries(tok):
+    ids, mask = tokenization.tensorize_queries("[Q]", False, tok, ["what is col bert", "hello"], 8)
+    assert ids.shape == (8, 2)
+    assert ids[1, 0] == tok.lookup("[UNK]")                                        # "[Q]" is not in the vocab -> [UNK]
+    assert not np.any(ids == tok.pad_id)                                           # [PAD] -> [MASK] augmentation
+    assert np.all(ids[4:, 1] == tok.lookup("[MASK]"))
+    assert mask[:, 1].sum() == 4 and mask[:, 0].sum() == 7                         # real tokens (+ marker) only
+    ids2, mask2 = tokenization.tensorize_queries("[Q]", True, tok, ["hello"], 8)
+    assert mask2.all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _random_bert(hidden=64, layers=2, heads=4, inter=128, vocab=120, max_pos=48, dim=32, seed=0):
+    torch = pytest.importorskip("torch")
+    transformers = pytest.importorskip("transformers")
+    torch.manual_seed(seed)
+    cfg = transformers.BertConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers,
+                                  num_attention_heads=heads, intermediate_size=inter,
+                                  max_position_embeddings=max_pos, type_vocab_size=2, hidden_act="gelu",
+                                  hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bert = transformers.BertModel(cfg, add_pooling_layer=False).eval()
+    linear = torch.nn.Linear(hidden, dim, bias=True)
+    with torch.no_grad():                              # default init is tiny (std 0.02): make the test sensitive
+        for p in bert.parameters():
+            p.mul_(4.0)
+    return torch, cfg, bert, linear
+
+
+def _state(bert, linear):
+    st = {k: v.detach().float().numpy() for k, v in bert.state_dict().items()}
+    st["linear.weight"] = linear.weight.detach().numpy(); st["linear.bias"] = linear.bias.detach().numpy()
+    return st
+
+
+@pytest.mark.gpu
+def test_bert_forward_matches_fp32_reference():
+    torch, cfg, bert, linear = _random_bert()
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    enc = clb.BertEncoder(pack_weights(_state(bert, linear), bcfg, 32), bcfg, dim=32)
+    rng = np.random.default_rng(1)
+    L, N = 37, 5
+    ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
+    lens = [37, 20, 1, 33, 9]
+    mask = np.zeros((N, L), bool)
+    for n, l in enumerate(lens):
+        mask[n, :l] = True
+    with torch.no_grad():
+        ref = linear(bert(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state)
+    ref = ref.numpy()                                                            # (N, L, dim)
+    got = enc.doc((ids0.T + 1).astype(np.int32), mask.T)                         # (dim, L, N), 1-based ids
+    assert got.shape == (32, L, N)
+    err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()                       # padded query rows are don't-care
+    assert err < 2e-4, err
+    # epilogues on top of the forward == the oracle's epilogue on the same forward output
+    from oracle import oracle as orc
+    skip = [5, 17, 33]
+    D, dl = enc.doc_embeddings_and_doclens(skip, (ids0.T + 1).astype(np.int32), mask.T)
+    rD, rdl = orc.doc_epilogue(got, (ids0.T + 1).astype(np.int32), skip)
+    assert np.array_equal(dl, rdl) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    Q = enc.query_embeddings(skip, (ids0.T + 1).astype(np.int32), mask.T)
+    assert np.array_equal(Q.view(np.uint32), orc.query_epilogue(got, (ids0.T + 1).astype(np.int32), skip).view(np.uint32))
+    with pytest.raises(clb.BoundsError):
+        enc.doc(np.full((4, 1), cfg.vocab_size + 1, np.int32), np.ones((4, 1), bool))
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_bert_base_shape_and_export_roundtrip(tmp_path, tok):
+    """bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072), one short batch; weights through the export tool."""
+    torch, cfg, bert, linear = _random_bert(hidden=768, layers=12, heads=12, inter=3072, vocab=len(VOCAB), max_pos=64, dim=128, seed=3)
+    hf = tmp_path / "hf"; hf.mkdir()
+    sd = {"bert." + k: v for k, v in bert.state_dict().items()}
+    sd["linear.weight"] = linear.weight.detach()
+    torch.save(sd, hf / "pytorch_model.bin")
+    (hf / "config.json").write_text(json.dumps(cfg.to_dict()))
+    (hf / "artifact.metadata").write_text(json.dumps({"dim": 128}))
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "export_checkpoint.py"), str(hf), str(tmp_path / "exp")], check=True)
+    enc = clb.BertEncoder.from_export(str(tmp_path / "exp"), tokenizer=tok,
+                                      config=clb.ColBERTConfig(doc_maxlen=24, query_maxlen=12, index_bsize=2))
+    passages = ["hello world!", "this is a longer passage with many words.", "a test of the tokenizer"]
+    embs, doclens = enc.encode_passages(passages)
+    assert embs.shape == (128, doclens.sum()) and np.allclose(np.linalg.norm(embs, axis=0), 1, atol=1e-5)
+    ids, mask = tokenization.tensorize_docs("[unused1]", tok, passages, 24)
+    with torch.no_grad():
+        h = bert(input_ids=torch.from_numpy((ids.T - 1).astype(np.int64)), attention_mask=torch.from_numpy(mask.T.astype(np.int64))).last_hidden_state
+        ref = (h @ linear.weight.T).numpy()                                       # exported without linear.bias -> zeros
+    keep = ~np.isin(ids, tok.doc_skiplist(True))
+    assert np.array_equal(doclens, keep.sum(axis=0))
+    flat = ref.transpose(0, 1, 2).reshape(-1, 128)[keep.T.ravel()]
+    flat = flat / (np.linalg.norm(flat, axis=1, keepdims=True) + np.finfo(np.float32).eps)
+    assert np.abs(embs.T - flat).max() < 1e-3      # 12 layers of fp32 rounding in two different summation orders
+    Q = enc.encode_queries(["what is col bert", "hello"])
+    assert Q.shape == (128, 12, 2) and np.allclose(np.linalg.norm(Q, axis=0), 1, atol=1e-5)
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_text_to_search_end_to_end(tmp_path, tok):
+    """BASELINE config 1 in spirit (a handful of passages through Indexer + Searcher with a text query): the API
+    plumbing of examples/indexing.jl + examples/searching.jl with a randomly initialised encoder."""
+    torch, cfg, bert, linear = _random_bert(hidden=64, layers=2, heads=4, inter=128, vocab=len(VOCAB), max_pos=64, dim=128, seed=5)
+    from colbert_jl_amd.encoder import pack_weights
+    from oracle import oracle as orc
+    bcfg = cfg.to_dict()
+    config = clb.ColBERTConfig(index_path=str(tmp_path / "short_index"), doc_maxlen=24, query_maxlen=12, index_bsize=4,
+                               chunksize=6, kmeans_niters=3, nbits=2)
+    enc = clb.BertEncoder(pack_weights(_state(bert, linear), bcfg, 128), bcfg, dim=128, tokenizer=tok, config=config)
+    words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with", "many", "words", "query", "colbert"]
+    rng = np.random.default_rng(7)
+    collection = [" ".join(rng.choice(words, size=rng.integers(4, 12))) + "." for _ in range(10)]
+    indexer = clb.Indexer(config, encoder=enc, collection=collection, seed=1)
+    assert clb.index(indexer) == config.index_path
+    searcher = clb.Searcher(config.index_path, encoder=enc)
+    query = collection[3]
+    pids, scores = clb.search(searcher, query, 3)
+    assert pids.shape == (3,) and np.all(np.diff(scores) <= 0) and np.all((pids >= 1) & (pids <= 10))
+    # same result as the oracle on the same query embeddings and index arrays
+    from colbert_jl_amd import storage
+    idx = storage.load_index(config.index_path)
+    Q = enc.encode_queries([query])[:, :, 0]
+    rp, rs, _ = orc.search(idx, Q, config.nprobe, 3)
+    assert np.array_equal(pids, rp) and np.array_equal(scores.view(np.uint32), rs.view(np.uint32))
+    with pytest.raises(clb.BoundsError):
+        clb.search(searcher, query, 11)
+    searcher.close(); enc.close()
