@@ -45,6 +45,15 @@ struct Prof {
 
 }  // namespace
 
+// Per-batch workspace (everything a batch of queries needs besides the resident index).
+struct Workspace {
+    int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
+    size_t cand_cap = 0;
+    int W = 0, nblk_bitmap = 0, topn_blocks = 0;
+    DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
+        outp, outs, flags, stats, redo;
+};
+
 struct clb_searcher {
     int device = 0;
     int64_t dim = 0, K = 0, n_docs = 0, n_emb = 0, pid_offset = 0;
@@ -62,16 +71,10 @@ struct clb_searcher {
     DevBuf ivf_pid;     // u32 [n_emb] local passage ids grouped by centroid
     DevBuf inv_norm;    // fp32 [n_emb]  (two-pass mode)
     DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
-    DevBuf redo;        // int [B] queries whose centroid selection must be redone in fp32
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
-    // workspace, sized for (Bcap, Tcap, nprobe_cap, kcap)
-    int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
-    size_t cand_cap = 0;
-    int W = 0, nblk_bitmap = 0, topn_blocks = 0;
-    DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats;
+    Workspace ws[1];     // per-batch scratch, grown on demand (ensure_workspace)
     Prof prof;
     int64_t last_cand_docs = 0, last_cand_embs = 0, last_resc_docs = 0, last_resc_embs = 0;
     int64_t index_bytes = 0;
@@ -108,11 +111,11 @@ int next_pow2(int x) {
     return p;
 }
 
-int ensure_workspace(clb_searcher* s, int64_t B, int64_t T, int64_t nprobe, int64_t k) {
-    if (B <= s->Bcap && T <= s->Tcap && nprobe <= s->npcap && k <= s->kcap) return CLB_OK;
+int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_t nprobe, int64_t k) {
+    if (B <= w.Bcap && T <= w.Tcap && nprobe <= w.npcap && k <= w.kcap) return CLB_OK;
     CLB_HIP(hipStreamSynchronize(s->stream));
-    B = std::max(B, s->Bcap); T = std::max(T, s->Tcap);
-    nprobe = std::max(nprobe, s->npcap); k = std::max(k, s->kcap);
+    B = std::max(B, w.Bcap); T = std::max(T, w.Tcap);
+    nprobe = std::max(nprobe, w.npcap); k = std::max(k, w.kcap);
     const int64_t Tpad = token_tiles(T) * 32;
     // candidates of one query <= sum of the T*nprobe longest IVF lists (and <= n_docs)
     size_t lists = (size_t)std::min<int64_t>(T * nprobe, s->K);
@@ -120,56 +123,56 @@ int ensure_workspace(clb_searcher* s, int64_t B, int64_t T, int64_t nprobe, int6
     for (size_t i = 0; i < lists; ++i) cap += s->ivf_len_sorted[i];
     cap = std::min<size_t>(cap, (size_t)s->n_docs);
     cap = std::max<size_t>(cap, 1);
-    s->cand_cap = (cap + 3) & ~(size_t)3;
-    s->W = (int)((s->n_docs + 31) / 32);
-    s->nblk_bitmap = (s->W + kScanBlock * kWordsPerThread - 1) / (kScanBlock * kWordsPerThread);
-    s->topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
+    w.cand_cap = (cap + 3) & ~(size_t)3;
+    w.W = (int)((s->n_docs + 31) / 32);
+    w.nblk_bitmap = (w.W + kScanBlock * kWordsPerThread - 1) / (kScanBlock * kWordsPerThread);
+    w.topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
-    CLB_TRY(s->Qdev.ensure(sizeof(float) * B * T * kDim));
-    CLB_TRY(s->cells.ensure(sizeof(float) * B * s->K * Tpad));
-    CLB_TRY(s->partial.ensure(sizeof(ValIdx) * B * s->topn_blocks * Tpad * NPs));
-    CLB_TRY(s->sel.ensure(sizeof(int) * B * Tpad * NPs));
-    const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * s->W;
-    const bool bm_new = bm_bytes > s->bitmap.bytes || !s->bitmap.p;
-    CLB_TRY(s->bitmap.ensure(bm_bytes));
-    if (bm_new) CLB_HIP(hipMemsetAsync(s->bitmap.p, 0, s->bitmap.bytes, s->stream));
-    CLB_TRY(s->blocksum.ensure(sizeof(int) * B * s->nblk_bitmap));
-    CLB_TRY(s->ncand.ensure(sizeof(int) * B));
-    CLB_TRY(s->cand.ensure(sizeof(uint32_t) * B * s->cand_cap));
-    CLB_TRY(s->cand_hdr.ensure(sizeof(uint2) * B * s->cand_cap));
-    CLB_TRY(s->scores.ensure(sizeof(float) * B * s->cand_cap));
-    CLB_TRY(s->list.ensure(sizeof(int) * B * s->cand_cap));
-    CLB_TRY(s->nlist.ensure(sizeof(int) * B));
-    CLB_TRY(s->thresh.ensure(sizeof(float) * B * 2));
-    CLB_TRY(s->outp.ensure(sizeof(int64_t) * B * k));
-    CLB_TRY(s->outs.ensure(sizeof(float) * B * k));
-    CLB_TRY(s->flags.ensure(sizeof(int) * B));
-    CLB_TRY(s->stats.ensure(sizeof(unsigned long long) * 8));
-    if (s->approx_ok) CLB_TRY(s->cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
-    s->Bcap = B; s->Tcap = T; s->npcap = nprobe; s->kcap = k;
+    CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * kDim));
+    CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
+    CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * NPs));
+    CLB_TRY(w.sel.ensure(sizeof(int) * B * Tpad * NPs));
+    const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * w.W;
+    const bool bm_new = bm_bytes > w.bitmap.bytes || !w.bitmap.p;
+    CLB_TRY(w.bitmap.ensure(bm_bytes));
+    if (bm_new) CLB_HIP(hipMemsetAsync(w.bitmap.p, 0, w.bitmap.bytes, s->stream));
+    CLB_TRY(w.blocksum.ensure(sizeof(int) * B * w.nblk_bitmap));
+    CLB_TRY(w.ncand.ensure(sizeof(int) * B));
+    CLB_TRY(w.cand.ensure(sizeof(uint32_t) * B * w.cand_cap));
+    CLB_TRY(w.cand_hdr.ensure(sizeof(uint2) * B * w.cand_cap));
+    CLB_TRY(w.scores.ensure(sizeof(float) * B * w.cand_cap));
+    CLB_TRY(w.list.ensure(sizeof(int) * B * w.cand_cap));
+    CLB_TRY(w.nlist.ensure(sizeof(int) * B));
+    CLB_TRY(w.thresh.ensure(sizeof(float) * B * 2));
+    CLB_TRY(w.outp.ensure(sizeof(int64_t) * B * k));
+    CLB_TRY(w.outs.ensure(sizeof(float) * B * k));
+    CLB_TRY(w.flags.ensure(sizeof(int) * B));
+    CLB_TRY(w.stats.ensure(sizeof(unsigned long long) * 8));
+    if (s->approx_ok) CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
+    w.Bcap = B; w.Tcap = T; w.npcap = nprobe; w.kcap = k;
     CLB_HIP(hipStreamSynchronize(s->stream));
     return CLB_OK;
 }
 
 template <int NP>
-void launch_topn(clb_searcher* s, hipStream_t st, int B, int Tpad) {
-    hipLaunchKernelGGL(topn_partial_kernel<NP>, dim3(s->topn_blocks, B), dim3(256), 0, st,
-                       s->cells.as<float>(), s->partial.as<ValIdx>(), (int)s->K, Tpad);
-    hipLaunchKernelGGL(topn_final_kernel<NP>, dim3(B), dim3(Tpad), 0, st, s->partial.as<ValIdx>(),
-                       s->sel.as<int>(), s->topn_blocks, Tpad);
+void launch_topn(clb_searcher* s, Workspace& w, hipStream_t st, int B, int Tpad) {
+    hipLaunchKernelGGL(topn_partial_kernel<NP>, dim3(w.topn_blocks, B), dim3(256), 0, st,
+                       w.cells.as<float>(), w.partial.as<ValIdx>(), (int)s->K, Tpad);
+    hipLaunchKernelGGL(topn_final_kernel<NP>, dim3(B), dim3(Tpad), 0, st, w.partial.as<ValIdx>(),
+                       w.sel.as<int>(), w.topn_blocks, Tpad);
 }
 
 template <int NBITS>
-void launch_score_exact(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, const int* list,
+void launch_score_exact(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, const int* list,
                         const int* nlist, int grid_x) {
     hipLaunchKernelGGL(score_exact_kernel<NBITS>, dim3(grid_x, B), dim3(256), 0, st, s->centroids.as<float>(),
                        s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
-                       s->cand_hdr.as<uint2>(), dQ, s->ncand.as<int>(), s->scores.as<float>(), T, s->cand_cap, list,
+                       w.cand_hdr.as<uint2>(), dQ, w.ncand.as<int>(), w.scores.as<float>(), T, w.cand_cap, list,
                        nlist);
 }
 
 // Candidate generation S1-S3 for B queries on stream st; leaves cand/ncand on the device.
-int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
+int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
     const int TT = token_tiles(T), Tpad = TT * 32;
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
     const int n_tiles = (int)((s->K + 31) / 32);
@@ -178,45 +181,45 @@ int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T,
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
         const int gx = std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
         const int nslots = gx * 4;
-        CLB_TRY(s->partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
+        CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
         if (s->s1_mode == 1 && s->cent_hi.p) {
-            CLB_TRY(s->redo.ensure(sizeof(int) * B));
-            CLB_HIP(hipMemsetAsync(s->redo.p, 0, sizeof(int) * B, st));
+            CLB_TRY(w.redo.ensure(sizeof(int) * B));
+            CLB_HIP(hipMemsetAsync(w.redo.p, 0, sizeof(int) * B, st));
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
                 if (want_half)
                     hipLaunchKernelGGL(centroid_top_bf16x3_kernel<true>, dim3(gx, B), dim3(128), lds_b16, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
-                                       s->partial.as<ValIdx>(), s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
+                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
                 else
                     hipLaunchKernelGGL(centroid_top_bf16x3_kernel<false>, dim3(gx, B), dim3(128), lds_b16, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
-                                       s->partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, n_tiles);
+                                       w.partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, n_tiles);
             }
             {
                 Timed t(s, KID_TOPN, st);
-                hipLaunchKernelGGL(top_refine_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
+                hipLaunchKernelGGL(top_refine_kernel, dim3(32, B), dim3(64), 0, st, w.partial.as<ValIdx>(),
                                    s->centroids.as<float>(), dQ, T, (int)s->K, nslots, s->approx_consts.cn_max,
-                                   s->sel.as<int>(), s->redo.as<int>());
+                                   w.sel.as<int>(), w.redo.as<int>());
             }
         } else {
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 if (want_half)
                     hipLaunchKernelGGL(centroid_top2_kernel<true>, dim3(gx, B), dim3(128), lds_f32, st,
-                                       s->centroids.as<float>(), dQ, s->partial.as<ValIdx>(),
-                                       s->cells_q.as<uint32_t>(), (int)s->K, T, n_tiles, (const int*)nullptr);
+                                       s->centroids.as<float>(), dQ, w.partial.as<ValIdx>(),
+                                       w.cells_q.as<uint32_t>(), (int)s->K, T, n_tiles, (const int*)nullptr);
                 else
                     hipLaunchKernelGGL(centroid_top2_kernel<false>, dim3(gx, B), dim3(128), lds_f32, st,
-                                       s->centroids.as<float>(), dQ, s->partial.as<ValIdx>(), (uint32_t*)nullptr,
+                                       s->centroids.as<float>(), dQ, w.partial.as<ValIdx>(), (uint32_t*)nullptr,
                                        (int)s->K, T, n_tiles, (const int*)nullptr);
             }
             {
                 Timed t(s, KID_TOPN, st);
-                hipLaunchKernelGGL(top2_merge_kernel, dim3(32, B), dim3(64), 0, st, s->partial.as<ValIdx>(),
-                                   s->sel.as<int>(), nslots, (const int*)nullptr);
+                hipLaunchKernelGGL(top2_merge_kernel, dim3(32, B), dim3(64), 0, st, w.partial.as<ValIdx>(),
+                                   w.sel.as<int>(), nslots, (const int*)nullptr);
             }
         }
     } else {
@@ -225,33 +228,33 @@ int run_retrieve(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T,
             const int gx = std::max(1, std::min(n_tiles / 2 + 1, 2048 / std::max(1, B * TT)));
             hipLaunchKernelGGL(centroid_scores_kernel, dim3(gx, B * TT), dim3(128),
                                2 * 32 * kCentTileStride * sizeof(float), st, s->centroids.as<float>(), dQ,
-                               s->cells.as<float>(), (int)s->K, T, TT, n_tiles);
+                               w.cells.as<float>(), (int)s->K, T, TT, n_tiles);
         }
         {
             Timed t(s, KID_TOPN, st);
-            if (NPs == 2) launch_topn<2>(s, st, B, Tpad);
-            else if (NPs == 8) launch_topn<8>(s, st, B, Tpad);
-            else launch_topn<32>(s, st, B, Tpad);
+            if (NPs == 2) launch_topn<2>(s, w, st, B, Tpad);
+            else if (NPs == 8) launch_topn<8>(s, w, st, B, Tpad);
+            else launch_topn<32>(s, w, st, B, Tpad);
         }
         if (want_half)
             hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
-                               s->cells.as<float>(), s->cells_q.as<uint32_t>(), (int)s->K);
+                               w.cells.as<float>(), w.cells_q.as<uint32_t>(), (int)s->K);
     }
     {
         Timed t(s, KID_MARK, st);
-        hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, s->sel.as<int>(),
-                           s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), s->bitmap.as<uint32_t>(), T,
-                           Tpad, NPs, nprobe, s->W);
+        hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, w.sel.as<int>(),
+                           s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(), T,
+                           Tpad, NPs, nprobe, w.W);
     }
     {
         Timed t(s, KID_COMPACT, st);
-        hipLaunchKernelGGL(bitmap_count_kernel, dim3(s->nblk_bitmap, B), dim3(kScanBlock), 0, st,
-                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->W);
-        hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, s->blocksum.as<int>(),
-                           s->ncand.as<int>(), s->nblk_bitmap);
-        hipLaunchKernelGGL(bitmap_emit_kernel, dim3(s->nblk_bitmap, B), dim3(kScanBlock), 0, st,
-                           s->bitmap.as<uint32_t>(), s->blocksum.as<int>(), s->cand.as<uint32_t>(),
-                           s->doc_off.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->W, s->cand_cap);
+        hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
+                           w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.W);
+        hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, w.blocksum.as<int>(),
+                           w.ncand.as<int>(), w.nblk_bitmap);
+        hipLaunchKernelGGL(bitmap_emit_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
+                           w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.cand.as<uint32_t>(),
+                           s->doc_off.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.W, w.cand_cap);
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
@@ -269,12 +272,12 @@ int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int
 }
 
 // The whole search for B device-resident queries, enqueued on st.
-int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
+int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
                int64_t* d_out_pids, float* d_out_scores) {
-    CLB_TRY(run_retrieve(s, st, dQ, B, T, nprobe));
+    CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
     const int kpow2 = next_pow2(k);
-    CLB_HIP(hipMemsetAsync(s->flags.p, 0, sizeof(int) * B, st));
-    if (s->prof.on) CLB_HIP(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * 8, st));
+    CLB_HIP(hipMemsetAsync(w.flags.p, 0, sizeof(int) * B, st));
+    if (s->prof.on) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
     const int* list = nullptr;
     const int* nlist = nullptr;
     if (s->mode == 1 && s->approx_ok && T <= 32) {
@@ -285,8 +288,8 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
 #define CLB_LAUNCH_APPROX(V)                                                                                         \
     hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * wgpg), dim3(256), 0, st, s->weights.as<float>(),              \
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
-                       s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(), \
-                       (int)s->K, T, B, s->cand_cap)
+                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(), \
+                       (int)s->K, T, B, w.cand_cap)
             if (variant == 1) CLB_LAUNCH_APPROX(1);
             else if (variant == 2) CLB_LAUNCH_APPROX(2);
             else if (variant == 3) CLB_LAUNCH_APPROX(3);
@@ -297,34 +300,34 @@ int run_search(clb_searcher* s, hipStream_t st, const float* dQ, int B, int T, i
         }
         {
             Timed t(s, KID_SELECT, st);
-            hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, s->scores.as<float>(),
-                               s->ncand.as<int>(), dQ, T, k, s->cand_cap, s->approx_consts, s->list.as<int>(),
-                               s->nlist.as<int>(), s->thresh.as<float>());
+            hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(),
+                               w.ncand.as<int>(), dQ, T, k, w.cand_cap, s->approx_consts, w.list.as<int>(),
+                               w.nlist.as<int>(), w.thresh.as<float>());
         }
-        list = s->list.as<int>();
-        nlist = s->nlist.as<int>();
+        list = w.list.as<int>();
+        nlist = w.nlist.as<int>();
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
         static const int gxl = getenv("CLB_DEBUG_EXACT_GX") ? atoi(getenv("CLB_DEBUG_EXACT_GX")) : 1024;
         const int gx = list ? std::max(1, gxl / B) : std::max(1, 2048 / B);
         switch (s->nbits) {
-            case 1: launch_score_exact<1>(s, st, dQ, B, T, list, nlist, gx); break;
-            case 2: launch_score_exact<2>(s, st, dQ, B, T, list, nlist, gx); break;
-            case 4: launch_score_exact<4>(s, st, dQ, B, T, list, nlist, gx); break;
+            case 1: launch_score_exact<1>(s, w, st, dQ, B, T, list, nlist, gx); break;
+            case 2: launch_score_exact<2>(s, w, st, dQ, B, T, list, nlist, gx); break;
+            case 4: launch_score_exact<4>(s, w, st, dQ, B, T, list, nlist, gx); break;
             default: return fail(CLB_EUNSUPPORTED, "nbits=%d not supported by the HIP search path", s->nbits);
         }
     }
     {
         Timed t(s, KID_TOPK, st);
         hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
-                           s->scores.as<float>(), s->cand.as<uint32_t>(), s->ncand.as<int>(), list, nlist, k,
-                           kpow2, s->cand_cap, s->pid_offset, d_out_pids, d_out_scores, s->flags.as<int>());
+                           w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
+                           kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>());
     }
     if (s->prof.on) {
-        hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, s->cand.as<uint32_t>(),
-                           s->ncand.as<int>(), list, nlist, s->doc_off.as<uint32_t>(), s->cand_cap,
-                           s->stats.as<unsigned long long>());
+        hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, w.cand.as<uint32_t>(),
+                           w.ncand.as<int>(), list, nlist, s->doc_off.as<uint32_t>(), w.cand_cap,
+                           w.stats.as<unsigned long long>());
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
@@ -458,10 +461,12 @@ int clb_searcher_destroy(clb_searcher* s) {
 
 int64_t clb_searcher_device_bytes(const clb_searcher* s) {
     if (!s) return 0;
-    const DevBuf* ws[] = {&s->Qdev, &s->cells, &s->cells_q, &s->partial, &s->sel, &s->bitmap, &s->blocksum, &s->ncand,
-                          &s->cand, &s->scores, &s->list, &s->nlist, &s->thresh, &s->outp, &s->outs, &s->flags, &s->stats};
     int64_t tot = s->index_bytes;
-    for (auto* b : ws) tot += (int64_t)b->bytes;
+    for (const auto& w : s->ws) {
+        const DevBuf* bufs[] = {&w.Qdev, &w.cells, &w.cells_q, &w.partial, &w.sel, &w.bitmap, &w.blocksum, &w.ncand, &w.cand,
+                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo};
+        for (auto* b : bufs) tot += (int64_t)b->bytes;
+    }
     return tot;
 }
 
@@ -479,13 +484,13 @@ int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_
                             void* hip_stream) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
     CLB_TRY(use_device(s->device));
-    CLB_TRY(ensure_workspace(s, B, T, nprobe, k));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-    CLB_TRY(run_search(s, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores));
-    if (d_n_cand) {
-        hipLaunchKernelGGL(widen_counts_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, st,
-                           s->ncand.as<int>(), d_n_cand, (int)B);
-    }
+    hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
+    Workspace& w = s->ws[0];
+    CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
+    CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores));
+    if (d_n_cand)
+        hipLaunchKernelGGL(widen_counts_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, st, w.ncand.as<int>(),
+                           d_n_cand, (int)B);
     CLB_HIP(hipGetLastError());
     return CLB_OK;
 }
@@ -494,16 +499,17 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
                      int pad_short, int64_t* out_pids, float* out_scores, int64_t* n_cand) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
     CLB_TRY(use_device(s->device));
-    CLB_TRY(ensure_workspace(s, B, T, nprobe, k));
+    Workspace& w = s->ws[0];
+    CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * B * T * kDim, hipMemcpyHostToDevice, st));
-    CLB_TRY(run_search(s, st, s->Qdev.as<float>(), (int)B, (int)T, (int)nprobe, (int)k, s->outp.as<int64_t>(),
-                       s->outs.as<float>()));
+    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * B * T * kDim, hipMemcpyHostToDevice, st));
+    CLB_TRY(run_search(s, w, st, w.Qdev.as<float>(), (int)B, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(),
+                       w.outs.as<float>()));
     std::vector<int> nc((size_t)B), fl((size_t)B);
-    CLB_HIP(hipMemcpyAsync(out_pids, s->outp.p, sizeof(int64_t) * B * k, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(out_scores, s->outs.p, sizeof(float) * B * k, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(nc.data(), s->ncand.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(fl.data(), s->flags.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(out_pids, w.outp.p, sizeof(int64_t) * B * k, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(out_scores, w.outs.p, sizeof(float) * B * k, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(nc.data(), w.ncand.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(fl.data(), w.flags.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
     int64_t docs = 0;
     for (int64_t b = 0; b < B; ++b) {
@@ -527,15 +533,16 @@ int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int
                  int64_t* n_out) {
     CLB_TRY(check_search_args(s, T, 1, nprobe, 1));
     CLB_TRY(use_device(s->device));
-    CLB_TRY(ensure_workspace(s, 1, T, nprobe, 1));
+    Workspace& w = s->ws[0];
+    CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, 1));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
-    CLB_TRY(run_retrieve(s, st, s->Qdev.as<float>(), 1, (int)T, (int)nprobe));
+    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
+    CLB_TRY(run_retrieve(s, w, st, w.Qdev.as<float>(), 1, (int)T, (int)nprobe));
     int nc = 0;
-    CLB_HIP(hipMemcpyAsync(&nc, s->ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
     std::vector<uint32_t> c((size_t)nc);
-    if (nc) CLB_HIP(hipMemcpy(c.data(), s->cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
+    if (nc) CLB_HIP(hipMemcpy(c.data(), w.cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
     for (int i = 0; i < nc; ++i) out_pids[i] = s->pid_offset + (int64_t)c[i] + 1;
     *n_out = nc;
     return CLB_OK;
@@ -560,37 +567,38 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_TRY(check_search_args(s, T, 1, nprobe, k));
     if (!s->approx_ok || T > 32) return fail(CLB_EUNSUPPORTED, "two-pass mode not available for this index/query");
     CLB_TRY(use_device(s->device));
-    CLB_TRY(ensure_workspace(s, 1, T, nprobe, k));
+    Workspace& w = s->ws[0];
+    CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, k));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(s->Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
-    const float* dQ = s->Qdev.as<float>();
-    CLB_TRY(run_retrieve(s, st, dQ, 1, (int)T, (int)nprobe));
+    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
+    const float* dQ = w.Qdev.as<float>();
+    CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
     hipLaunchKernelGGL(score_approx_kernel<0>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
-                       s->cells_q.as<uint32_t>(), s->cand_hdr.as<uint2>(), s->ncand.as<int>(), s->scores.as<float>(),
-                       (int)s->K, (int)T, 1, s->cand_cap);
-    hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, s->scores.as<float>(), s->ncand.as<int>(), dQ,
-                       (int)T, (int)k, s->cand_cap, s->approx_consts, s->list.as<int>(), s->nlist.as<int>(),
-                       s->thresh.as<float>());
+                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                       (int)s->K, (int)T, 1, w.cand_cap);
+    hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ,
+                       (int)T, (int)k, w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(),
+                       w.thresh.as<float>());
     int nc = 0, nl = 0;
     float th[2];
-    CLB_HIP(hipMemcpyAsync(&nc, s->ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(&nl, s->nlist.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(th, s->thresh.p, sizeof th, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(&nl, w.nlist.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(th, w.thresh.p, sizeof th, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
     if (nc > cap) return fail(CLB_EARGUMENT, "output capacity %lld < %d candidates", (long long)cap, nc);
     std::vector<uint32_t> c((size_t)nc);
     if (nc) {
-        CLB_HIP(hipMemcpy(c.data(), s->cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
-        CLB_HIP(hipMemcpy(out_approx, s->scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
+        CLB_HIP(hipMemcpy(c.data(), w.cand.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
+        CLB_HIP(hipMemcpy(out_approx, w.scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
     }
     switch (s->nbits) {
-        case 2: launch_score_exact<2>(s, st, dQ, 1, (int)T, nullptr, nullptr, 2048); break;
+        case 2: launch_score_exact<2>(s, w, st, dQ, 1, (int)T, nullptr, nullptr, 2048); break;
         default: return fail(CLB_EUNSUPPORTED, "nbits");
     }
     CLB_HIP(hipGetLastError());
     CLB_HIP(hipStreamSynchronize(st));
-    if (nc) CLB_HIP(hipMemcpy(out_exact, s->scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
+    if (nc) CLB_HIP(hipMemcpy(out_exact, w.scores.p, sizeof(float) * nc, hipMemcpyDeviceToHost));
     for (int i = 0; i < nc; ++i) out_pids[i] = s->pid_offset + (int64_t)c[i] + 1;
     *n_out = nc; *tau = th[0]; *eps = th[1]; *n_rescore = nl;
     return CLB_OK;
@@ -635,7 +643,11 @@ int clb_last_batch_stats(clb_searcher* s, int64_t* cand_docs, int64_t* cand_embs
     CLB_HIP(hipDeviceSynchronize());
     // computed on demand from the device-side counts of the last batch
     unsigned long long h[8] = {0};
-    if (s->stats.p) CLB_HIP(hipMemcpy(h, s->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    for (auto& w : s->ws) {
+        unsigned long long t[8] = {0};
+        if (w.stats.p) CLB_HIP(hipMemcpy(t, w.stats.p, sizeof t, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) h[i] += t[i];
+    }
     if (cand_docs) *cand_docs = (int64_t)h[0];
     if (cand_embs) *cand_embs = (int64_t)h[1];
     if (rescored_docs) *rescored_docs = (int64_t)h[2];

@@ -71,7 +71,8 @@ int clb_search(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64
 int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
                      int pad_short, int64_t* out_pids, float* out_scores, int64_t* n_cand);
 /* Same, device-resident: every pointer is a device pointer on the searcher's device; the work is
- * enqueued on `hip_stream` (a hipStream_t; NULL = the searcher's own stream) and not waited for.
+ * enqueued in stream order on `hip_stream` (a hipStream_t; NULL = the HIP null stream) and not waited for:
+ * work queued later on that stream sees the results.
  * Always pads short results (pid 0, -Inf).  Used by the multi-GPU driver and bench.py. */
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
