@@ -60,6 +60,12 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
 }
 
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // ---- index-load: inv_norm[e] = 1/(sqrtf(sumsq(c + r)) + eps32), canonical sumsq; running max -------------------
 static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ C,
                                                              const float* __restrict__ weights,
@@ -236,6 +242,141 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv[p], bi[p]};
 }
 
+// Batched variant (B >= 8).  The kernel above re-reads the whole split centroid table once per query (64 MB x B
+// through L2: 2 GB per 32-query batch, which held it at the L2/HBM rate instead of the MFMA rate).  Here a
+// work-group of 4 waves stages each 32-centroid tile (hi and lo halves) ONCE in LDS, double-buffered, and every
+// wave scores it against its own two queries, whose split bf16 operands stay in registers: 8 queries per tile
+// load, the same three MFMA products per accumulator in the same order (so the error bound is unchanged).
+// grid = (gx, ceil(B / 8)), block = 256, LDS = 2 buffers * 2 arrays * 32 rows * 272 B + 4 waves * 2 KB.
+// partial: [B][nslots = gx * 2 halves][32][kTopPartial].
+constexpr int kMqQueries = 8;
+
+template <bool WRITE_HALF>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_mq_kernel(
+    const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
+    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int bq0 = blockIdx.y * kMqQueries + wave * 2;   // this wave's queries: bq0, bq0 + 1
+    u32x4 qh[2][8], ql[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = bq0 + q < B ? bq0 + q : B - 1;      // past the batch: a duplicate whose results are dropped
+        const float* qrow = Q + ((size_t)b * T + (i < T ? i : T - 1)) * kDim + 64 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 8 * s);
+            const float4 c = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            uint32_t hh[8], ll[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = i < T ? v[j] : 0.f;
+                hh[j] = f32_to_bf16_rne(x);
+                ll[j] = f32_to_bf16_rne(x - __uint_as_float(hh[j] << 16));
+            }
+            qh[q][s] = u32x4{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+            ql[q][s] = u32x4{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+        }
+    }
+    float bv0[kTopPartial], bv1[kTopPartial];
+    int bi0[kTopPartial], bi1[kTopPartial];
+#pragma unroll
+    for (int p = 0; p < kTopPartial; ++p) { bv0[p] = bv1[p] = kNegInf; bi0[p] = bi1[p] = 0x7fffffff; }
+    // loader: thread tid moves 16-B chunk (tid & 15) of rows (tid >> 4) and 16 + (tid >> 4), hi and lo
+    const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
+    uint4 ph0, ph1, pl0, pl1;
+#define CLB_MQ_LOAD(TL)                                                                                   \
+    {                                                                                                     \
+        int c0_ = (TL) * 32 + prow, c1_ = c0_ + 16;                                                       \
+        c0_ = c0_ < K ? c0_ : K - 1;                                                                      \
+        c1_ = c1_ < K ? c1_ : K - 1;                                                                      \
+        ph0 = *reinterpret_cast<const uint4*>(Chi + (size_t)c0_ * kDim + 8 * pchunk);                      \
+        pl0 = *reinterpret_cast<const uint4*>(Clo + (size_t)c0_ * kDim + 8 * pchunk);                      \
+        ph1 = *reinterpret_cast<const uint4*>(Chi + (size_t)c1_ * kDim + 8 * pchunk);                      \
+        pl1 = *reinterpret_cast<const uint4*>(Clo + (size_t)c1_ * kDim + 8 * pchunk);                      \
+    }
+    int tile = blockIdx.x;
+    CLB_MQ_LOAD(tile < n_tiles ? tile : n_tiles - 1)
+    int buf = 0;
+    while (tile < n_tiles) {            // uniform over the work-group: tile depends on blockIdx only
+        unsigned char* my = lds16 + buf * (2 * 32 * kRowBytes16);
+        *reinterpret_cast<uint4*>(my + prow * kRowBytes16 + 16 * pchunk) = ph0;
+        *reinterpret_cast<uint4*>(my + (16 + prow) * kRowBytes16 + 16 * pchunk) = ph1;
+        *reinterpret_cast<uint4*>(my + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl0;
+        *reinterpret_cast<uint4*>(my + (48 + prow) * kRowBytes16 + 16 * pchunk) = pl1;
+        const int next = tile + gridDim.x;
+        CLB_MQ_LOAD(next < n_tiles ? next : n_tiles - 1)
+        // one barrier per tile: the buffer written now was last read two iterations ago, before the previous barrier
+        __syncthreads();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(my + i * kRowBytes16 + 16 * (8 * h + s)));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(my + (32 + i) * kRowBytes16 + 16 * (8 * h + s)));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][s]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0);
+        }
+        const int c0 = tile * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            topn_insert_lazy<kTopPartial>(bv0, bi0, c < K ? acc0[r] : kNegInf, c);
+            topn_insert_lazy<kTopPartial>(bv1, bi1, c < K ? acc1[r] : kNegInf, c);
+        }
+        if (WRITE_HALF) {
+            // the tile's 32 x 32 scores leave as one contiguous 2-KB block of fp16 pairs {t, t+16}: transposed through
+            // a per-wave LDS patch (16 ds_write_b16 + 2 ds_read_b128) so that the wave issues 2 full-width stores
+            // instead of 16 quarter-filled ones
+            unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 2048;
+            const int pos = 2 * (i & 15) + (i >> 4);           // halfword of token i inside its centroid's 64 B
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    *reinterpret_cast<__half*>(patch + cl * 64 + pos * 2) = __float2half_rn(q ? acc1[r] : acc0[r]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int b = bq0 + q;
+                if (b < B) {
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(cells16 + ((size_t)b * K + c0) * 16);
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        const int off = part * 1024 + lane * 16;   // centroid c0 + off / 64
+                        if (c0 + (off >> 6) < K)
+                            *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(patch + off);
+                    }
+                }
+            }
+        }
+        tile = next;
+        buf ^= 1;
+    }
+#undef CLB_MQ_LOAD
+    const int slot = blockIdx.x * 2 + h;
+    const int nslots = gridDim.x * 2;
+    if (bq0 < B) {
+        ValIdx* out = partial + (((size_t)bq0 * nslots + slot) * 32 + i) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv0[p], bi0[p]};
+    }
+    if (bq0 + 1 < B) {
+        ValIdx* out = partial + (((size_t)(bq0 + 1) * nslots + slot) * 32 + i) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv1[p], bi1[p]};
+    }
+}
+
 // One wave per (token, query): merge the partial lists to the 8 best approximate centroids, re-score with the
 // canonical fp32 chain those within 2 eps_c of the 2nd best, emit the exact top-2.  grid = (32, B), block = 64.
 static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __restrict__ partial,
@@ -360,11 +501,6 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 // time, which keeps that table in the XCD's L2.
 // grid = 8 * wg_per_group, block = 256.
 // -------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 
 // One 16-embedding step of pass 1.  rb = this lane's 8 residual bytes; code/inv = the 4 rows this lane
 // finishes.  No row masking: in the tail step rows past the end of the passage are clamped copies of its last

@@ -179,8 +179,12 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
     const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
     if (nprobe <= 2 && T <= 32) {
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
-        const int gx = std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
-        const int nslots = gx * 4;
+        // batches of 8+ queries share each staged centroid tile between 8 queries (centroid_top_bf16x3_mq_kernel)
+        const bool mq = s->s1_mode == 1 && s->cent_hi.p && B >= kMqQueries;
+        const int groups = (B + kMqQueries - 1) / kMqQueries;
+        const int gx = mq ? std::max(1, std::min(n_tiles, std::min(256, std::max(512 / groups, 16))))
+                          : std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
+        const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
         if (s->s1_mode == 1 && s->cent_hi.p) {
@@ -189,7 +193,15 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
-                if (want_half)
+                if (mq && want_half)
+                    hipLaunchKernelGGL(centroid_top_bf16x3_mq_kernel<true>, dim3(gx, groups), dim3(256), lds_b16 + 4 * 2048, st,
+                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
+                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
+                else if (mq)
+                    hipLaunchKernelGGL(centroid_top_bf16x3_mq_kernel<false>, dim3(gx, groups), dim3(256), lds_b16, st,
+                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
+                                       w.partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, B, n_tiles);
+                else if (want_half)
                     hipLaunchKernelGGL(centroid_top_bf16x3_kernel<true>, dim3(gx, B), dim3(128), lds_b16, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);

@@ -239,6 +239,27 @@ def test_search_query_lengths(oracle, T):
     check_search(oracle, idx, synthetic.make_queries(idx, 12, 2, T=T), k=25)
 
 
+@pytest.mark.parametrize("T", [32, 20])
+def test_search_batch_sizes(oracle, T):
+    """Batches of 8+ queries take the shared-tile centroid kernel (8 queries per work-group, ragged last group);
+    smaller ones the per-query kernel.  Both must give the oracle's result in both modes."""
+    idx = synthetic.make_index(seed=19, n_docs=4000, K=1024)
+    Qs = synthetic.make_queries(idx, 20, 19, T=T)
+    ref = [oracle.search(idx, Qs[:, :, j], nprobe=2, k=50) for j in range(Qs.shape[2])]
+    s = clb.Searcher(index=idx)
+    try:
+        for mode in (0, 1):
+            s.set_mode(mode)
+            for B in (7, 8, 11, 16, 19):
+                bp, bs, bn = s.search_batch(np.asfortranarray(Qs[:, :, :B]), 50, nprobe=2)
+                for j in range(B):
+                    rp, rs, rn = ref[j]
+                    assert np.array_equal(bp[:, j], rp) and bn[j] == rn, (mode, B, j)
+                    assert_same_f32(bs[:, j], rs, f"mode={mode} B={B} q={j}")
+    finally:
+        s.close()
+
+
 def test_search_ragged_and_empty_passages(oracle):
     idx = synthetic.make_index(seed=13, n_docs=800, K=64, doclen_mean=20, doclen_std=30)
     # force zero-length passages (the reference tolerates them: _build_emb2pid test 3)
