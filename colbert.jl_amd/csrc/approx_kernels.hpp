@@ -502,56 +502,6 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 // grid = 8 * wg_per_group, block = 256.
 // -------------------------------------------------------------------------------------------------------------
 
-// One 16-embedding step of pass 1.  rb = this lane's 8 residual bytes; code/inv = the 4 rows this lane
-// finishes.  No row masking: in the tail step rows past the end of the passage are clamped copies of its last
-// embedding, which cannot change a max.
-template <int VARIANT>
-__device__ __forceinline__ void approx_tile(const uint2 rb, const uint32_t (&code)[4], const float (&inv)[4],
-                                            const uint32_t* __restrict__ c16, const u32x4 (&qb)[2][4],
-                                            uint32_t lut_lo, uint32_t lut_hi, uint32_t kmask, uint32_t kbase,
-                                            float& m0, float& m1) {
-    uint32_t cell[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cell[q] = c16[code[q] * 16u];
-    // bf16 A fragments: 16 nibbles -> 16 dwords of (w[i0], w[i1]) via the 4-entry byte LUT
-    u32x4 a[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t word = (s & 2) ? rb.y : rb.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (VARIANT == 1) { a[s][q] = word + q; continue; }     // ablation: no LUT expansion
-            const uint32_t nib = (word >> (16 * (s & 1) + 4 * q)) & 15u;
-            const uint32_t sel = ((nib * 0x808202u) & kmask) | kbase;
-            a[s][q] = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
-        }
-    }
-    // accumulators start from the centroid scores: acc = cells[t][code] + Q_t . r
-    f32x4 acc0, acc1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float2 cf = __half22float2(*reinterpret_cast<const __half2*>(&cell[q]));
-        acc0[q] = cf.x;
-        acc1[q] = cf.y;
-    }
-    if (VARIANT == 2) {                                             // ablation: no MFMA
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { acc0[s] += __uint_as_float(a[s][0] ^ a[s][2]); acc1[s] += __uint_as_float(a[s][1] ^ a[s][3]); }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                           __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                           __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0);
-        }
-    }
-    m0 = max3f(m0, acc0[0] * inv[0], acc0[1] * inv[1]);
-    m0 = max3f(m0, acc0[2] * inv[2], acc0[3] * inv[3]);
-    m1 = max3f(m1, acc1[0] * inv[0], acc1[1] * inv[1]);
-    m1 = max3f(m1, acc1[2] * inv[2], acc1[3] * inv[3]);
-}
-
 // Software pipeline, three 16-embedding steps in flight per wave (the code -> cells gather is a dependent
 // memory chain, and one step per wave leaves the kernel latency-bound):
 //   stage A(i+2): stream loads (8 residual bytes/lane, 4 codes, 4 inv_norms)
@@ -563,14 +513,38 @@ struct StepTag {      // wave-uniform description of a step
     int j;            // candidate slot, -1 = dummy
     int rows;         // valid rows (1..16)
     int last;         // 1 = last step of its passage
+    int base;         // index of the step's first embedding inside its passage
 };
 
+constexpr int kVariantRows = 6;
+
+// fp32 -> fp16 rounded toward -inf (a lower bound of x that is at most one fp16 ulp away)
+__device__ __forceinline__ uint32_t f32_to_f16_floor(float x) {
+    const __half hr = __float2half_rn(x);
+    uint32_t bits = *reinterpret_cast<const uint16_t*>(&hr);
+    if (__half2float(hr) > x) bits = (bits & 0x8000u) ? bits + 1u : (bits == 0u ? 0x8001u : bits - 1u);
+    return bits;
+}
+
+// VARIANT 0: pass 1 as described above; besides the score it leaves tokmax[b][slot][16] = fp16 pairs {t, t+16} of
+//            the per-token maxima a_t = max_j A[t][j] of every candidate passage, rounded DOWN.
+// VARIANT kVariantRows: pass 2 preparation over the passages in `list` -- which embeddings of a listed passage can
+//            hold a per-token maximum?  With |A - S| <= e (e = eps_pair[b]) the exact argmax j* of token t satisfies
+//            A[t][j*] >= S[t][j*] - e >= S[t][ja] - e >= a_t - 2e (ja = the approximate argmax).  So the exact
+//            kernel only has to decompress and multiply the rows J = { j : exists t, A[t][j] >= a_t - 2e } --
+//            typically a third of the passage -- and still finds the identical per-token maxima, hence the identical
+//            fp32 score.  The sweep recomputes A with the same pipeline, compares against the stored (floored, so
+//            only more permissive) a_t and writes rowmask[b][list position][4] x 64 bits; passages longer than
+//            kMaxMaskedRows embeddings are ignored downstream (the exact kernel then takes every row).
+// VARIANTs 2..5 are the ablations quoted in DESIGN.md.
 template <int VARIANT>
 static __global__ __launch_bounds__(256) void score_approx_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
     const float* __restrict__ inv_norm, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
-    int B, size_t cand_cap) {
+    int B, size_t cand_cap, uint32_t* __restrict__ tokmax, const int* __restrict__ list,
+    const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask) {
+    constexpr bool ROWS = VARIANT == kVariantRows;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int x = blockIdx.x & 7;             // XCD group label
@@ -611,25 +585,34 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
         const uint32_t* c16 = cells16 + (size_t)b * K * 16 + r;
         float* out = scores + (size_t)b * cand_cap;
-        const int n = ncand[b];
+        uint32_t* tmax = tokmax + (size_t)b * cand_cap * 16 + r;
+        const int* lst = ROWS ? list + (size_t)b * cand_cap : nullptr;
+        unsigned long long* rmask = ROWS ? rowmask + (size_t)b * cand_cap * 4 : nullptr;
+        const float window = ROWS ? 2.f * eps_pair[b] : 0.f;
+        const int n = ROWS ? nlist[b] : ncand[b];
         const int stride = wg_per_group * 4 * nsub;
+        unsigned long long wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;   // ROWS: the current passage's mask (wave-uniform)
 
         // ---- wave-uniform iterator over the steps of passages j0, j0+stride, ... ------------------------------
         // The headers {first embedding, length} of the wave's next 64 passages sit in one VGPR pair (lane k =
         // k-th passage) and are extracted with v_readlane: no memory wait at a passage switch.
         for (int j0 = (sub * wg_per_group + wg) * 4 + wave; j0 < n; j0 += 64 * stride) {
         const int jl = j0 + lane * stride;
-        const uint2 hv = hdr[jl < n ? jl : j0];
+        int slot_l = jl < n ? jl : j0;                       // candidate slot of this lane's passage
+        if (ROWS) slot_l = lst[slot_l];
+        const uint2 hv = hdr[slot_l];
         const int nd = (n - j0 + stride - 1) / stride < 64 ? (n - j0 + stride - 1) / stride : 64;   // passages here
         int it_k = 0;
         uint32_t it_off = __builtin_amdgcn_readlane(hv.x, 0);
         int it_len = (int)__builtin_amdgcn_readlane(hv.y, 0);
+        int it_slot = __builtin_amdgcn_readlane(slot_l, 0);
         int it_base = 0;
 
-#define CLB_STAGE_A(RB, CV, IV, TAG)                                                                        \
+#define CLB_STAGE_A(RB, CV, IV, PM, TAG)                                                                    \
     {                                                                                                       \
         const bool live = it_k < nd;                                                                        \
         const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
+        if (ROWS) PM = tmax[(size_t)(live ? it_slot : 0) * 16];   /* the passage's stored maxima {t, t+16} */ \
         if (VARIANT == 5) {   /* ablation: no streaming loads */                                           \
             RB = make_uint2(e0 * 2654435761u + lane_res, e0 ^ lane_res);                                    \
             CV = u32x4{(e0 + lane_row) & 131071u, (e0 * 7u + lane_row) & 131071u, (e0 * 13u) & 131071u, (e0 * 29u) & 131071u}; \
@@ -644,12 +627,14 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \
         TAG.rows = left < 16 ? left : 16;                                                                   \
         TAG.last = left <= 16;                                                                              \
+        TAG.base = it_base;                                                                                 \
         it_base += 16;                                                                                      \
         if (TAG.last) {                                                                                     \
             it_k += 1;                                                                                      \
             const int kk = it_k < 64 ? it_k : 63;                                                           \
             it_off = __builtin_amdgcn_readlane(hv.x, kk);                                                   \
             it_len = (int)__builtin_amdgcn_readlane(hv.y, kk);                                              \
+            it_slot = __builtin_amdgcn_readlane(slot_l, kk);                                                \
             it_base = 0;                                                                                    \
         }                                                                                                   \
     }
@@ -657,7 +642,7 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
     {                                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) CELL[q] = VARIANT == 3 ? CV[q] : c16[CV[q] * 16u];    \
     }
-#define CLB_STAGE_C(RB, IV, CELL, TAG)                                                                      \
+#define CLB_STAGE_C(RB, IV, CELL, PM, TAG)                                                                  \
     {                                                                                                       \
         u32x4 a[4];                                                                                         \
         /* byte -> 4 bf16 bucket weights through the 2-KB LDS table: 8 ds_read_b64 replace 64 VALU ops.   */ \
@@ -713,6 +698,30 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
                 v1[q] = ok ? v1[q] : kNegInf;                                                               \
             }                                                                                               \
         }                                                                                                   \
+        if (ROWS) {                                                                                         \
+            const float2 pm = __half22float2(*reinterpret_cast<const __half2*>(&PM));                       \
+            const float lo0 = r < T ? pm.x - window : __builtin_inff();   /* tokens past T select nothing */ \
+            const float lo1 = 16 + r < T ? pm.y - window : __builtin_inff();                                \
+            unsigned long long bits = 0;                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(v0[q] >= lo0 || v1[q] >= lo1);   \
+                _Pragma("unroll") for (int gg = 0; gg < 4; ++gg)                                            \
+                    if ((bal >> (16 * gg)) & 0xffffull) bits |= 1ull << (4 * gg + q);                       \
+            }                                                                                               \
+            bits <<= (TAG.base & 63);                                                                       \
+            const int wi = (TAG.base >> 6) & 3;                                                             \
+            wm0 |= wi == 0 ? bits : 0ull;                                                                   \
+            wm1 |= wi == 1 ? bits : 0ull;                                                                   \
+            wm2 |= wi == 2 ? bits : 0ull;                                                                   \
+            wm3 |= wi == 3 ? bits : 0ull;                                                                   \
+            if (TAG.last) {                                                                                 \
+                if (lane == 0 && TAG.j >= 0) {                                                              \
+                    unsigned long long* o = rmask + (size_t)TAG.j * 4;                                      \
+                    o[0] = wm0; o[1] = wm1; o[2] = wm2; o[3] = wm3;                                         \
+                }                                                                                           \
+                wm0 = wm1 = wm2 = wm3 = 0;                                                                  \
+            }                                                                                               \
+        } else {                                                                                            \
         m0 = max3f(m0, v0[0], v0[1]);                                                                       \
         m0 = max3f(m0, v0[2], v0[3]);                                                                       \
         m1 = max3f(m1, v1[0], v1[1]);                                                                       \
@@ -728,8 +737,11 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
             sum += __shfl_xor(sum, 4, 64);                                                                  \
             sum += __shfl_xor(sum, 8, 64);                                                                  \
             if (lane == 0 && TAG.j >= 0) out[TAG.j] = sum;                                                  \
+            if (VARIANT == 0 && g == 0 && TAG.j >= 0)                                                       \
+                tmax[(size_t)TAG.j * 16] = f32_to_f16_floor(m0) | (f32_to_f16_floor(m1) << 16);             \
             m0 = kNegInf;                                                                                   \
             m1 = kNegInf;                                                                                   \
+        }                                                                                                   \
         }                                                                                                   \
     }
 
@@ -738,20 +750,21 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         u32x4 cv0, cv1, cv2;
         f32x4 iv0, iv1, iv2;
         uint32_t ce0[4], ce1[4], ce2[4];
+        uint32_t pm0 = 0, pm1 = 0, pm2 = 0;
         StepTag t0, t1, t2;
-        CLB_STAGE_A(rb0, cv0, iv0, t0);
-        CLB_STAGE_A(rb1, cv1, iv1, t1);
+        CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
+        CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
         CLB_STAGE_G(cv0, ce0);
         while (t0.j >= 0) {
-            CLB_STAGE_A(rb2, cv2, iv2, t2);
+            CLB_STAGE_A(rb2, cv2, iv2, pm2, t2);
             CLB_STAGE_G(cv1, ce1);
-            CLB_STAGE_C(rb0, iv0, ce0, t0);
-            CLB_STAGE_A(rb0, cv0, iv0, t0);
+            CLB_STAGE_C(rb0, iv0, ce0, pm0, t0);
+            CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
             CLB_STAGE_G(cv2, ce2);
-            CLB_STAGE_C(rb1, iv1, ce1, t1);
-            CLB_STAGE_A(rb1, cv1, iv1, t1);
+            CLB_STAGE_C(rb1, iv1, ce1, pm1, t1);
+            CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
             CLB_STAGE_G(cv0, ce0);
-            CLB_STAGE_C(rb2, iv2, ce2, t2);
+            CLB_STAGE_C(rb2, iv2, ce2, pm2, t2);
         }
         }   // chunk of 64 passages
 #undef CLB_STAGE_A
@@ -775,7 +788,8 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    const float* __restrict__ Q, int T, int k,
                                                                    size_t cand_cap, ApproxConsts ac,
                                                                    int* __restrict__ list, int* __restrict__ nlist,
-                                                                   float* __restrict__ thresh) {
+                                                                   float* __restrict__ thresh,
+                                                                   float* __restrict__ eps_pair) {
     __shared__ int hist[256];
     __shared__ int sh_scan[16];
     __shared__ uint32_t s_prefix;
@@ -798,6 +812,13 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     __syncthreads();
     const int keff = n < k ? n : k;
     float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
+    // bound on |approx - canonical| of ONE (token, embedding) score; see the header of this file
+    const float u = 5.9604645e-08f;  // 2^-24
+    const float qn = s_qn;
+    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
+    const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
+    const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
+    if (tid == 0) eps_pair[b] = kEpsSafety * eps_t;
     if (n > k) {
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
@@ -821,11 +842,6 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             }
             __syncthreads();
         }
-        const float u = 5.9604645e-08f;  // 2^-24
-        const float qn = s_qn;
-        const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
-        const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
-        const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;

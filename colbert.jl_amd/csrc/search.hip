@@ -19,11 +19,13 @@ enum KernelId {
     KID_SCORE_EXACT,
     KID_SCORE_APPROX,
     KID_SELECT,
+    KID_ROWS,
     KID_TOPK,
     KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"centroid_scores", "top_nprobe", "mark_candidates", "compact_candidates",
-                                       "score_exact",     "score_approx", "select_margin", "topk"};
+                                       "score_exact",     "score_approx", "select_margin", "rescore_rows",
+                                       "topk"};
 
 struct Prof {
     bool on = false;
@@ -51,7 +53,7 @@ struct Workspace {
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax;
 };
 
 struct clb_searcher {
@@ -148,7 +150,12 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     CLB_TRY(w.outs.ensure(sizeof(float) * B * k));
     CLB_TRY(w.flags.ensure(sizeof(int) * B));
     CLB_TRY(w.stats.ensure(sizeof(unsigned long long) * 8));
-    if (s->approx_ok) CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
+    if (s->approx_ok) {
+        CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
+        CLB_TRY(w.rowmask.ensure(sizeof(unsigned long long) * 4 * B * w.cand_cap));
+        CLB_TRY(w.eps_pair.ensure(sizeof(float) * B));
+        CLB_TRY(w.tokmax.ensure(sizeof(uint32_t) * 16 * B * w.cand_cap));
+    }
     w.Bcap = B; w.Tcap = T; w.npcap = nprobe; w.kcap = k;
     CLB_HIP(hipStreamSynchronize(s->stream));
     return CLB_OK;
@@ -301,7 +308,8 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     hipLaunchKernelGGL(score_approx_kernel<V>, dim3(8 * wgpg), dim3(256), 0, st, s->weights.as<float>(),              \
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(), \
-                       (int)s->K, T, B, w.cand_cap)
+                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint32_t>(), (const int*)nullptr,                    \
+                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
             if (variant == 1) CLB_LAUNCH_APPROX(1);
             else if (variant == 2) CLB_LAUNCH_APPROX(2);
             else if (variant == 3) CLB_LAUNCH_APPROX(3);
@@ -314,15 +322,33 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
             Timed t(s, KID_SELECT, st);
             hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(),
                                w.ncand.as<int>(), dQ, T, k, w.cand_cap, s->approx_consts, w.list.as<int>(),
-                               w.nlist.as<int>(), w.thresh.as<float>());
+                               w.nlist.as<int>(), w.thresh.as<float>(), w.eps_pair.as<float>());
         }
         list = w.list.as<int>();
         nlist = w.nlist.as<int>();
+    }
+    static const bool no_subset = getenv("CLB_DEBUG_NO_SUBSET") != nullptr;
+    const bool subset = list && !no_subset;   // two-pass mode (nbits 2, T <= 32): re-score only the rows that matter
+    if (subset) {
+        Timed t(s, KID_ROWS, st);
+        // the pass-1 pipeline again, over the listed passages only: marks the rows that can hold a token maximum
+        static const int rows_wgpg = getenv("CLB_DEBUG_ROWS_WGPG") ? atoi(getenv("CLB_DEBUG_ROWS_WGPG")) : 128;
+        hipLaunchKernelGGL(score_approx_kernel<kVariantRows>, dim3(8 * rows_wgpg), dim3(256), 0, st, s->weights.as<float>(),
+                           s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
+                           w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                           (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint32_t>(), list, nlist, w.eps_pair.as<float>(),
+                           w.rowmask.as<unsigned long long>());
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
         static const int gxl = getenv("CLB_DEBUG_EXACT_GX") ? atoi(getenv("CLB_DEBUG_EXACT_GX")) : 1024;
         const int gx = list ? std::max(1, gxl / B) : std::max(1, 2048 / B);
+        if (subset) {
+            hipLaunchKernelGGL((score_exact_kernel<2, true>), dim3(gx, B), dim3(256), 0, st, s->centroids.as<float>(),
+                               s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
+                               w.cand_hdr.as<uint2>(), dQ, w.ncand.as<int>(), w.scores.as<float>(), T, w.cand_cap,
+                               list, nlist, w.rowmask.as<unsigned long long>());
+        } else
         switch (s->nbits) {
             case 1: launch_score_exact<1>(s, w, st, dQ, B, T, list, nlist, gx); break;
             case 2: launch_score_exact<2>(s, w, st, dQ, B, T, list, nlist, gx); break;
@@ -339,7 +365,8 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (s->prof.on) {
         hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, w.cand.as<uint32_t>(),
                            w.ncand.as<int>(), list, nlist, s->doc_off.as<uint32_t>(), w.cand_cap,
-                           w.stats.as<unsigned long long>());
+                           w.stats.as<unsigned long long>(),
+                           subset ? w.rowmask.as<unsigned long long>() : (const unsigned long long*)nullptr);
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
@@ -476,7 +503,7 @@ int64_t clb_searcher_device_bytes(const clb_searcher* s) {
     int64_t tot = s->index_bytes;
     for (const auto& w : s->ws) {
         const DevBuf* bufs[] = {&w.Qdev, &w.cells, &w.cells_q, &w.partial, &w.sel, &w.bitmap, &w.blocksum, &w.ncand, &w.cand,
-                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo};
+                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax};
         for (auto* b : bufs) tot += (int64_t)b->bytes;
     }
     return tot;
@@ -588,10 +615,11 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     hipLaunchKernelGGL(score_approx_kernel<0>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                       (int)s->K, (int)T, 1, w.cand_cap);
+                       (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint32_t>(), (const int*)nullptr,
+                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ,
                        (int)T, (int)k, w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(),
-                       w.thresh.as<float>());
+                       w.thresh.as<float>(), w.eps_pair.as<float>());
     int nc = 0, nl = 0;
     float th[2];
     CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));

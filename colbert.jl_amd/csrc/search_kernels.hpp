@@ -539,13 +539,20 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
 //     strided dword gathers per lane -- the gathers alone held the kernel at 0.9 ms for 3.4 M embeddings (TA
 //     bound); 16-B chunk c of row r sits at slot c*16 + (r ^ (c & 15)), which makes both the b128 writes and
 //     the stride-4 b32 reads of lane (r, g) at most 2-way bank conflicted.
-template <int NBITS>
+// SUBSET (two-pass mode): `rowmask` ([B][cand_cap][4] x 64 bits, indexed by the position in `list`, written by
+// rescore_rows_kernel) names the embeddings of each listed passage that can hold a per-token maximum; only those
+// rows are decompressed and multiplied.  Passages longer than kMaxMaskedRows take every row.
+constexpr int kMaxMaskedRows = 256;
+
+template <int NBITS, bool SUBSET = false>
 static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
     const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const float* __restrict__ Q,
     const int* __restrict__ ncand, float* __restrict__ scores, int T, size_t cand_cap,
-    const int* __restrict__ list /*optional*/, const int* __restrict__ nlist) {
+    const int* __restrict__ list /*optional*/, const int* __restrict__ nlist,
+    const unsigned long long* __restrict__ rowmask = nullptr) {
     constexpr int RD = NBITS * 4;  // residual dwords per embedding
+    __shared__ uint16_t rowlists[SUBSET ? 4 * kMaxMaskedRows : 4];
     __shared__ float tbl[(8 / NBITS) * kWTblStride];
     __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];    // 16 KB
     __shared__ __attribute__((aligned(16))) float ctiles[4 * 512 * 4];  // 4 waves x 8 KB
@@ -598,21 +605,65 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
         __syncthreads();
         stage_q(tt);
         __syncthreads();
+        // The header (and mask) of the next passage and the slot of the one after are requested while the current
+        // passage is being scored: the list -> header -> codes -> rows chain of dependent loads otherwise leaves
+        // the wave idle for several memory round trips per passage.
+        int slot_cur = wave_global < n ? (lst ? lst[wave_global] : wave_global) : 0;
+        int slot_nxt = wave_global + nwaves < n ? (lst ? lst[wave_global + nwaves] : wave_global + nwaves) : 0;
+        uint2 h_cur = hdr[slot_cur];
+        unsigned long long mk_cur[4] = {0, 0, 0, 0};
+        if (SUBSET && wave_global < n) {
+            const unsigned long long* mw = rowmask + ((size_t)b * cand_cap + wave_global) * 4;
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) mk_cur[wi] = mw[wi];
+        }
         for (int j = wave_global; j < n; j += nwaves) {
-            const int slot = lst ? lst[j] : j;  // index into the candidate array
-            const uint2 h = hdr[slot];
-            const uint32_t off = __builtin_amdgcn_readfirstlane(h.x);
-            const int len = (int)__builtin_amdgcn_readfirstlane(h.y);
+            const int slot = slot_cur;  // index into the candidate array
+            const uint32_t off = __builtin_amdgcn_readfirstlane(h_cur.x);
+            int len = (int)__builtin_amdgcn_readfirstlane(h_cur.y);   // SUBSET: becomes the number of selected rows
+            unsigned long long mk[4];
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) mk[wi] = mk_cur[wi];
+            {
+                const int j1 = j + nwaves, j2 = j + 2 * nwaves;
+                slot_cur = slot_nxt;
+                if (j1 < n) {
+                    h_cur = hdr[slot_nxt];
+                    if (SUBSET) {
+                        const unsigned long long* mw = rowmask + ((size_t)b * cand_cap + j1) * 4;
+#pragma unroll
+                        for (int wi = 0; wi < 4; ++wi) mk_cur[wi] = mw[wi];
+                    }
+                }
+                slot_nxt = j2 < n ? (lst ? lst[j2] : j2) : 0;
+            }
+            bool ident = true;
+            uint16_t* rowlist = rowlists + (SUBSET ? wave * kMaxMaskedRows : 0);
+            if (SUBSET && len <= kMaxMaskedRows) {
+                // expand the 256-bit mask into the ascending list of selected rows (lane L owns bit L of each word)
+                ident = false;
+                int prefix = 0;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const unsigned long long word = 64 * wi < len ? mk[wi] : 0ull;
+                    const unsigned long long below = word & ((1ull << lane) - 1ull);
+                    if ((word >> lane) & 1ull) rowlist[prefix + __popcll(below)] = (uint16_t)(64 * wi + lane);
+                    prefix += __popcll(word);
+                }
+                __builtin_amdgcn_wave_barrier();
+                len = __builtin_amdgcn_readfirstlane(prefix);
+            }
             float m0 = kNegInf, m1 = kNegInf;
             // software prefetch, two steps deep for the codes (the row loads of step i+1 need code(i+1) early)
-            auto code_at = [&](int base) {
-                const int el = base + r;
-                return codes0[off + (uint32_t)(el < len ? el : len - 1)];
+            auto row_at = [&](int el) -> uint32_t {
+                const int idx = el < len ? el : len - 1;
+                return (SUBSET && !ident) ? (uint32_t)rowlist[idx] : (uint32_t)idx;
             };
+            auto code_at = [&](int base) { return codes0[off + row_at(base + r)]; };
             uint32_t Rn[RD];
             auto load_res = [&](int base) {
-                const int el = base + r;
-                const uint32_t e = off + (uint32_t)(el < len ? el : len - 1);
+                const uint32_t e = off + row_at(base + r);
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(residuals + (size_t)e * (RD * 4));
 #pragma unroll
                 for (int k4 = 0; k4 < RD; k4 += 4) {
@@ -846,7 +897,8 @@ static __global__ void widen_counts_kernel(const int* __restrict__ in, int64_t* 
 static __global__ void batch_stats_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
                                    const int* __restrict__ list, const int* __restrict__ nlist,
                                    const uint32_t* __restrict__ doc_off, size_t cand_cap,
-                                   unsigned long long* __restrict__ stats) {
+                                   unsigned long long* __restrict__ stats,
+                                   const unsigned long long* __restrict__ rowmask /*optional*/) {
     const int b = blockIdx.y;
     const uint32_t* cnd = cand + (size_t)b * cand_cap;
     unsigned long long embs = 0, lembs = 0;
@@ -858,7 +910,13 @@ static __global__ void batch_stats_kernel(const uint32_t* __restrict__ cand, con
     const int nl = list ? nlist[b] : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
         const uint32_t p = cnd[list[(size_t)b * cand_cap + i]];
-        lembs += doc_off[p + 1] - doc_off[p];
+        const uint32_t len = doc_off[p + 1] - doc_off[p];
+        if (rowmask && len <= (uint32_t)kMaxMaskedRows) {      // rows the exact kernel really multiplies
+            const unsigned long long* mw = rowmask + ((size_t)b * cand_cap + i) * 4;
+            lembs += __popcll(mw[0]) + __popcll(mw[1]) + __popcll(mw[2]) + __popcll(mw[3]);
+        } else {
+            lembs += len;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         embs += __shfl_down(embs, o, 64);
