@@ -377,71 +377,113 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// One wave per (token, query): merge the partial lists to the 8 best approximate centroids, re-score with the
-// canonical fp32 chain those within 2 eps_c of the 2nd best, emit the exact top-2.  grid = (32, B), block = 64.
+// One wave per (token, query).  a2 = the token's 2nd best approximate score over all partial lists; every listed
+// centroid with an approximate score >= a2 - 2 eps_c is re-scored with the canonical fp32 fmaf chain and the exact
+// top-2 by (score desc, index asc) comes out.  Two streaming sweeps over the lists (they stay in L2): sweep 1 keeps
+// each lane's two best entries and reduces them over the wave, sweep 2 compacts the qualifying entries (normally 2 to
+// 4) into LDS.  A partial list whose LAST entry qualifies may have dropped a qualifying centroid, and more than
+// kTopRefine qualifying entries do not fit: both cases fall back to the exhaustive canonical scan in this wave
+// (never seen in practice).  grid = (32, B), block = 64.
 static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __restrict__ partial,
                                                               const float* __restrict__ C,
                                                               const float* __restrict__ Q, int T, int K,
                                                               int nslots, float cn_max, int* __restrict__ sel,
                                                               int* __restrict__ redo_flag) {
+    static_assert(kTopPartial == 4, "a partial list is read as two 16-byte halves");
     const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (t >= T) {
         if (lane == 0) { sel[((size_t)b * 32 + t) * 2] = 0; sel[((size_t)b * 32 + t) * 2 + 1] = 0; }
         return;
     }
-    float bv[kTopRefine];
-    int bi[kTopRefine];
-#pragma unroll
-    for (int p = 0; p < kTopRefine; ++p) { bv[p] = kNegInf; bi[p] = 0x7fffffff; }
-    float fourth_max = kNegInf;   // largest "last entry" of any partial list this lane saw
+    __shared__ float qs[kDim];
+    __shared__ ValIdx cand[kTopRefine];
+    __shared__ int cand_n;
+    const float* q = Q + ((size_t)b * T + t) * kDim;
+    qs[lane] = q[lane];
+    qs[lane + 64] = q[lane + 64];
+    if (lane == 0) cand_n = 0;
+    const ValIdx* lists = partial + ((size_t)b * nslots * 32 + t) * kTopPartial;   // slot stride: 32 * kTopPartial
+    const size_t slot_stride = (size_t)32 * kTopPartial;
+    // sweep 1: the lane's two best entries.  Lists are sorted, so only their first two entries can matter here;
+    // last_max = the largest LAST entry (the overflow test below).
+    float b1v = kNegInf, b2v = kNegInf, last_max = kNegInf;
+    int b1i = 0x7fffffff, b2i = 0x7fffffff;
+#pragma unroll 4
     for (int sl = lane; sl < nslots; sl += 64) {
-        const ValIdx* in = partial + (((size_t)b * nslots + sl) * 32 + t) * kTopPartial;
+        const uint4 lo = *reinterpret_cast<const uint4*>(lists + (size_t)sl * slot_stride);
+        const float last = lists[(size_t)sl * slot_stride + kTopPartial - 1].v;
+        const float v0 = __uint_as_float(lo.x), v1 = __uint_as_float(lo.z);
+        const int i0 = (int)lo.y, i1 = (int)lo.w;
 #pragma unroll
-        for (int p = 0; p < kTopPartial; ++p) topn_insert_lazy<kTopRefine>(bv, bi, in[p].v, in[p].i);
-        fourth_max = fmaxf(fourth_max, in[kTopPartial - 1].v);
+        for (int e = 0; e < 2; ++e) {
+            const float v = e ? v1 : v0;
+            const int i = e ? i1 : i0;
+            const bool gt1 = better(v, i, b1v, b1i), gt2 = better(v, i, b2v, b2i);
+            b2v = gt1 ? b1v : (gt2 ? v : b2v);
+            b2i = gt1 ? b1i : (gt2 ? i : b2i);
+            b1v = gt1 ? v : b1v;
+            b1i = gt1 ? i : b1i;
+        }
+        last_max = fmaxf(last_max, last);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        float ov[kTopRefine];
-        int oi[kTopRefine];
-#pragma unroll
-        for (int p = 0; p < kTopRefine; ++p) { ov[p] = __shfl_xor(bv[p], o, 64); oi[p] = __shfl_xor(bi[p], o, 64); }
-#pragma unroll
-        for (int p = 0; p < kTopRefine; ++p) topn_insert<kTopRefine>(bv, bi, ov[p], oi[p]);
-        fourth_max = fmaxf(fourth_max, __shfl_xor(fourth_max, o, 64));
+        const float o1v = __shfl_xor(b1v, o, 64), o2v = __shfl_xor(b2v, o, 64);
+        const int o1i = __shfl_xor(b1i, o, 64), o2i = __shfl_xor(b2i, o, 64);
+        // merge two sorted pairs: the best two of {b1, b2, o1, o2}
+        const bool mine = better(b1v, b1i, o1v, o1i);
+        const float w1v = mine ? b1v : o1v, l1v = mine ? o1v : b1v;      // winner / loser of the firsts
+        const int w1i = mine ? b1i : o1i, l1i = mine ? o1i : b1i;
+        const float s2v = mine ? b2v : o2v;                              // the winner's own second
+        const int s2i = mine ? b2i : o2i;
+        const bool sec = better(l1v, l1i, s2v, s2i);
+        b1v = w1v; b1i = w1i;
+        b2v = sec ? l1v : s2v;
+        b2i = sec ? l1i : s2i;
+        last_max = fmaxf(last_max, __shfl_xor(last_max, o, 64));
     }
-    // every lane now holds the same top-8; error bound of the approximate scores for this token
-    const float* q = Q + ((size_t)b * T + t) * kDim;
-    __shared__ float qs[kDim];
-    qs[lane] = q[lane];
-    qs[lane + 64] = q[lane + 64];
     __syncthreads();
     float qq = qs[lane] * qs[lane] + qs[lane + 64] * qs[lane + 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
     const float eps_c = kEpsSafety * 7.4e-5f * (sqrtf(qq) * 1.001f) * cn_max;
-    const float thr = bv[1] - 2.f * eps_c;
-    // a partial list that is full down to its last entry above thr may have dropped a qualifying centroid;
-    // so may the merged list -- flag the query for the fp32 kernel
-    const bool overflow = (K > kTopRefine && bv[kTopRefine - 1] >= thr) || (K > kTopPartial && fourth_max >= thr);
+    const float thr = b2v - 2.f * eps_c;
+    // sweep 2: every entry >= thr goes to the LDS candidate list (order is irrelevant: they are re-scored exactly)
+    int total = 0;
+    for (int base = 0; base < nslots; base += 64) {
+        const int sl = base + lane;
+        uint4 lo = make_uint4(0xff800000u, 0x7fffffffu, 0xff800000u, 0x7fffffffu), hi = lo;
+        if (sl < nslots) {
+            lo = *reinterpret_cast<const uint4*>(lists + (size_t)sl * slot_stride);
+            hi = *reinterpret_cast<const uint4*>(lists + (size_t)sl * slot_stride + 2);
+        }
+        const float v[4] = {__uint_as_float(lo.x), __uint_as_float(lo.z), __uint_as_float(hi.x), __uint_as_float(hi.z)};
+        const int id[4] = {(int)lo.y, (int)lo.w, (int)hi.y, (int)hi.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool take = id[e] != 0x7fffffff && v[e] >= thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            if (m == 0) break;                                   // sorted lists: later entries are smaller
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (take && pos < kTopRefine) cand[pos] = ValIdx{v[e], id[e]};
+            total += __popcll(m);
+        }
+    }
+    __syncthreads();
+    const bool overflow = total > kTopRefine || (K > kTopPartial && last_max >= thr);
     float tv[2] = {kNegInf, kNegInf};
     int ti[2] = {0x7fffffff, 0x7fffffff};
     if (!overflow) {
-        // lanes 0..7 re-score candidate `lane` exactly
-        float ex = kNegInf;
-        int id = 0x7fffffff;
-#pragma unroll
-        for (int p = 0; p < kTopRefine; ++p)
-            if (lane == p) { ex = bv[p]; id = bi[p]; }
-        const bool valid = lane < kTopRefine && id != 0x7fffffff && ex >= thr;
-        if (valid) {
+        // lanes 0..total-1 re-score one candidate each with the chain the fp32 MFMA kernel performs
+        if (lane < total) {
+            const int id = cand[lane].i;
             const float4* c4 = reinterpret_cast<const float4*>(C + (size_t)id * kDim);
             float4 cr[32];
 #pragma unroll
             for (int m = 0; m < 32; ++m) cr[m] = c4[m];               // all loads in flight, then the ordered chain
             float a = 0.f;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) {                            // the chain the fp32 MFMA kernel performs
+            for (int m = 0; m < 32; ++m) {
                 a = fmaf(cr[m].x, qs[4 * m], a);
                 a = fmaf(cr[m].y, qs[4 * m + 1], a);
                 a = fmaf(cr[m].z, qs[4 * m + 2], a);
@@ -450,8 +492,6 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
             topn_insert<2>(tv, ti, a, id);
         }
     } else {
-        // too many near-ties for the candidate lists (never seen in practice): this wave scores every centroid
-        // for its token with the canonical chain
         for (int c = lane; c < K; c += 64) {
             const float* cr = C + (size_t)c * kDim;
             float a = 0.f;
