@@ -830,7 +830,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    int* __restrict__ list, int* __restrict__ nlist,
                                                                    float* __restrict__ thresh,
                                                                    float* __restrict__ eps_pair) {
-    __shared__ int hist[256];
+    __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[16];
     __shared__ uint32_t s_prefix;
     __shared__ int s_remaining, s_run;
@@ -842,15 +842,19 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
     if (tid == 0) s_qn = 0.f;
     __syncthreads();
-    if (tid < T) {
-        const float* q = Q + ((size_t)b * T + tid) * kDim;
+    {   // 32 threads per token, one float4 each (T <= 32 in this mode)
+        const int t = tid >> 5, part = tid & 31;
         float a = 0.f;
-        for (int d = 0; d < kDim; ++d) a = fmaf(q[d], q[d], a);
-        atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
+        if (t < T) {
+            const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
+            a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (t < T && part == 0) atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
     }
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
     __syncthreads();
-    const int keff = n < k ? n : k;
     float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
     // bound on |approx - canonical| of ONE (token, embedding) score; see the header of this file
     const float u = 5.9604645e-08f;  // 2^-24
@@ -859,6 +863,33 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
     const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
     if (tid == 0) eps_pair[b] = kEpsSafety * eps_t;
+    // thread t owns the contiguous slots [t*chunk, (t+1)*chunk); up to kSelCache order keys stay in registers for the
+    // radix passes and the compaction (the approximate scores are read once)
+    const int chunk = (n + 1023) >> 10;
+    const int i0 = tid * chunk;
+    const bool cached = chunk <= kSelCache;   // uniform over the block
+    uint32_t ckey[kSelCache];
+    if (cached) {
+#pragma unroll
+        for (int c = 0; c < kSelCache; ++c) ckey[c] = (c < chunk && i0 + c < n) ? f32_order_key(sc[i0 + c]) : 0u;
+    }
+#define CLB_SEL_FOR_EACH(...)                                                                   \
+    if (cached) {                                                                               \
+        _Pragma("unroll") for (int c = 0; c < kSelCache; ++c) {                                 \
+            if (c >= chunk) break;                                                              \
+            const int i = i0 + c;                                                               \
+            const bool valid = i < n;                                                           \
+            const uint32_t key = ckey[c];                                                       \
+            __VA_ARGS__                                                                         \
+        }                                                                                       \
+    } else {                                                                                    \
+        for (int c = 0; c < chunk; ++c) {                                                       \
+            const int i = i0 + c;                                                               \
+            const bool valid = i < n;                                                           \
+            const uint32_t key = valid ? f32_order_key(sc[i]) : 0u;                             \
+            __VA_ARGS__                                                                         \
+        }                                                                                       \
+    }
     if (n > k) {
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
@@ -866,52 +897,41 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             __syncthreads();
             const uint32_t prefix = s_prefix;
             const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int i = tid; i < n; i += 1024) {
-                const uint32_t key = f32_order_key(sc[i]);
-                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
-            }
+            CLB_SEL_FOR_EACH((void)i; hist_add_aggregated(hist, (key >> shift) & 255, valid && (key & himask) == prefix);)
             __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining, d = 255;
-                for (; d > 0; --d) {
-                    if (hist[d] >= rem) break;
-                    rem -= hist[d];
-                }
-                s_prefix = prefix | ((uint32_t)d << shift);
-                s_remaining = rem;
-            }
+            if (tid < 64) radix_pick(hist, s_remaining, prefix, shift, &s_prefix, &s_remaining);
             __syncthreads();
         }
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;
     }
-    (void)keff;
-    // ordered compaction of the slots with approx >= thr (all of them when n <= k)
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const bool take = i < n && sc[i] >= thr;
+    // ordered compaction of the slots with approx >= thr (all of them when n <= k): one block-wide scan of the
+    // per-thread counts places every chunk in order
+    {
+        int cnt = 0;
+        CLB_SEL_FOR_EACH((void)i; cnt += valid && f32_from_order_key(key) >= thr;)
         const int lane = tid & 63, wave = tid >> 6;
-        int xv = take ? 1 : 0;
-        const int v = xv;
+        int xv = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            int y = __shfl_up(xv, o, 64);
+            const int y = __shfl_up(xv, o, 64);
             if (lane >= o) xv += y;
         }
         if (lane == 63) sh_scan[wave] = xv;
         __syncthreads();
         int wbase = 0, tot = 0;
         for (int w2 = 0; w2 < 16; ++w2) {
-            const int s = sh_scan[w2];
-            if (w2 < wave) wbase += s;
-            tot += s;
+            const int sv = sh_scan[w2];
+            if (w2 < wave) wbase += sv;
+            tot += sv;
         }
-        if (take) lst[s_run + wbase + xv - v] = i;
-        __syncthreads();
-        if (tid == 0) s_run += tot;
+        int pos = wbase + xv - cnt;
+        CLB_SEL_FOR_EACH(if (valid && f32_from_order_key(key) >= thr) lst[pos++] = i;)
+        if (tid == 0) s_run = tot;
         __syncthreads();
     }
+#undef CLB_SEL_FOR_EACH
     if (tid == 0) {
         nlist[b] = s_run;
         thresh[2 * b] = tau_f;

@@ -725,6 +725,52 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
 #undef CLB_ROW_STORE
 }
 
+// hist[bin] += 1 for every active lane.  MaxSim scores of one query share their exponent and leading mantissa bits,
+// so in the first radix passes a whole wave hits one or two bins and per-lane LDS atomics serialise 64 deep; lanes
+// sharing a bin are therefore merged into one atomic (up to four distinct bins per call, plain atomics after that).
+// One radix-select step on a finished 256-bin histogram, by the first wave of the block: the digit d whose bin
+// holds the rem-th largest key (bins above d hold fewer than rem keys, together with bin d at least rem), and the
+// rank that remains inside that bin.  Lane L owns bins 4L..4L+3; a wave-wide suffix sum replaces the serial walk
+// over 256 LDS words (which cost ~7 us per pass).  Requires 1 <= rem <= sum(hist).
+__device__ __forceinline__ void radix_pick(const int* hist, int rem, uint32_t prefix, int shift,
+                                           uint32_t* s_prefix, int* s_remaining) {
+    const int lane = threadIdx.x & 63;
+    const int4 h = *reinterpret_cast<const int4*>(hist + 4 * lane);
+    const int own = h.x + h.y + h.z + h.w;
+    int x = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_down(x, o, 64);
+        if (lane + o < 64) x += y;
+    }
+    int above = x - own;                       // keys in bins above this lane's four
+    const int hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        if (above < rem && rem <= above + hv[j]) {
+            *s_prefix = prefix | ((uint32_t)(4 * lane + j) << shift);
+            *s_remaining = rem - above;
+        }
+        above += hv[j];
+    }
+}
+
+constexpr int kSelCache = 32;   // elements per thread kept in registers by the selection kernels
+
+__device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+#pragma unroll 1
+    for (int it = 0; it < 4 && todo != 0; ++it) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const uint32_t lb = __builtin_amdgcn_readlane(bin, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(active && bin == lb) & todo;
+        if (lane == leader) atomicAdd(&hist[lb], (int)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
+}
+
 // -------------------------------------------------------------------------------------------------
 // S7  indices = sortperm(scores, rev=true) ; first k     (searching.jl:125-127)
 // The sort is stable, so ties keep ascending candidate order = ascending pid.  One workgroup per
@@ -743,16 +789,51 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
                                                     float* __restrict__ out_scores,
                                                     int* __restrict__ short_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // kpow2 entries
-    __shared__ int hist[256];
+    __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[32];
     __shared__ uint32_t s_prefix;
-    __shared__ int s_remaining, s_run_sel, s_run_eq;
+    __shared__ int s_remaining;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = list ? nlist[b] : ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
     const int keff = n < k ? n : k;
     if (tid == 0 && n < k) short_flag[b] = 1;
+
+    // Thread t owns the contiguous elements [t*chunk, (t+1)*chunk) of the (listed) candidates; up to kSelCache of
+    // them stay in registers as (order key, slot) for the four radix passes and the compaction, so the scores are
+    // read from memory once.  Larger inputs (single-pass mode on a big shard) re-read them in every pass.
+    const int chunk = (n + 1023) >> 10;
+    const int i0 = tid * chunk;
+    const bool cached = chunk <= kSelCache;   // uniform over the block
+    uint32_t ckey[kSelCache];
+    int cslot[kSelCache];
+    if (cached) {
+#pragma unroll
+        for (int c = 0; c < kSelCache; ++c) {
+            const int i = i0 + c;
+            const bool valid = c < chunk && i < n;
+            cslot[c] = valid ? (lst ? lst[i] : i) : 0;
+            ckey[c] = valid ? f32_order_key(sc[cslot[c]]) : 0u;
+        }
+    }
+#define CLB_SEL_FOR_EACH(...)                                                                   \
+    if (cached) {                                                                               \
+        _Pragma("unroll") for (int c = 0; c < kSelCache; ++c) {                                 \
+            if (c >= chunk) break;                                                              \
+            const bool valid = i0 + c < n;                                                      \
+            const int slot = cslot[c];                                                          \
+            const uint32_t key = ckey[c];                                                       \
+            __VA_ARGS__                                                                         \
+        }                                                                                       \
+    } else {                                                                                    \
+        for (int c = 0; c < chunk; ++c) {                                                       \
+            const bool valid = i0 + c < n;                                                      \
+            const int slot = valid ? (lst ? lst[i0 + c] : i0 + c) : 0;                          \
+            const uint32_t key = valid ? f32_order_key(sc[slot]) : 0u;                          \
+            __VA_ARGS__                                                                         \
+        }                                                                                       \
+    }
 
     // ---- radix select: tau = keff-th largest key -------------------------------------------------
     if (tid == 0) { s_prefix = 0u; s_remaining = keff; }
@@ -764,78 +845,54 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
             __syncthreads();
             const uint32_t prefix = s_prefix;
             const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int i = tid; i < n; i += 1024) {
-                const uint32_t key = f32_order_key(sc[lst ? lst[i] : i]);
-                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
-            }
+            CLB_SEL_FOR_EACH((void)slot; hist_add_aggregated(hist, (key >> shift) & 255, valid && (key & himask) == prefix);)
             __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining, d = 255;
-                for (; d > 0; --d) {
-                    if (hist[d] >= rem) break;
-                    rem -= hist[d];
-                }
-                s_prefix = prefix | ((uint32_t)d << shift);
-                s_remaining = rem;
-            }
+            if (tid < 64) radix_pick(hist, s_remaining, prefix, shift, &s_prefix, &s_remaining);
             __syncthreads();
         }
     }
     const uint32_t tau = s_prefix;
     const int need_eq = s_remaining;  // how many of the == tau entries to take, lowest index first
 
-    // ---- ordered compaction ---------------------------------------------------------------------
+    // ---- ordered compaction: one block-wide scan of the per-thread (#gt, #eq) counts ---------------
     for (int i = tid; i < kpow2; i += 1024) skeys[i] = 0ull;
-    if (tid == 0) { s_run_sel = 0; s_run_eq = 0; }
     __syncthreads();
     if (keff > 0) {
-        for (int base = 0; base < n; base += 1024) {
-            const int i = base + tid;
-            uint32_t key = 0;
-            int slot = 0;
-            bool gt = false, eq = false;
-            if (i < n) {
-                slot = lst ? lst[i] : i;
-                key = f32_order_key(sc[slot]);
-                gt = key > tau;
-                eq = key == tau;
-            }
-            // packed scan: low 16 bits = eq count, high 16 bits = gt count
-            int v = (gt ? (1 << 16) : 0) | (eq ? 1 : 0);
-            const int lane = tid & 63, wave = tid >> 6;
-            int x = v;
+        int ngt = 0, neq = 0;
+        CLB_SEL_FOR_EACH((void)slot; ngt += valid && key > tau; neq += valid && key == tau;)
+        const int lane = tid & 63, wave = tid >> 6;
+        int xg = ngt, xe = neq;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int y = __shfl_up(x, o, 64);
-                if (lane >= o) x += y;
-            }
-            if (lane == 63) sh_scan[wave] = x;
-            __syncthreads();
-            int wbase = 0, tot = 0;
-            for (int w2 = 0; w2 < 16; ++w2) {
-                const int s = sh_scan[w2];
-                if (w2 < wave) wbase += s;
-                tot += s;
-            }
-            const int ex = wbase + x - v;
-            const int eq_rank = s_run_eq + (ex & 0xffff);
-            const int gt_before = s_run_sel + (ex >> 16);
-            // position = (#gt before) + (#eq taken before) ; eq taken before = min(eq_rank, need_eq)
-            const bool take = gt || (eq && eq_rank < need_eq);
-            if (take) {
-                const int pos = gt_before + (eq_rank < need_eq ? eq_rank : need_eq);
-                // slot ascends with i, so ~slot makes lower index = larger key on equal scores
-                skeys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
-            }
-            __syncthreads();
-            if (tid == 0) { s_run_sel += tot >> 16; s_run_eq += tot & 0xffff; }
-            __syncthreads();
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yg = __shfl_up(xg, o, 64), ye = __shfl_up(xe, o, 64);
+            if (lane >= o) { xg += yg; xe += ye; }
         }
+        if (lane == 63) { sh_scan[wave] = xg; sh_scan[16 + wave] = xe; }
+        __syncthreads();
+        int gt_before = xg - ngt, eq_rank = xe - neq;
+        for (int w2 = 0; w2 < wave; ++w2) { gt_before += sh_scan[w2]; eq_rank += sh_scan[16 + w2]; }
+        CLB_SEL_FOR_EACH(
+            if (valid) {
+                const bool gt = key > tau, eq = key == tau;
+                // position = (#gt before) + (#eq taken before) ; eq taken before = min(eq_rank, need_eq)
+                if (gt || (eq && eq_rank < need_eq)) {
+                    const int pos = gt_before + (eq_rank < need_eq ? eq_rank : need_eq);
+                    // slot ascends with i, so ~slot makes lower index = larger key on equal scores
+                    skeys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
+                }
+                gt_before += gt;
+                eq_rank += eq;
+            })
     }
+#undef CLB_SEL_FOR_EACH
     // ---- bitonic sort, descending -----------------------------------------------------------------
+    // pair i of a step touches elements inside the 128-aligned tile of its wave whenever stride <= 64, so only the
+    // wide strides need the block barrier (6 of the 55 steps at k = 1000)
+    __syncthreads();   // the compaction above wrote skeys from arbitrary threads
     for (int size = 2; size <= kpow2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (stride >= 64 || (kpow2 >> 1) > 1024) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
             for (int i = tid; i < (kpow2 >> 1); i += 1024) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
