@@ -134,10 +134,24 @@ static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* 
     lo[i] = (uint16_t)f32_to_bf16_rne(rem);
 }
 
+// Insert into a lane's descending list of approximate scores.  Ordering is by value only: which of several EQUAL
+// approximate scores survives at the end of a list is irrelevant, because top_refine_kernel re-scores everything above
+// its cut and treats a list whose last entry reaches the cut as overflowed.  Branch-free shift (3 compares, 14
+// selects) behind a wave-level reject.
 template <int NP>
 __device__ __forceinline__ void topn_insert_lazy(float (&bv)[NP], int (&bi)[NP], float v, int idx) {
-    // wave-level fast reject: after the first few tiles almost no value beats a lane's NP-th best
-    if (__builtin_amdgcn_ballot_w64(v > bv[NP - 1]) != 0) topn_insert<NP>(bv, bi, v, idx);
+    if (__builtin_amdgcn_ballot_w64(v > bv[NP - 1]) == 0) return;
+    const bool in = v > bv[NP - 1];
+#pragma unroll
+    for (int p = NP - 1; p > 0; --p) {
+        const bool above = v > bv[p - 1];              // v belongs above slot p: slot p takes its upper neighbour
+        const float nv = above ? bv[p - 1] : v;
+        const int ni = above ? bi[p - 1] : idx;
+        const bool touch = in && v > bv[p];            // slots below v's position are unchanged
+        bv[p] = touch ? nv : bv[p];
+        bi[p] = touch ? ni : bi[p];
+    }
+    if (in && v > bv[0]) { bv[0] = v; bi[0] = idx; }
 }
 
 // grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * 2 arrays * 32 rows * 272 B.

@@ -68,7 +68,7 @@ static __global__ __launch_bounds__(256) void decompress_dim128_kernel(const flo
                                                                const uint8_t* __restrict__ residuals,
                                                                int64_t n, float* __restrict__ out) {
     constexpr int RD = NBITS * 4;
-    __shared__ float tbl[(8 / NBITS) * kWTblStride];
+    __shared__ float tbl[weight_table_floats<NBITS>()];
     fill_weight_table<NBITS>(tbl, weights);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;

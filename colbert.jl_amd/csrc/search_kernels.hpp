@@ -473,16 +473,14 @@ __device__ __forceinline__ float div_by_reciprocal(float x, float den, float y) 
     return fmaf(r, y, q0);
 }
 
-// Bucket-weight table in LDS, one copy per position of a field inside its byte: tbl[v][byte] =
-// w[(byte >> (NBITS*v)) & mask].  Row stride 264 floats staggers the copies over the banks.
-constexpr int kWTblStride = 264;
+// Bucket-weight table in LDS, replicated over the 32 banks: tbl[idx][bank] = weights[idx].  Lane L reads
+// tbl[idx][L & 31], so the data-dependent lookups of a wave never collide on a bank (a [field][byte] table indexed
+// by the packed byte cost ~5 LDS cycles per read in conflicts).
+template <int NBITS>
+constexpr int weight_table_floats() { return (1 << NBITS) * 32; }
 template <int NBITS>
 __device__ __forceinline__ void fill_weight_table(float* tbl, const float* __restrict__ weights) {
-    constexpr int V = 8 / NBITS;
-    for (int i = threadIdx.x; i < V * 256; i += blockDim.x) {
-        const int v = i >> 8, byte = i & 255;
-        tbl[v * kWTblStride + byte] = weights[(byte >> (NBITS * v)) & ((1 << NBITS) - 1)];
-    }
+    for (int i = threadIdx.x; i < weight_table_floats<NBITS>(); i += blockDim.x) tbl[i] = weights[i >> 5];
 }
 
 // Decompresses the 32 dims {4s+g} of one embedding (canonical order, see decompress_lane_dims) using the LDS
@@ -495,23 +493,14 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
                                                           const float* __restrict__ tbl, float (&x)[32],
                                                           const float* ctile = nullptr, int r = 0) {
     float p = 0.f;
+    const float* tbl_lane = tbl + (threadIdx.x & 31);
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        // dim d = 4s+g starts at bit d*NBITS: byte (4s*NBITS)/8 (+ g*NBITS/8), field v inside the byte
-        int byte_idx, v;
-        if constexpr (NBITS == 2) { byte_idx = s; v = g; }
-        else if constexpr (NBITS == 1) { byte_idx = s >> 1; v = 4 * (s & 1) + g; }
-        else { byte_idx = 2 * s + (g >> 1); v = g & 1; }
-        uint32_t byte;
-        if constexpr (NBITS == 4) {
-            const uint32_t w0 = R[(2 * s) >> 2], sh0 = ((2 * s) & 3) * 8;       // byte 2s and 2s+1 share a dword
-            byte = (w0 >> (sh0 + 8 * (g >> 1))) & 255u;
-            (void)byte_idx;
-        } else {
-            byte = (R[byte_idx >> 2] >> ((byte_idx & 3) * 8)) & 255u;
-        }
+        // dim d = 4s+g starts at bit d*NBITS = 4s*NBITS + g*NBITS; a group of four dims never crosses a dword
+        const int bit0 = 4 * s * NBITS;
+        const uint32_t idx = __builtin_amdgcn_ubfe(R[bit0 >> 5], (uint32_t)((bit0 & 31) + g * NBITS), (uint32_t)NBITS);
         const float c = ctile ? ctile[(s * 16 + (r ^ (s & 15))) * 4 + g] : cent_row[4 * s];
-        const float val = c + tbl[v * kWTblStride + byte];
+        const float val = c + tbl_lane[idx * 32];
         x[s] = val;
         const float sq = val * val;
         p = p + sq;
@@ -545,7 +534,7 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
 constexpr int kMaxMaskedRows = 256;
 
 template <int NBITS, bool SUBSET = false>
-static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
+static __global__ __launch_bounds__(256, SUBSET ? 2 : 3) void score_exact_kernel(
     const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
     const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const float* __restrict__ Q,
     const int* __restrict__ ncand, float* __restrict__ scores, int T, size_t cand_cap,
@@ -553,7 +542,7 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const unsigned long long* __restrict__ rowmask = nullptr) {
     constexpr int RD = NBITS * 4;  // residual dwords per embedding
     __shared__ uint16_t rowlists[SUBSET ? 4 * kMaxMaskedRows : 4];
-    __shared__ float tbl[(8 / NBITS) * kWTblStride];
+    __shared__ float tbl[weight_table_floats<NBITS>()];
     __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];    // 16 KB
     __shared__ __attribute__((aligned(16))) float ctiles[4 * 512 * 4];  // 4 waves x 8 KB
     fill_weight_table<NBITS>(tbl, weights);
@@ -691,9 +680,13 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
                 if (base + 16 < len) { CLB_REP8(CLB_ROW_LOAD) }
                 code_next = code_at(base + 32);
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+                // fully unrolled (x[] stays statically indexed) with the query operand read one k-step ahead, so
+                // the LDS latency hides behind the four MFMAs in flight instead of stalling every group
+                float4 qnext = qv[0];
+#pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const float4 q = qv[k * 64];
+                    const float4 q = qnext;
+                    if (k < 15) qnext = qv[(k + 1) * 64];
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.x, a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.y, a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.z, a0, 0, 0, 0);
