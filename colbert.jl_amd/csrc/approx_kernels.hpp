@@ -846,7 +846,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    float* __restrict__ eps_pair) {
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[16];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix, s_kmin, s_kmax;
     __shared__ int s_remaining, s_run;
     __shared__ float s_qn;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -905,17 +905,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         }                                                                                       \
     }
     if (n > k) {
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const uint32_t prefix = s_prefix;
-            const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            CLB_SEL_FOR_EACH((void)i; hist_add_aggregated(hist, (key >> shift) & 255, valid && (key & himask) == prefix);)
-            __syncthreads();
-            if (tid < 64) radix_pick(hist, s_remaining, prefix, shift, &s_prefix, &s_remaining);
-            __syncthreads();
-        }
+        CLB_RADIX_SELECT()
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;

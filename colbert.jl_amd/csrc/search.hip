@@ -189,14 +189,18 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         // batches of 8+ queries share each staged centroid tile between 8 queries (centroid_top_bf16x3_mq_kernel)
         const bool mq = s->s1_mode == 1 && s->cent_hi.p && B >= kMqQueries;
         const int groups = (B + kMqQueries - 1) / kMqQueries;
-        const int gx = mq ? std::max(1, std::min(n_tiles, std::min(256, std::max(512 / groups, 16))))
+        int gx = mq ? std::max(1, std::min(n_tiles, std::min(256, std::max(512 / groups, 16))))
                           : std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
+        static const int gx_dbg = getenv("CLB_DEBUG_S1_GX") ? atoi(getenv("CLB_DEBUG_S1_GX")) : 0;
+        if (gx_dbg > 0 && !mq) gx = std::min(gx_dbg, n_tiles / 2 + 1);
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
         if (s->s1_mode == 1 && s->cent_hi.p) {
-            CLB_TRY(w.redo.ensure(sizeof(int) * B));
-            CLB_HIP(hipMemsetAsync(w.redo.p, 0, sizeof(int) * B, st));
+            if (w.redo.bytes < sizeof(int) * B) {          // cumulative fallback counter (statistics only)
+                CLB_TRY(w.redo.ensure(sizeof(int) * B));
+                CLB_HIP(hipMemsetAsync(w.redo.p, 0, w.redo.bytes, st));
+            }
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
@@ -292,10 +296,9 @@ int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int
 
 // The whole search for B device-resident queries, enqueued on st.
 int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
-               int64_t* d_out_pids, float* d_out_scores) {
+               int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr) {
     CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
     const int kpow2 = next_pow2(k);
-    CLB_HIP(hipMemsetAsync(w.flags.p, 0, sizeof(int) * B, st));
     if (s->prof.on) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
     const int* list = nullptr;
     const int* nlist = nullptr;
@@ -360,7 +363,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         Timed t(s, KID_TOPK, st);
         hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
                            w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
-                           kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>());
+                           kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
     }
     if (s->prof.on) {
         hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, w.cand.as<uint32_t>(),
@@ -526,11 +529,7 @@ int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_
     hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
     Workspace& w = s->ws[0];
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
-    CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores));
-    if (d_n_cand)
-        hipLaunchKernelGGL(widen_counts_kernel, dim3((int)((B + 255) / 256)), dim3(256), 0, st, w.ncand.as<int>(),
-                           d_n_cand, (int)B);
-    CLB_HIP(hipGetLastError());
+    CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores, d_n_cand));
     return CLB_OK;
 }
 

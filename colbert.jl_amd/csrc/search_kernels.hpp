@@ -758,11 +758,60 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         const uint32_t lb = __builtin_amdgcn_readlane(bin, leader);
         const unsigned long long same = __builtin_amdgcn_ballot_w64(active && bin == lb) & todo;
+        if (__popcll(same) < 8) break;                 // spread-out bins: per-lane atomics are cheaper
         if (lane == leader) atomicAdd(&hist[lb], (int)__popcll(same));
         todo &= ~same;
     }
     if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
 }
+
+// Radix select of the rem-th largest of the block's keys, written with the CLB_SEL_FOR_EACH macro of the calling
+// kernel (which yields `valid` and `key` for every element the thread owns).  The bits on which the smallest and
+// the largest key agree are skipped: MaxSim scores of one query share their exponent and leading mantissa bits, so
+// a fixed MSB-first schedule spends its first passes on histograms with one occupied bin.  The first pass covers
+// the (up to) eight bits below the highest differing bit -- well spread -- and later passes only touch the keys of
+// the selected bin.  Leaves tau in *s_prefix and the rank inside the == tau group in *s_remaining.
+// Needs: __shared__ hist[256] (16-byte aligned), s_prefix, s_remaining (= rem on entry), s_kmin, s_kmax.
+#define CLB_RADIX_SELECT()                                                                                  \
+    {                                                                                                       \
+        uint32_t kmin_ = 0xffffffffu, kmax_ = 0u;                                                           \
+        CLB_SEL_FOR_EACH(if (valid) { kmin_ = key < kmin_ ? key : kmin_; kmax_ = key > kmax_ ? key : kmax_; }) \
+        _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) {                                             \
+            const uint32_t a_ = __shfl_xor(kmin_, o_, 64), b_ = __shfl_xor(kmax_, o_, 64);                  \
+            kmin_ = a_ < kmin_ ? a_ : kmin_;                                                                \
+            kmax_ = b_ > kmax_ ? b_ : kmax_;                                                                \
+        }                                                                                                   \
+        if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0u; }                                                \
+        __syncthreads();                                                                                    \
+        if ((tid & 63) == 0) { atomicMin(&s_kmin, kmin_); atomicMax(&s_kmax, kmax_); }                      \
+        __syncthreads();                                                                                    \
+        const uint32_t diff_ = s_kmin ^ s_kmax;                                                             \
+        if (diff_ == 0u) {                                                                                  \
+            if (tid == 0) s_prefix = s_kmax;          /* all keys equal: rank unchanged */                  \
+            __syncthreads();                                                                                \
+        } else {                                                                                            \
+            const int top_ = 31 - __clz((int)diff_);                                                        \
+            int shift_ = top_ > 7 ? top_ - 7 : 0;                                                           \
+            int width_ = top_ - shift_ + 1;                                                                 \
+            if (tid == 0) s_prefix = top_ == 31 ? 0u : (s_kmax & (0xffffffffu << (top_ + 1)));              \
+            for (;;) {                                                                                      \
+                if (tid < 256) hist[tid] = 0;                                                               \
+                __syncthreads();                                                                            \
+                const uint32_t prefix_ = s_prefix;                                                          \
+                const uint32_t himask_ = shift_ + width_ >= 32 ? 0u : (0xffffffffu << (shift_ + width_));   \
+                const uint32_t bmask_ = (1u << width_) - 1u;                                                \
+                CLB_SEL_FOR_EACH(hist_add_aggregated(hist, (key >> shift_) & bmask_,                        \
+                                                     valid && (key & himask_) == prefix_);)                 \
+                __syncthreads();                                                                            \
+                if (tid < 64) radix_pick(hist, s_remaining, prefix_, shift_, &s_prefix, &s_remaining);      \
+                __syncthreads();                                                                            \
+                if (shift_ == 0) break;                                                                     \
+                const int ns_ = shift_ > 8 ? shift_ - 8 : 0;                                                \
+                width_ = shift_ - ns_;                                                                      \
+                shift_ = ns_;                                                                               \
+            }                                                                                               \
+        }                                                                                                   \
+    }
 
 // -------------------------------------------------------------------------------------------------
 // S7  indices = sortperm(scores, rev=true) ; first k     (searching.jl:125-127)
@@ -780,18 +829,22 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
                                                     size_t cand_cap, int64_t pid_offset,
                                                     int64_t* __restrict__ out_pids,
                                                     float* __restrict__ out_scores,
-                                                    int* __restrict__ short_flag) {
+                                                    int* __restrict__ short_flag,
+                                                    int64_t* __restrict__ n_cand_out /*optional*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // kpow2 entries
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[32];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix, s_kmin, s_kmax;
     __shared__ int s_remaining;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = list ? nlist[b] : ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
     const int keff = n < k ? n : k;
-    if (tid == 0 && n < k) short_flag[b] = 1;
+    if (tid == 0) {
+        short_flag[b] = n < k ? 1 : 0;
+        if (n_cand_out) n_cand_out[b] = ncand[b];
+    }
 
     // Thread t owns the contiguous elements [t*chunk, (t+1)*chunk) of the (listed) candidates; up to kSelCache of
     // them stay in registers as (order key, slot) for the four radix passes and the compaction, so the scores are
@@ -831,19 +884,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     // ---- radix select: tau = keff-th largest key -------------------------------------------------
     if (tid == 0) { s_prefix = 0u; s_remaining = keff; }
     __syncthreads();
-    if (keff > 0) {
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const uint32_t prefix = s_prefix;
-            const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            CLB_SEL_FOR_EACH((void)slot; hist_add_aggregated(hist, (key >> shift) & 255, valid && (key & himask) == prefix);)
-            __syncthreads();
-            if (tid < 64) radix_pick(hist, s_remaining, prefix, shift, &s_prefix, &s_remaining);
-            __syncthreads();
-        }
-    }
+    if (keff > 0) CLB_RADIX_SELECT()
     const uint32_t tau = s_prefix;
     const int need_eq = s_remaining;  // how many of the == tau entries to take, lowest index first
 
@@ -935,11 +976,6 @@ static __global__ void codes_to_zero_based_kernel(uint32_t* __restrict__ codes, 
     if (i >= n) return;
     const uint32_t c = codes[i];
     if (c < 1u || c > K) { atomicOr(err, 2); codes[i] = 0; } else codes[i] = c - 1u;
-}
-
-static __global__ void widen_counts_kernel(const int* __restrict__ in, int64_t* __restrict__ out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
 }
 
 // work counters of one batch: [0] candidate passages, [1] candidate embeddings, [2] passages in the
