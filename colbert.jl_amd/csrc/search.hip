@@ -28,7 +28,8 @@ const char* kKernelNames[KID_COUNT] = {"centroid_scores", "top_nprobe", "mark_ca
                                        "topk"};
 
 struct Prof {
-    bool on = false;
+    bool on = false;        // HIP-event timing of every kernel
+    bool counters = false;  // additionally count the work of each batch (one extra kernel per batch)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KID_COUNT];
     std::vector<hipEvent_t> pool;
     double total_ms[KID_COUNT] = {0};
@@ -299,7 +300,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr) {
     CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
     const int kpow2 = next_pow2(k);
-    if (s->prof.on) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
+    if (s->prof.counters) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
     const int* list = nullptr;
     const int* nlist = nullptr;
     if (s->mode == 1 && s->approx_ok && T <= 32) {
@@ -365,7 +366,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                            w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
                            kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
     }
-    if (s->prof.on) {
+    if (s->prof.counters) {
         hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, w.cand.as<uint32_t>(),
                            w.ncand.as<int>(), list, nlist, s->doc_off.as<uint32_t>(), w.cand_cap,
                            w.stats.as<unsigned long long>(),
@@ -646,6 +647,7 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
 int clb_profile_enable(clb_searcher* s, int on) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
     s->prof.on = on != 0;
+    s->prof.counters = on >= 2;
     return CLB_OK;
 }
 

@@ -128,8 +128,10 @@ class Searcher:
         return self.search_embeddings(Q[:, :, 0], k)
 
     # -- profiling (bench.py) -----------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        check(lib().clb_profile_enable(self._h, C.c_int(1 if on else 0)))
+    def profile_enable(self, on: bool = True, counters: bool = False):
+        """Per-kernel HIP-event timing; `counters` additionally fills `last_batch_stats` (one extra kernel per
+        batch -- not for timed regions)."""
+        check(lib().clb_profile_enable(self._h, C.c_int((2 if counters else 1) if on else 0)))
 
     def profile_read(self) -> dict:
         cap = 16

@@ -106,6 +106,8 @@ int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scor
 /* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's roofline).
  * enable, run searches, then read: names[i] (static strings), total milliseconds and launch counts.
  * Returns the number of entries written (<= cap). */
+/* on = 0: off; 1: event timing only; 2: timing + the work counters read by clb_last_batch_stats (one extra
+ * kernel per batch, so keep it out of timed regions). */
 int clb_profile_enable(clb_searcher* s, int on);
 int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int64_t* launches, int cap);
 /* per-kernel work counters of the last batch: candidate passages / candidate embeddings summed over
