@@ -672,10 +672,16 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
             CV = u32x4{(e0 + lane_row) & 131071u, (e0 * 7u + lane_row) & 131071u, (e0 * 13u) & 131071u, (e0 * 29u) & 131071u}; \
             IV = f32x4{1.f, 1.f, 1.f, 1.f};                                                                 \
         } else {                                                                                            \
-        /* plain loads: non-temporal hints on these once-read streams were measured 7 % slower */          \
-        RB = *reinterpret_cast<const uint2*>(residuals + (size_t)e0 * 32 + lane_res);                       \
-        CV = *reinterpret_cast<const u32x4_a4*>(codes0 + (size_t)e0 + lane_row);                            \
-        IV = *reinterpret_cast<const f32x4_a4*>(inv_norm + (size_t)e0 + lane_row);                          \
+        /* plain loads: non-temporal hints on these once-read streams were measured 7 % slower.         */ \
+        /* Rows past the end of the passage (tail step) are discarded later; their lanes re-read row 0 of */ \
+        /* the step instead of fetching the unrelated bytes behind the passage -- and, through the codes,  */ \
+        /* unrelated score rows: ~15 % of the kernel's traffic at 82 embeddings per passage.              */ \
+        const int left_ = it_len - it_base;                                                                 \
+        const uint32_t res_off = (live && r >= left_) ? (uint32_t)(8 * g) : lane_res;                       \
+        const uint32_t row_off = (live && 4 * g >= left_) ? 0u : lane_row;                                  \
+        RB = *reinterpret_cast<const uint2*>(residuals + (size_t)e0 * 32 + res_off);                        \
+        CV = *reinterpret_cast<const u32x4_a4*>(codes0 + (size_t)e0 + row_off);                             \
+        IV = *reinterpret_cast<const f32x4_a4*>(inv_norm + (size_t)e0 + row_off);                           \
         }                                                                                                   \
         const int left = it_len - it_base;                                                                  \
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \

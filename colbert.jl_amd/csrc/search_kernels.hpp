@@ -721,6 +721,223 @@ static __global__ __launch_bounds__(256, SUBSET ? 2 : 3) void score_exact_kernel
 // hist[bin] += 1 for every active lane.  MaxSim scores of one query share their exponent and leading mantissa bits,
 // so in the first radix passes a whole wave hits one or two bins and per-lane LDS atomics serialise 64 deep; lanes
 // sharing a bin are therefore merged into one atomic (up to four distinct bins per call, plain atomics after that).
+// -------------------------------------------------------------------------------------------------
+// Pass 2 of the two-pass mode as a flat step pipeline (nbits 2, T <= 32).  Same arithmetic per step as
+// score_exact_kernel<2, true>; what changes is the control structure.  With the row subset a listed passage is
+// only ~2.4 steps of 16 rows, so a per-passage loop spends most of its time in the start-up chain of dependent
+// loads (list -> header -> codes -> centroid rows).  Here each wave walks a wave-uniform iterator over the steps
+// of ITS passages (headers and row masks of 64 passages at a time sit in VGPRs and are extracted with v_readlane,
+// as in score_approx_kernel) and keeps three steps in flight across passage boundaries:
+//   stage A (step i+2): row index of lane r = the (base + r)-th set bit of the passage's 256-bit mask (a
+//                       branch-free popcount search), then its code and 32-B residual are requested;
+//   stage G (step i+1): the 16 centroid rows are requested as whole 512-B rows;
+//   stage C (step i)  : rows -> swizzled LDS tile, decompress, 64 fp32 MFMAs, running per-token max; at the last
+//                       step of a passage reduce, sum the tokens in order, store the score.
+// Steps past the end of the wave's work read a dummy address and are discarded.
+// grid = (G, B), block = 256; the waves of a query's work-groups take its listed passages round-robin.
+// -------------------------------------------------------------------------------------------------
+struct ExactStepTag {
+    int slot;   // candidate slot to store the score to, -1 = dummy step
+    int last;   // 1 = last step of its passage
+};
+
+// the n-th (0-based) set bit of a 256-bit mask held in four wave-uniform 64-bit words; n < popcount(mask)
+__device__ __forceinline__ uint32_t nth_set_bit_256(unsigned long long w0, unsigned long long w1,
+                                                    unsigned long long w2, unsigned long long w3, int n) {
+    const int c0 = __popcll(w0), c1 = c0 + __popcll(w1), c2 = c1 + __popcll(w2);
+    unsigned long long w = w0;
+    int add = 0, loc = n;
+    if (n >= c0) { w = w1; add = 64; loc = n - c0; }
+    if (n >= c1) { w = w2; add = 128; loc = n - c1; }
+    if (n >= c2) { w = w3; add = 192; loc = n - c2; }
+    uint32_t x = (uint32_t)w;
+    const int cl = __popc(x);
+    if (loc >= cl) { x = (uint32_t)(w >> 32); add += 32; loc -= cl; }
+#pragma unroll
+    for (int width = 16; width >= 1; width >>= 1) {
+        const int t = __popc(x & ((1u << width) - 1u));
+        if (loc >= t) { x >>= width; add += width; loc -= t; }
+    }
+    return (uint32_t)add;
+}
+
+static __global__ __launch_bounds__(256, 3) void score_exact_flat_kernel(
+    const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
+    const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const float* __restrict__ Q,
+    float* __restrict__ scores, int T, size_t cand_cap, const int* __restrict__ list,
+    const int* __restrict__ nlist, const unsigned long long* __restrict__ rowmask) {
+    constexpr int NBITS = 2;
+    __shared__ float tbl[weight_table_floats<NBITS>()];
+    __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];    // 16 KB
+    __shared__ __attribute__((aligned(16))) float ctiles[4 * 512 * 4];  // 4 waves x 8 KB
+    fill_weight_table<NBITS>(tbl, weights);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* ctile = ctiles + wave * 2048;
+    const int c4 = lane & 31, rhalf = lane >> 5;    // row loader: instruction m moves chunk c4 of row 2m + rhalf
+    const float4* qv = reinterpret_cast<const float4*>(qlds) + lane;
+
+#define CLB_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define CLB_ROW_DECL(m) float4 rowA##m;
+#define CLB_ROW_LOAD(P, CODE, m)                                                                               \
+    {                                                                                                          \
+        const uint32_t ca = __builtin_amdgcn_readlane(CODE, 2 * m), cb = __builtin_amdgcn_readlane(CODE, 2 * m + 1); \
+        row##P##m = *reinterpret_cast<const float4*>(C + (size_t)(rhalf ? cb : ca) * kDim + 4 * c4);           \
+    }
+#define CLB_ROW_LOAD8(P, CODE)                                                                                 \
+    CLB_ROW_LOAD(P, CODE, 0) CLB_ROW_LOAD(P, CODE, 1) CLB_ROW_LOAD(P, CODE, 2) CLB_ROW_LOAD(P, CODE, 3)        \
+    CLB_ROW_LOAD(P, CODE, 4) CLB_ROW_LOAD(P, CODE, 5) CLB_ROW_LOAD(P, CODE, 6) CLB_ROW_LOAD(P, CODE, 7)
+#define CLB_ROW_STORE(P, m)                                                                                    \
+    *reinterpret_cast<float4*>(ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4) = row##P##m;
+#define CLB_ROW_STORE8(P)                                                                                      \
+    CLB_ROW_STORE(P, 0) CLB_ROW_STORE(P, 1) CLB_ROW_STORE(P, 2) CLB_ROW_STORE(P, 3)                            \
+    CLB_ROW_STORE(P, 4) CLB_ROW_STORE(P, 5) CLB_ROW_STORE(P, 6) CLB_ROW_STORE(P, 7)
+
+    {
+        const int b = blockIdx.y;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {     // query operand, see score_exact_kernel
+            const int k = i >> 6, l = i & 63;
+            const int rr = l & 15, gg = l >> 4;
+            const int t0 = rr, t1 = rr + 16;
+            const float* qa = Q + ((size_t)b * T + (t0 < T ? t0 : T - 1)) * kDim + gg;
+            const float* qb = Q + ((size_t)b * T + (t1 < T ? t1 : T - 1)) * kDim + gg;
+            float4 v;
+            v.x = t0 < T ? qa[8 * k] : 0.f;
+            v.y = t1 < T ? qb[8 * k] : 0.f;
+            v.z = t0 < T ? qa[8 * k + 4] : 0.f;
+            v.w = t1 < T ? qb[8 * k + 4] : 0.f;
+            *reinterpret_cast<float4*>(qlds + (size_t)i * 4) = v;
+        }
+        __syncthreads();
+        const int n = nlist[b];
+        const int* lst = list + (size_t)b * cand_cap;
+        const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
+        const unsigned long long* mw = rowmask + (size_t)b * cand_cap * 4;
+        float* out = scores + (size_t)b * cand_cap;
+        const int stride = gridDim.x * 4;
+
+        for (int j0 = blockIdx.x * 4 + wave; j0 < n; j0 += 64 * stride) {
+            // lane k of the wave holds the description of the wave's k-th passage of this batch
+            const int jl = j0 + lane * stride;
+            const int jj = jl < n ? jl : j0;
+            const int slot_l = lst[jj];
+            const uint2 hv = hdr[slot_l];
+            const unsigned long long mk0 = mw[(size_t)jj * 4], mk1 = mw[(size_t)jj * 4 + 1],
+                                     mk2 = mw[(size_t)jj * 4 + 2], mk3 = mw[(size_t)jj * 4 + 3];
+            const bool ident_l = (int)hv.y > kMaxMaskedRows;      // too long for the mask: every row
+            // rows to multiply; bit 31 flags the identity mapping
+            const uint32_t nj_l = ident_l ? (hv.y | 0x80000000u)
+                                          : (uint32_t)(__popcll(mk0) + __popcll(mk1) + __popcll(mk2) + __popcll(mk3));
+            const int nd = (n - j0 + stride - 1) / stride < 64 ? (n - j0 + stride - 1) / stride : 64;
+            int it_k = 0, it_base = 0;
+            uint32_t it_off, it_nj;
+            int it_slot;
+            unsigned long long it_m0, it_m1, it_m2, it_m3;
+#define CLB_IT_LOAD(KK)                                                                                        \
+    {                                                                                                          \
+        it_off = __builtin_amdgcn_readlane(hv.x, KK);                                                          \
+        it_nj = __builtin_amdgcn_readlane(nj_l, KK);                                                           \
+        it_slot = __builtin_amdgcn_readlane(slot_l, KK);                                                       \
+        it_m0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk0 >> 32), KK) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk0, KK); \
+        it_m1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk1 >> 32), KK) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk1, KK); \
+        it_m2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk2 >> 32), KK) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk2, KK); \
+        it_m3 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk3 >> 32), KK) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk3, KK); \
+    }
+            CLB_IT_LOAD(0)
+
+            // stage A: describe the next step, request the code and residual of this lane's row
+#define CLB_XSTAGE_A(CODE, R0, R1, TAG)                                                                        \
+    {                                                                                                          \
+        const bool live = it_k < nd;                                                                           \
+        const int nj = (int)(it_nj & 0x7fffffffu);                                                             \
+        const int idx = it_base + r < nj ? it_base + r : nj - 1;                                               \
+        const uint32_t row = (it_nj & 0x80000000u) ? (uint32_t)idx : nth_set_bit_256(it_m0, it_m1, it_m2, it_m3, idx); \
+        const uint32_t e = live ? it_off + row : 0u;                                                           \
+        CODE = codes0[e];                                                                                      \
+        const uint4* rp = reinterpret_cast<const uint4*>(residuals + (size_t)e * 32);                          \
+        R0 = rp[0];                                                                                            \
+        R1 = rp[1];                                                                                            \
+        TAG.slot = live ? it_slot : -1;                                                                        \
+        TAG.last = it_base + 16 >= nj;                                                                         \
+        it_base += 16;                                                                                         \
+        if (TAG.last) {                                                                                        \
+            it_k += 1;                                                                                         \
+            const int kk = it_k < 64 ? it_k : 63;                                                              \
+            CLB_IT_LOAD(kk)                                                                                    \
+            it_base = 0;                                                                                       \
+        }                                                                                                      \
+    }
+            // stage C: rows (requested one step ago) -> LDS, decompress, request the next step's rows into the
+            // registers just freed, MFMAs
+#define CLB_XSTAGE_C(P, R0, R1, TAG, CODE_NEXT2)                                                               \
+    {                                                                                                          \
+        CLB_ROW_STORE8(P)                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        const uint32_t R[8] = {R0.x, R0.y, R0.z, R0.w, R1.x, R1.y, R1.z, R1.w};                                \
+        float x[32];                                                                                           \
+        decompress_lane_dims_fast<NBITS>(nullptr, R, g, tbl, x, ctile, r);                                     \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        CLB_ROW_LOAD8(P, CODE_NEXT2)                                                                           \
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};                                            \
+        float4 qnext = qv[0];                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                       \
+            const float4 q = qnext;                                                                            \
+            if (k < 15) qnext = qv[(k + 1) * 64];                                                              \
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.x, a0, 0, 0, 0);                             \
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k], q.y, a1, 0, 0, 0);                             \
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.z, a0, 0, 0, 0);                         \
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.w, a1, 0, 0, 0);                         \
+        }                                                                                                      \
+        /* rows past the selection are copies of its last row: they cannot change a max */                    \
+        m0 = fmaxf(fmaxf(m0, fmaxf(a0[0], a0[1])), fmaxf(a0[2], a0[3]));                                       \
+        m1 = fmaxf(fmaxf(m1, fmaxf(a1[0], a1[1])), fmaxf(a1[2], a1[3]));                                       \
+        if (TAG.last) {                                                                                        \
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));                                                            \
+            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));                                                            \
+            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));                                                            \
+            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));                                                            \
+            float total = 0.f;           /* sequential sum over tokens (ranking.jl:83) */                     \
+            _Pragma("unroll") for (int t = 0; t < 32; ++t) {                                                   \
+                const float v = __shfl(t < 16 ? m0 : m1, t & 15, 64);                                          \
+                if (t < T) total = total + v;                                                                  \
+            }                                                                                                  \
+            if (lane == 0 && TAG.slot >= 0) out[TAG.slot] = total;                                             \
+            m0 = kNegInf;                                                                                      \
+            m1 = kNegInf;                                                                                      \
+        }                                                                                                      \
+    }
+
+            float m0 = kNegInf, m1 = kNegInf;
+            uint32_t cd0, cd1, cd2;
+            uint4 ra0, rb0, ra1, rb1, ra2, rb2;
+            ExactStepTag t0, t1, t2;
+            CLB_REP8(CLB_ROW_DECL)
+            CLB_XSTAGE_A(cd0, ra0, rb0, t0)
+            CLB_XSTAGE_A(cd1, ra1, rb1, t1)
+            CLB_ROW_LOAD8(A, cd0)
+            while (t0.slot >= 0) {
+                CLB_XSTAGE_A(cd2, ra2, rb2, t2)
+                CLB_XSTAGE_C(A, ra0, rb0, t0, cd1)
+                CLB_XSTAGE_A(cd0, ra0, rb0, t0)
+                CLB_XSTAGE_C(A, ra1, rb1, t1, cd2)
+                CLB_XSTAGE_A(cd1, ra1, rb1, t1)
+                CLB_XSTAGE_C(A, ra2, rb2, t2, cd0)
+            }
+#undef CLB_IT_LOAD
+#undef CLB_XSTAGE_A
+#undef CLB_XSTAGE_C
+        }
+    }
+#undef CLB_REP8
+#undef CLB_ROW_DECL
+#undef CLB_ROW_LOAD
+#undef CLB_ROW_LOAD8
+#undef CLB_ROW_STORE
+#undef CLB_ROW_STORE8
+}
+
 // One radix-select step on a finished 256-bin histogram, by the first wave of the block: the digit d whose bin
 // holds the rem-th largest key (bins above d hold fewer than rem keys, together with bin d at least rem), and the
 // rank that remains inside that bin.  Lane L owns bins 4L..4L+3; a wave-wide suffix sum replaces the serial walk
