@@ -53,7 +53,7 @@ def main():
     import torch
     import colbert_jl_amd as clb
     from colbert_jl_amd import synthetic
-    from colbert_jl_amd.distributed import DeviceSearch, all_gather_topk, merge_gathered
+    from colbert_jl_amd.distributed import DeviceSearch, all_gather_packed, merge_packed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,19 +87,35 @@ def main():
     n_queries = max(B * 8, 256)
     Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=n_queries, T=T)   # (dim, T, nq)
     Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).to(dev)               # (nq, T, dim)
-    run = DeviceSearch(s, T, B, k, args.nprobe)
-    merged_p = torch.empty((B, k), dtype=torch.int64, device=dev)
-    merged_s = torch.empty((B, k), dtype=torch.float32, device=dev)
-
     gather = world > 1 or args.force_gather
+    # Two result buffers alternate so that the exchange of batch i (one RCCL all-gather of the packed per-shard
+    # top-k + the merge kernel, on a side stream) overlaps the search of batch i+1 on the main stream.
+    runs = [DeviceSearch(s, T, B, k, args.nprobe) for _ in range(2)]
+    run = runs[0]
+    merged = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev))
+              for _ in range(2)]
+    comm = torch.cuda.Stream(device=dev) if gather else None
+    free_ev = [None, None]          # buffer set i may be overwritten once its exchange has finished
 
     def step(i):
         off = (i * B) % (n_queries - B + 1)
-        p, sc = run(Qdev[off:off + B])
-        if gather:
-            gp, gs = all_gather_topk(p, sc)
-            return merge_gathered(gp, gs, k, out_p=merged_p, out_s=merged_s)
-        return p, sc
+        r = runs[i & 1]
+        if not gather:
+            return r(Qdev[off:off + B])
+        main = torch.cuda.current_stream(dev)
+        if free_ev[i & 1] is not None:
+            main.wait_event(free_ev[i & 1])
+        r(Qdev[off:off + B])
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(done)
+            g = all_gather_packed(r.packed)
+            out = merge_packed(g, B, k, out_p=merged[i & 1][0], out_s=merged[i & 1][1])
+            ev = torch.cuda.Event()
+            ev.record(comm)
+            free_ev[i & 1] = ev
+        return out
 
     def barrier():
         torch.cuda.synchronize()
@@ -138,8 +154,7 @@ def main():
         t1 = time.perf_counter()
         p, sc = one(Qdev[i:i + 1])
         if gather:
-            gp, gs = all_gather_topk(p, sc)
-            merge_gathered(gp, gs, k)
+            merge_packed(all_gather_packed(one.packed), 1, k)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     p50_ms = float(np.median(lat[5:]) * 1e3) if lat else None

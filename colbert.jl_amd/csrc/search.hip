@@ -594,17 +594,37 @@ int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int
     return CLB_OK;
 }
 
-int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scores, int64_t k, int64_t n_lists,
-                          int64_t B, int64_t* d_out_pids, float* d_out_scores, void* hip_stream) {
+static int merge_topk_launch(int device, const int64_t* d_pids, const float* d_scores, int64_t k, int64_t n_lists,
+                             int64_t B, size_t pid_stride, size_t score_stride, int64_t* d_out_pids,
+                             float* d_out_scores, void* hip_stream) {
     if (k < 1 || n_lists < 1 || B < 1) return fail(CLB_EARGUMENT, "k, n_lists and B must be >= 1");
     CLB_TRY(use_device(device));
     hipStream_t st = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)((B * k + 255) / 256)), dim3(256), 0, st, d_out_pids,
                        d_out_scores, B * k);
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((n_lists * k + 255) / 256), (unsigned)B), dim3(256), 0, st,
-                       d_pids, d_scores, (int)k, (int)n_lists, (int)B, d_out_pids, d_out_scores);
+                       d_pids, d_scores, (int)k, (int)n_lists, (int)B, pid_stride, score_stride, d_out_pids,
+                       d_out_scores);
     CLB_HIP(hipGetLastError());
     return CLB_OK;
+}
+
+int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scores, int64_t k, int64_t n_lists,
+                          int64_t B, int64_t* d_out_pids, float* d_out_scores, void* hip_stream) {
+    return merge_topk_launch(device, d_pids, d_scores, k, n_lists, B, (size_t)(B * k), (size_t)(B * k), d_out_pids,
+                             d_out_scores, hip_stream);
+}
+
+int64_t clb_packed_topk_bytes(int64_t k, int64_t B) { return (B * k * 12 + 7) / 8 * 8; }
+
+int clb_merge_topk_packed_device(int device, const void* d_packed, int64_t k, int64_t n_lists, int64_t B,
+                                 int64_t* d_out_pids, float* d_out_scores, void* hip_stream) {
+    if (k < 1 || B < 1) return fail(CLB_EARGUMENT, "k, n_lists and B must be >= 1");
+    const size_t block = (size_t)clb_packed_topk_bytes(k, B);
+    const char* base = static_cast<const char*>(d_packed);
+    return merge_topk_launch(device, reinterpret_cast<const int64_t*>(base),
+                             reinterpret_cast<const float*>(base + (size_t)B * k * 8), k, n_lists, B, block / 8, block / 4,
+                             d_out_pids, d_out_scores, hip_stream);
 }
 
 int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t k, int64_t cap,

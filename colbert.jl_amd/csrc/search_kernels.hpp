@@ -1242,27 +1242,30 @@ static __global__ void batch_stats_kernel(const uint32_t* __restrict__ cand, con
 __device__ __forceinline__ bool rec_before(float s, int64_t p, float s2, int64_t p2) {
     return s > s2 || (s == s2 && p < p2);
 }
+// pid_stride / score_stride: elements between the (B, k) blocks of consecutive lists (B*k when the lists are
+// stacked densely; larger when every rank's pids and scores travel in one packed all-gather buffer).
 static __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restrict__ pids,
                                                          const float* __restrict__ scores, int k, int n_lists,
-                                                         int B, int64_t* __restrict__ out_pids,
+                                                         int B, size_t pid_stride, size_t score_stride,
+                                                         int64_t* __restrict__ out_pids,
                                                          float* __restrict__ out_scores) {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_lists * k) return;
     const int l = idx / k, i = idx % k;
-    const size_t me = ((size_t)l * B + b) * k + i;
-    const int64_t p = pids[me];
-    const float s = scores[me];
+    const int64_t p = pids[(size_t)l * pid_stride + (size_t)b * k + i];
+    const float s = scores[(size_t)l * score_stride + (size_t)b * k + i];
     if (p <= 0) return;  // padding
     int rank = i;
     for (int l2 = 0; l2 < n_lists; ++l2) {
         if (l2 == l) continue;
-        const size_t base = ((size_t)l2 * B + b) * k;
+        const int64_t* pl = pids + (size_t)l2 * pid_stride + (size_t)b * k;
+        const float* sl = scores + (size_t)l2 * score_stride + (size_t)b * k;
         int lo = 0, hi = k;  // number of records of list l2 that come before (s, p)
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            const int64_t p2 = pids[base + mid];
-            const float s2 = scores[base + mid];
+            const int64_t p2 = pl[mid];
+            const float s2 = sl[mid];
             if (p2 > 0 && rec_before(s2, p2, s, p)) lo = mid + 1; else hi = mid;
         }
         rank += lo;

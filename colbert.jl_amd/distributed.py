@@ -29,6 +29,41 @@ def all_gather_topk(pids, scores, group=None):
     return gp.view(world, B, k), gs.view(world, B, k)
 
 
+def packed_topk_bytes(k: int, B: int) -> int:
+    """Bytes of one rank's packed (B, k) result block: [B*k int64 pids][B*k fp32 scores][pad to 8]."""
+    return (B * k * 12 + 7) // 8 * 8
+
+
+def all_gather_packed(packed, group=None):
+    """ONE all-gather for a rank's whole result.  `packed`: the uint8 tensor of `packed_topk_bytes` bytes that
+    DeviceSearch wrote its pids and scores into -> (world, nbytes) uint8 tensor on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)   # concatenation along dim 0
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return out.view(world, packed.numel())
+
+
+def merge_packed(gathered, B: int, k: int, out_p=None, out_s=None):
+    """(world, nbytes) gathered packed blocks -> (B, k) merged top-k via clb_merge_topk_packed_device on torch's
+    current stream."""
+    import torch
+    world = gathered.shape[0]
+    if not gathered.is_cuda:      # host merge (gloo tests): unpack the blocks and reuse the unpacked path
+        gp = gathered[:, :B * k * 8].contiguous().view(torch.int64).view(world, B, k)
+        gs = gathered[:, B * k * 8:B * k * 12].contiguous().view(torch.float32).view(world, B, k)
+        return merge_gathered(gp, gs, k)
+    if out_p is None:
+        out_p = torch.empty((B, k), dtype=torch.int64, device=gathered.device)
+        out_s = torch.empty((B, k), dtype=torch.float32, device=gathered.device)
+    st = torch.cuda.current_stream(gathered.device).cuda_stream
+    check(lib().clb_merge_topk_packed_device(gathered.device.index, C.c_void_p(gathered.data_ptr()), i64(k), i64(world),
+                                             i64(B), C.c_void_p(out_p.data_ptr()), C.c_void_p(out_s.data_ptr()),
+                                             C.c_void_p(st)))
+    return out_p, out_s
+
+
 def merge_gathered(gp, gs, k: int, device_index=None, out_p=None, out_s=None):
     """(world, B, k) gathered records -> (B, k) merged top-k.  GPU tensors go through the HIP merge
     kernel (clb_merge_topk_device) on torch's current stream; CPU tensors through the host merge."""
@@ -52,10 +87,23 @@ def merge_gathered(gp, gs, k: int, device_index=None, out_p=None, out_s=None):
     return torch.from_numpy(out_p), torch.from_numpy(out_s)
 
 
-def sharded_search(local_search, Q, k: int, group=None):
+def pack_topk(pids, scores):
+    """(B, k) int64 pids + (B, k) fp32 scores -> the packed uint8 block of `packed_topk_bytes(k, B)` bytes."""
+    import torch
+    B, k = pids.shape
+    buf = torch.zeros(packed_topk_bytes(k, B), dtype=torch.uint8, device=pids.device)
+    buf[:B * k * 8].view(torch.int64).copy_(pids.reshape(-1))
+    buf[B * k * 8:B * k * 12].view(torch.float32).copy_(scores.reshape(-1))
+    return buf
+
+
+def sharded_search(local_search, Q, k: int, group=None, packed: bool = False):
     """local_search(Q) -> (pids (B, k), scores (B, k)) torch tensors for this rank's shard, padded with
-    (0, -inf).  Returns the merged (B, k) result, identical on every rank."""
+    (0, -inf).  Returns the merged (B, k) result, identical on every rank.  `packed`: move pids and scores in ONE
+    all-gather of packed blocks (what bench.py does) instead of one collective each."""
     p, s = local_search(Q)
+    if packed:
+        return merge_packed(all_gather_packed(pack_topk(p, s), group), p.shape[0], k)
     gp, gs = all_gather_topk(p, s, group)
     return merge_gathered(gp, gs, k)
 
@@ -68,8 +116,10 @@ class DeviceSearch:
         import torch
         self.s, self.T, self.B, self.k, self.nprobe = searcher, T, B, k, nprobe
         self.dev = torch.device("cuda", searcher.device)
-        self.out_p = torch.empty((B, k), dtype=torch.int64, device=self.dev)
-        self.out_s = torch.empty((B, k), dtype=torch.float32, device=self.dev)
+        # pids and scores live in one packed block so that a single all-gather can move both (all_gather_packed)
+        self.packed = torch.empty(packed_topk_bytes(k, B), dtype=torch.uint8, device=self.dev)
+        self.out_p = self.packed[:B * k * 8].view(torch.int64).view(B, k)
+        self.out_s = self.packed[B * k * 8:B * k * 12].view(torch.float32).view(B, k)
         self.ncand = torch.zeros(B, dtype=torch.int64, device=self.dev)
 
     def __call__(self, Qdev):

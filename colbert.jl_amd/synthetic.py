@@ -40,13 +40,13 @@ def _centroids(seed: int, K: int, dim: int) -> np.ndarray:
 
 
 def _block(seed: int, block: int, n_docs: int, K: int, dim: int, nbits: int, doclen_mean: float,
-           doclen_std: float, constant_doclen: bool, topical: bool):
+           doclen_std: float, constant_doclen: bool, topical: bool, doclen_max: int = 220):
     """Passages of one generation block: (doclens, codes, residuals as (n_emb, rows))."""
     rng = np.random.default_rng([seed, 1000 + block])
     if constant_doclen:
         doclens = np.full(n_docs, int(doclen_mean), dtype=np.int64)
     else:
-        doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, 220).astype(np.int64)
+        doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, doclen_max).astype(np.int64)
     n_emb = int(doclens.sum())
     if topical:
         doc_of = np.repeat(np.arange(n_docs, dtype=np.int32), doclens)
@@ -64,7 +64,7 @@ def _block(seed: int, block: int, n_docs: int, K: int, dim: int, nbits: int, doc
 
 def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbits: int = 2,
                doclen_mean: float = 80.0, doclen_std: float = 16.0, constant_doclen: bool = False,
-               topical: bool = True, n_blocks: int = 1, blocks=None):
+               topical: bool = True, n_blocks: int = 1, blocks=None, doclen_max: int = 220):
     """A compressed index of `n_docs` passages.  `topical`: each passage draws 80 % of its tokens
     from the 16 centroids nearest (by id, a cheap stand-in for similarity) to 4 per-passage topic
     centroids, the rest uniformly -- uniform codes are the worst case for candidate counts.
@@ -80,7 +80,8 @@ def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbi
     parts = []
     for b in blocks:
         lo, hi = b * per, min(n_docs, (b + 1) * per)
-        parts.append(_block(seed, b, hi - lo, K, dim, nbits, doclen_mean, doclen_std, constant_doclen, topical))
+        parts.append(_block(seed, b, hi - lo, K, dim, nbits, doclen_mean, doclen_std, constant_doclen, topical,
+                            doclen_max))
     doclens = np.concatenate([p[0] for p in parts])
     codes = np.concatenate([p[1] for p in parts])
     residuals = np.asfortranarray(np.concatenate([p[2] for p in parts], axis=0).T)   # (rows, n_emb) col-major

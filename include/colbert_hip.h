@@ -102,6 +102,12 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
 int clb_merge_topk_device(int device, const int64_t* d_pids, const float* d_scores, int64_t k,
                           int64_t n_lists, int64_t B, int64_t* d_out_pids, float* d_out_scores,
                           void* hip_stream);
+/* The same merge over PACKED per-rank blocks, so that one all-gather moves a rank's whole result: block r of
+ * `d_packed` is clb_packed_topk_bytes(k, B) bytes = [B*k int64 pids][B*k fp32 scores][pad to 8 bytes].  A rank
+ * produces its block by pointing clb_search_batch_device's d_out_pids / d_out_scores into one such buffer. */
+int64_t clb_packed_topk_bytes(int64_t k, int64_t B);
+int clb_merge_topk_packed_device(int device, const void* d_packed, int64_t k, int64_t n_lists, int64_t B,
+                                 int64_t* d_out_pids, float* d_out_scores, void* hip_stream);
 
 /* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's roofline).
  * enable, run searches, then read: names[i] (static strings), total milliseconds and launch counts.

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, k, q):
+def _worker(rank, world, port, k, q, packed=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,7 +48,7 @@ def _worker(rank, world, port, k, q):
                 P[b, :kk] = p + off; S[b, :kk] = s
         return torch.from_numpy(P), torch.from_numpy(S)
 
-    mp, ms = sharded_search(local_search, Qs, k)
+    mp, ms = sharded_search(local_search, Qs, k, packed=packed)
     if rank == 0:
         ok = True
         for b in range(Qs.shape[2]):
@@ -59,13 +59,13 @@ def _worker(rank, world, port, k, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [50, 400])
-def test_two_rank_sharded_search_equals_unsharded(k):
+@pytest.mark.parametrize("k,packed", [(50, False), (400, False), (401, True)])
+def test_two_rank_sharded_search_equals_unsharded(k, packed):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, k, q, packed)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -273,6 +273,15 @@ def test_search_ragged_and_empty_passages(oracle):
     check_search(oracle, idx2, synthetic.make_queries(idx2, 15, 3), k=20)
 
 
+def test_search_long_passages(oracle):
+    """Passages longer than 256 embeddings do not fit the row mask of the two-pass mode and take every row in the
+    exact pass; shorter ones in the same index use the mask.  Both must equal the oracle, in both modes."""
+    idx = synthetic.make_index(seed=23, n_docs=400, K=128, doclen_mean=230, doclen_std=90, doclen_max=600)
+    assert int(idx["doclens"].max()) > 256 and int(idx["doclens"].min()) < 128
+    check_search(oracle, idx, synthetic.make_queries(idx, 24, 3), k=50)
+    check_search(oracle, idx, synthetic.make_queries(idx, 25, 9, T=20), k=30, modes=(1,))
+
+
 def test_search_ties_keep_ascending_pid(oracle):
     """Duplicate passages score identically; the stable sortperm keeps the lower pid first."""
     idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
@@ -308,22 +317,25 @@ def test_device_merge_kernel_matches_unsharded(oracle):
     """The multi-GPU data path on one GPU: per-shard device search -> stacked (world, B, k) records (what
     all_gather_into_tensor produces) -> clb_merge_topk_device == unsharded oracle result."""
     torch = pytest.importorskip("torch")
-    from colbert_jl_amd.distributed import DeviceSearch, merge_gathered
+    from colbert_jl_amd.distributed import DeviceSearch, merge_gathered, merge_packed
     from colbert_jl_amd.sharding import shard_index
     idx = synthetic.make_index(seed=33, n_docs=5000, K=512)
-    Qs = synthetic.make_queries(idx, 34, 4)
-    k, world = 300, 4
+    Qs = synthetic.make_queries(idx, 34, 3)                       # B*k odd-sized blocks exercise the padding
+    k, world = 301, 4
     Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
-    gp, gs, keep = [], [], []
+    gp, gs, packed, keep = [], [], [], []
     for rnk in range(world):
         sub, off = shard_index(idx, rnk, world)
         s = clb.Searcher(index=sub, pid_offset=off)
         run = DeviceSearch(s, 32, Qs.shape[2], k, 2)
         p, sc = run(Qdev)
         torch.cuda.synchronize()
-        gp.append(p.clone()); gs.append(sc.clone()); keep.append(s)
+        gp.append(p.clone()); gs.append(sc.clone()); packed.append(run.packed.clone()); keep.append(s)
     mp, ms = merge_gathered(torch.stack(gp), torch.stack(gs), k)
+    # the packed layout one all-gather produces: (world, packed_topk_bytes) -> clb_merge_topk_packed_device
+    pp, ps = merge_packed(torch.stack(packed), Qs.shape[2], k)
     torch.cuda.synchronize()
+    assert torch.equal(mp, pp) and torch.equal(ms, ps)
     mp = mp.cpu().numpy(); ms = ms.cpu().numpy()
     for j in range(Qs.shape[2]):
         rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
