@@ -121,7 +121,7 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
 // -------------------------------------------------------------------------------------------------------------
 constexpr int kRowBytes16 = 272;   // staged bf16 row: 256 B + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
 constexpr int kTopPartial = 4;     // per-lane list length in the bf16x3 kernel
-constexpr int kTopRefine = 8;      // candidates re-scored exactly per token
+constexpr int kTopRefine = 4;      // groups of 16 centroids re-scored exactly per token (one per 16 lanes)
 
 static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
                                          uint16_t* __restrict__ lo, int64_t n) {
@@ -152,6 +152,29 @@ __device__ __forceinline__ void topn_insert_lazy(float (&bv)[NP], int (&bi)[NP],
         bi[p] = touch ? ni : bi[p];
     }
     if (in && v > bv[0]) { bv[0] = v; bi[0] = idx; }
+}
+
+// Largest of the 16 scores a lane holds of one 32-centroid tile (its "group": token i, centroids
+// c0 + (r & 3) + 8 (r >> 2) + 4 h).  The per-lane lists keep the best GROUPS by this maximum -- one list operation
+// per tile instead of sixteen; top_refine_kernel re-scores all 16 centroids of every group that can matter.
+__device__ __forceinline__ float group_max16(const f32x16& acc, int c0, int h, int K) {
+    if (__builtin_expect(c0 + 32 > K, 0)) {         // last, partial tile: rows past K are copies of row K-1
+        float m = kNegInf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, c0 + (r & 3) + 8 * (r >> 2) + 4 * h < K ? acc[r] : kNegInf);
+        return m;
+    }
+    // plain fmaxf (the compiler fuses them to v_max3_f32): the accumulator comes straight from the MFMA, and the
+    // wait states that hazard needs are only inserted for instructions the compiler can see through -- an inline
+    // asm v_max3 here read stale registers
+    float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+    m = fmaxf(fmaxf(m, acc[3]), acc[4]);
+    m = fmaxf(fmaxf(m, acc[5]), acc[6]);
+    m = fmaxf(fmaxf(m, acc[7]), acc[8]);
+    m = fmaxf(fmaxf(m, acc[9]), acc[10]);
+    m = fmaxf(fmaxf(m, acc[11]), acc[12]);
+    m = fmaxf(fmaxf(m, acc[13]), acc[14]);
+    return fmaxf(m, acc[15]);
 }
 
 // grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * 2 arrays * 32 rows * 272 B.
@@ -231,10 +254,10 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, qh[s]), acc, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        topn_insert_lazy<kTopPartial>(bv, bi, group_max16(acc, c0, h, K), 2 * tile + h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            topn_insert_lazy<kTopPartial>(bv, bi, c < K ? acc[r] : kNegInf, c);
             if (WRITE_HALF) {
                 const float other = __shfl_xor(acc[r], 16, 64);
                 if ((i & 16) == 0 && c < K) {
@@ -340,12 +363,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0);
         }
         const int c0 = tile * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            topn_insert_lazy<kTopPartial>(bv0, bi0, c < K ? acc0[r] : kNegInf, c);
-            topn_insert_lazy<kTopPartial>(bv1, bi1, c < K ? acc1[r] : kNegInf, c);
-        }
+        topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * tile + h);
+        topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * tile + h);
         if (WRITE_HALF) {
             // the tile's 32 x 32 scores leave as one contiguous 2-KB block of fp16 pairs {t, t+16}: transposed through
             // a per-wave LDS patch (16 ds_write_b16 + 2 ds_read_b128) so that the wave issues 2 full-width stores
@@ -391,13 +410,14 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// One wave per (token, query).  a2 = the token's 2nd best approximate score over all partial lists; every listed
-// centroid with an approximate score >= a2 - 2 eps_c is re-scored with the canonical fp32 fmaf chain and the exact
-// top-2 by (score desc, index asc) comes out.  Two streaming sweeps over the lists (they stay in L2): sweep 1 keeps
-// each lane's two best entries and reduces them over the wave, sweep 2 compacts the qualifying entries (normally 2 to
-// 4) into LDS.  A partial list whose LAST entry qualifies may have dropped a qualifying centroid, and more than
-// kTopRefine qualifying entries do not fit: both cases fall back to the exhaustive canonical scan in this wave
-// (never seen in practice).  grid = (32, B), block = 64.
+// One wave per (token, query).  The partial lists hold GROUPS (16 centroids of one tile, see group_max16) keyed by
+// their largest approximate score.  g2 = the 2nd largest group maximum over all lists is a lower bound of a2, the
+// token's 2nd best approximate score, so every centroid with an approximate score >= a2 - 2 eps_c lives in a group
+// whose maximum is >= g2 - 2 eps_c.  Those groups (normally 2) are compacted to LDS in two streaming sweeps over the
+// lists (they stay in L2) and all their centroids are re-scored with the canonical fp32 fmaf chain, 16 lanes per
+// group; the exact top-2 by (score desc, index asc) comes out.  A list whose LAST entry qualifies may have dropped a
+// qualifying group, and more than kTopRefine qualifying groups do not fit the wave: both cases fall back to the
+// exhaustive canonical scan in this wave (mass ties only).  grid = (32, B), block = 64.
 static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __restrict__ partial,
                                                               const float* __restrict__ C,
                                                               const float* __restrict__ Q, int T, int K,
@@ -484,13 +504,17 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
         }
     }
     __syncthreads();
-    const bool overflow = total > kTopRefine || (K > kTopPartial && last_max >= thr);
+    // a list holds more than kTopPartial groups' worth of history only if the lane saw that many tiles
+    const bool overflow = total > kTopRefine || last_max >= thr;
     float tv[2] = {kNegInf, kNegInf};
     int ti[2] = {0x7fffffff, 0x7fffffff};
     if (!overflow) {
-        // lanes 0..total-1 re-score one candidate each with the chain the fp32 MFMA kernel performs
-        if (lane < total) {
-            const int id = cand[lane].i;
+        // 16 lanes per qualifying group: lane (grp, rr) re-scores centroid rr of group grp with the chain the fp32
+        // MFMA kernel performs
+        const int grp = lane >> 4, rr = lane & 15;
+        const int gid = grp < total ? cand[grp].i : 0;
+        const int id = (gid >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (gid & 1);
+        if (grp < total && id < K) {
             const float4* c4 = reinterpret_cast<const float4*>(C + (size_t)id * kDim);
             float4 cr[32];
 #pragma unroll
