@@ -60,6 +60,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
 }
 
+// NOTE: never feed an MFMA accumulator straight into this helper.  The wait states an MFMA result needs before a
+// VALU read are inserted by the compiler only for instructions it can see through; through the inline asm a stale
+// register is read (seen in group_max16: wrong centroids selected).  Arguments must come from ordinary VALU code.
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
