@@ -291,10 +291,15 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
 // partial: [B][nslots = gx * 2 halves][32][kTopPartial].
 constexpr int kMqQueries = 8;
 
-template <bool WRITE_HALF>
+// BIAS (index build): `bias[c]` (padded to a multiple of 32 entries) is added to every score of centroid c before
+// the group maximum is taken -- with bias = -||c||^2 / 2 the ranking is that of the k-means distance
+// (nearest_centroids in codec.hip).  q_rows = number of valid rows of Q (rows past it re-read the last one; for the
+// search path q_rows = B*T).
+template <bool WRITE_HALF, bool BIAS = false>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_mq_kernel(
     const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
-    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles) {
+    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles,
+    const float* __restrict__ bias = nullptr, int64_t q_rows = -1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -303,7 +308,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int b = bq0 + q < B ? bq0 + q : B - 1;      // past the batch: a duplicate whose results are dropped
-        const float* qrow = Q + ((size_t)b * T + (i < T ? i : T - 1)) * kDim + 64 * h;
+        int64_t qr = (int64_t)b * T + (i < T ? i : T - 1);
+        if (q_rows >= 0 && qr >= q_rows) qr = q_rows - 1;
+        const float* qrow = Q + (size_t)qr * kDim + 64 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v[8];
@@ -366,6 +373,15 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0);
         }
         const int c0 = tile * 32;
+        if (BIAS) {
+            // this lane's rows: c0 + (r & 3) + 8 (r >> 2) + 4 h -- four aligned float4 of the bias row
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + c0 + 8 * qd + 4 * h);
+                acc0[4 * qd] += b4.x; acc0[4 * qd + 1] += b4.y; acc0[4 * qd + 2] += b4.z; acc0[4 * qd + 3] += b4.w;
+                acc1[4 * qd] += b4.x; acc1[4 * qd + 1] += b4.y; acc1[4 * qd + 2] += b4.z; acc1[4 * qd + 3] += b4.w;
+            }
+        }
         topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * tile + h);
         topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * tile + h);
         if (WRITE_HALF) {

@@ -23,12 +23,58 @@ struct Stream {
     }
 };
 
-// device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means
+// Scratch of the bf16x3 nearest-centroid path, kept across calls (k-means calls it once per iteration).
+struct NearestScratch {
+    DevBuf hi, lo, bias, partial, cn;
+};
+
+// device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means.
+// dim 128, K >= 32: approximate scores at the bf16 MFMA rate (three split products, proven bound) shared between
+// 256 points per staged centroid tile, then an exact re-evaluation of the few candidates per point with the
+// canonical arithmetic -- the same codes as the all-fp32 kernel (kept as the small-K / other-dim path), bit for bit.
 template <int MODE>
 int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim, int K, const float* dX, int64_t n,
-                      uint32_t* dOut) {
+                      uint32_t* dOut, NearestScratch* scratch = nullptr) {
     if (n == 0) return CLB_OK;
-    if (dim == kDim) {
+    static const bool force_fp32 = getenv("CLB_DEBUG_NEAREST_FP32") != nullptr;
+    if (dim == kDim && K >= 32 && scratch && !force_fp32) {
+        NearestScratch& w = *scratch;
+        const size_t cel = (size_t)K * kDim;
+        const int kpad = (K + 31) / 32 * 32 + 32;
+        CLB_TRY(w.hi.ensure(sizeof(uint16_t) * cel));
+        CLB_TRY(w.lo.ensure(sizeof(uint16_t) * cel));
+        CLB_TRY(w.bias.ensure(sizeof(float) * kpad));
+        CLB_TRY(w.cn.ensure(sizeof(unsigned int)));
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC,
+                           w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), (int64_t)cel);
+        CLB_HIP(hipMemsetAsync(w.cn.p, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K,
+                           w.cn.as<unsigned int>());
+        if (MODE == 1)
+            hipLaunchKernelGGL(half_neg_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, dc2, K, w.bias.as<float>(), kpad);
+        const int n_tiles = (K + 31) / 32;
+        const int64_t chunk_max = (int64_t)1 << 22;                     // points per launch: 256 MB of group lists
+        CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)((std::min(n, chunk_max) + 31) / 32) * 2 * 32 * kTopPartial));
+        const size_t lds = 2 * 2 * 32 * kRowBytes16;
+        for (int64_t p0 = 0; p0 < n; p0 += chunk_max) {
+            const int64_t m = std::min(chunk_max, n - p0);
+            const int groups32 = (int)((m + 31) / 32);                  // "queries" of 32 points
+            const dim3 grid(1, (unsigned)((groups32 + kMqQueries - 1) / kMqQueries));
+            if (MODE == 1)
+                hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, true>), grid, dim3(256), lds, st,
+                                   w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), dX + (size_t)p0 * kDim,
+                                   w.partial.as<ValIdx>(), (uint32_t*)nullptr, K, 32, groups32, n_tiles,
+                                   w.bias.as<float>(), m);
+            else
+                hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, false>), grid, dim3(256), lds, st,
+                                   w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), dX + (size_t)p0 * kDim,
+                                   w.partial.as<ValIdx>(), (uint32_t*)nullptr, K, 32, groups32, n_tiles,
+                                   (const float*)nullptr, m);
+            hipLaunchKernelGGL(nearest_refine_kernel<MODE>, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st,
+                               w.partial.as<ValIdx>(), dC, dc2, dX + (size_t)p0 * kDim, m, K, w.cn.as<unsigned int>(),
+                               dOut + p0);
+        }
+    } else if (dim == kDim) {
         const int64_t ptiles = (n + 31) / 32;
         hipLaunchKernelGGL(nearest_centroid_mfma_kernel<MODE>, dim3((unsigned)((ptiles + 1) / 2)), dim3(128),
                            2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX, n, dOut);
@@ -155,7 +201,8 @@ int clb_compress_into_codes(int device, uint32_t* codes, int64_t n_codes, const 
     CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
     CLB_TRY(upload(dX, embs, sizeof(float) * dim * n, s.st));
     CLB_TRY(dOut.alloc(sizeof(uint32_t) * n));
-    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dOut.as<uint32_t>()));
+    NearestScratch nscratch;
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dOut.as<uint32_t>(), &nscratch));
     CLB_HIP(hipMemcpyAsync(codes, dOut.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s.st));
     CLB_HIP(hipStreamSynchronize(s.st));
     return CLB_OK;
@@ -176,7 +223,8 @@ int clb_compress(int device, const float* centroids, int64_t K, const float* buc
     CLB_TRY(upload(dCut, bucket_cutoffs, sizeof(float) * std::max<int64_t>(n_cutoffs, 1), s.st));
     CLB_TRY(dCodes.alloc(sizeof(uint32_t) * n));
     CLB_TRY(dRes.alloc((size_t)rows * n));
-    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>()));
+    NearestScratch nscratch;
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>(), &nscratch));
     hipLaunchKernelGGL(pack_residuals_kernel, dim3(blocks_for(n * rows)), dim3(256), 0, s.st, dC.as<float>(),
                        dCut.as<float>(), (int)n_cutoffs, (int)dim, nbits, dX.as<float>(), dCodes.as<uint32_t>(), n,
                        dRes.as<uint8_t>());
@@ -194,6 +242,7 @@ int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* cen
     CLB_TRY(use_device(device));
     Stream s; CLB_TRY(s.init());
     DevBuf dX, dC, dNew, dC2, dAssign, dOrder, dIota, dKeys, dCounts, dStart, dDelta, dErr, dCnt32;
+    NearestScratch nscratch;
     CLB_TRY(upload(dX, data, sizeof(float) * dim * std::max<int64_t>(n, 1), s.st));
     CLB_TRY(upload(dC, centroids, sizeof(float) * dim * K, s.st));
     CLB_TRY(dNew.alloc(sizeof(float) * dim * K));
@@ -215,7 +264,7 @@ int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* cen
         hipLaunchKernelGGL(centroid_sumsq_kernel, dim3(blocks_for(K, 64)), dim3(64), 0, s.st, dC.as<float>(), (int)dim,
                            (int)K, dC2.as<float>());
         CLB_TRY(nearest_centroids<1>(s.st, dC.as<float>(), dC2.as<float>(), (int)dim, (int)K, dX.as<float>(), n,
-                                     dAssign.as<uint32_t>()));
+                                     dAssign.as<uint32_t>(), &nscratch));
         // group the points by cluster, ascending point id inside a cluster (stable)
         CLB_HIP(hipMemsetAsync(dCounts.p, 0, sizeof(uint32_t) * (K + 1), s.st));
         CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), s.st));
@@ -265,7 +314,8 @@ int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int
     CLB_TRY(dSorted.alloc(sizeof(float) * dim * n));
     CLB_TRY(dAbs.alloc(sizeof(double)));
     CLB_HIP(hipMemsetAsync(dAbs.p, 0, sizeof(double), s.st));
-    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>()));
+    NearestScratch nscratch;
+    CLB_TRY(nearest_centroids<0>(s.st, dC.as<float>(), nullptr, (int)dim, (int)K, dX.as<float>(), n, dCodes.as<uint32_t>(), &nscratch));
     hipLaunchKernelGGL(heldout_residual_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, s.st, dC.as<float>(), (int)dim,
                        dX.as<float>(), dCodes.as<uint32_t>(), n, dRes.as<float>(), dAbs.as<double>());
     CLB_HIP(hipGetLastError());

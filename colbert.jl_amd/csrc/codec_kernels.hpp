@@ -5,6 +5,7 @@
 #pragma once
 #include "common.hpp"
 #include "search_kernels.hpp"
+#include "approx_kernels.hpp"
 
 namespace clb {
 
@@ -376,6 +377,98 @@ static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, in
         const float den = sqrtf(sumsq_canonical(x, dim)) + FLT_EPSILON;
         for (int d = 0; d < dim; ++d) o[d] = x[d] / den;
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Index build: exact nearest centroid of every point from the group lists centroid_top_bf16x3_mq_kernel<false, BIAS>
+// wrote with gx = 1 (partial: [ceil(n/32)][2 halves][32][kTopPartial]).  MODE 0: argmax of the canonical dot
+// product, first index on ties (compress_into_codes!, residual.jl:67-81).  MODE 1: argmin of
+// fl(fl(-2 dot + ||c||^2) + ||x||^2), first index on ties (assign_clusters of kmeans_gpu_onehot!, utils.jl:38-79).
+// With w(c) = x.c - ||c||^2/2 the k-means distance is -2 w + ||x||^2 up to its own rounding (<= delta), and the
+// listed group maxima approximate w within e_dot, so the exact winner lives in a group whose maximum is
+// >= g1 - (2 e_dot + delta), g1 = the largest group maximum.  16 lanes per point re-score those groups (normally
+// one) with the canonical arithmetic.  A full list whose last entry qualifies triggers the exhaustive scan.
+// grid = ceil(n / 16), block = 256 (4 waves x 4 points).
+// -------------------------------------------------------------------------------------------------------------
+template <int MODE>
+static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx* __restrict__ partial,
+                                                                   const float* __restrict__ C,
+                                                                   const float* __restrict__ c2,
+                                                                   const float* __restrict__ X, int64_t n, int K,
+                                                                   const unsigned int* __restrict__ cn_max_bits,
+                                                                   uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int64_t pp = p < n ? p : n - 1;                       // idle quarters shadow the last point
+    const float* x = X + (size_t)pp * kDim;
+    // ||x||: 8 dims per lane; the canonical ||x||^2 of MODE 1 is computed separately below
+    float part = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) part = fmaf(x[8 * sub + d], x[8 * sub + d], part);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o, 64);
+    const float xn = sqrtf(part) * 1.001f, cn = __uint_as_float(*cn_max_bits);
+    const float margin = 2.f * kEpsSafety * 7.4e-5f * xn * cn + 4e-6f * (1.f + xn * xn + cn * cn);
+    const float x2 = MODE == 1 ? sumsq_canonical(x, kDim) : 0.f;
+    const int64_t b = pp >> 5;
+    const int i = (int)(pp & 31);
+    const ValIdx* l0 = partial + ((size_t)(b * 2 + 0) * 32 + i) * kTopPartial;
+    const ValIdx* l1 = partial + ((size_t)(b * 2 + 1) * 32 + i) * kTopPartial;
+    ValIdx ent[2 * kTopPartial];
+#pragma unroll
+    for (int e = 0; e < kTopPartial; ++e) { ent[e] = l0[e]; ent[kTopPartial + e] = l1[e]; }
+    const float g1 = fmaxf(ent[0].v, ent[kTopPartial].v);
+    const float thr = g1 - margin;
+    const bool overflow = (ent[kTopPartial - 1].i != 0x7fffffff && ent[kTopPartial - 1].v >= thr) ||
+                          (ent[2 * kTopPartial - 1].i != 0x7fffffff && ent[2 * kTopPartial - 1].v >= thr);
+    float bestv = 0.f;
+    int best = 0x7fffffff;
+    auto consider = [&](int c) {
+        const float4* c4 = reinterpret_cast<const float4*>(C + (size_t)c * kDim);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float a = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {                            // the chain the fp32 MFMA kernel performs
+            const float4 cv = c4[m], xv = x4[m];
+            a = fmaf(cv.x, xv.x, a);
+            a = fmaf(cv.y, xv.y, a);
+            a = fmaf(cv.z, xv.z, a);
+            a = fmaf(cv.w, xv.w, a);
+        }
+        if (MODE == 1) {
+            float v = -2.0f * a;
+            v = v + c2[c];
+            v = v + x2;
+            if (best == 0x7fffffff || v < bestv || (v == bestv && c < best)) { bestv = v; best = c; }
+        } else {
+            if (best == 0x7fffffff || a > bestv || (a == bestv && c < best)) { bestv = a; best = c; }
+        }
+    };
+    if (!overflow) {
+#pragma unroll
+        for (int e = 0; e < 2 * kTopPartial; ++e) {
+            if (ent[e].i == 0x7fffffff || !(ent[e].v >= thr)) continue;    // uniform over the point's 16 lanes
+            const int gid = ent[e].i;
+            const int c = (gid >> 1) * 32 + (sub & 3) + 8 * (sub >> 2) + 4 * (gid & 1);
+            if (c < K) consider(c);
+        }
+    } else {
+        for (int c = sub; c < K; c += 16) consider(c);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float ov = __shfl_xor(bestv, o, 64);
+        const int oi = __shfl_xor(best, o, 64);
+        const bool take = oi != 0x7fffffff &&
+                          (best == 0x7fffffff || (MODE == 1 ? ov < bestv : ov > bestv) || (ov == bestv && oi < best));
+        if (take) { bestv = ov; best = oi; }
+    }
+    if (sub == 0 && p < n) out[p] = (uint32_t)(best + 1);
+}
+
+static __global__ void half_neg_kernel(const float* __restrict__ c2, int K, float* __restrict__ out, int n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_out) out[i] = i < K ? -0.5f * c2[i] : 0.f;
 }
 
 }  // namespace clb

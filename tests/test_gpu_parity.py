@@ -104,7 +104,7 @@ def test_maxsim_bit_exact(oracle):
     assert_same_f32(codec.maxsim(Q, D, pids, doclens), oracle.maxsim(Q, D, pids, doclens), "maxsim")
 
 
-@pytest.mark.parametrize("dim,K,n", [(128, 300, 2100), (128, 1, 5), (128, 33, 31), (48, 20, 200)])
+@pytest.mark.parametrize("dim,K,n", [(128, 300, 2100), (128, 1, 5), (128, 33, 31), (48, 20, 200), (128, 1000, 9001)])
 def test_compress_bit_exact(oracle, dim, K, n):
     rng = np.random.default_rng(103 + K)
     cent = oracle.normalize_array(rng.normal(size=(dim, K)).astype(np.float32))
@@ -126,7 +126,8 @@ def test_compress_ties_pick_first_centroid(oracle):
     assert np.all(codec.compress_into_codes(cent, embs) == 38)
 
 
-@pytest.mark.parametrize("dim,n,K,bsize", [(128, 3000, 40, 1000), (128, 700, 64, 100), (16, 500, 9, 1000)])
+@pytest.mark.parametrize("dim,n,K,bsize", [(128, 3000, 40, 1000), (128, 700, 64, 100), (16, 500, 9, 1000),
+                                             (128, 6000, 200, 1000)])
 def test_kmeans_bit_exact(oracle, dim, n, K, bsize):
     rng = np.random.default_rng(104 + K)
     data = oracle.normalize_array(rng.normal(size=(dim, n)).astype(np.float32))
