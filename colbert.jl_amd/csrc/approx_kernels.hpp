@@ -450,11 +450,9 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
     }
     __shared__ float qs[kDim];
     __shared__ ValIdx cand[kTopRefine];
-    __shared__ int cand_n;
     const float* q = Q + ((size_t)b * T + t) * kDim;
     qs[lane] = q[lane];
     qs[lane + 64] = q[lane + 64];
-    if (lane == 0) cand_n = 0;
     const ValIdx* lists = partial + ((size_t)b * nslots * 32 + t) * kTopPartial;   // slot stride: 32 * kTopPartial
     const size_t slot_stride = (size_t)32 * kTopPartial;
     // sweep 1: the lane's two best entries.  Lists are sorted, so only their first two entries can matter here;

@@ -347,18 +347,12 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         Timed t(s, KID_SCORE_EXACT, st);
         static const int gxl = getenv("CLB_DEBUG_EXACT_GX") ? atoi(getenv("CLB_DEBUG_EXACT_GX")) : 1024;
         const int gx = list ? std::max(1, gxl / B) : std::max(1, 2048 / B);
-        static const bool exact_old = getenv("CLB_DEBUG_EXACT_OLD") != nullptr;
         static const int flat_gx = getenv("CLB_DEBUG_FLAT_GX") ? atoi(getenv("CLB_DEBUG_FLAT_GX")) : 768;   // one resident round at 3 work-groups per CU
-        if (subset && !exact_old) {
+        if (subset) {
             hipLaunchKernelGGL(score_exact_flat_kernel, dim3(std::max(1, flat_gx / B), B), dim3(256), 0, st, s->centroids.as<float>(),
                                s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
                                w.cand_hdr.as<uint2>(), dQ, w.scores.as<float>(), T, w.cand_cap, list, nlist,
                                w.rowmask.as<unsigned long long>());
-        } else if (subset) {
-            hipLaunchKernelGGL((score_exact_kernel<2, true>), dim3(gx, B), dim3(256), 0, st, s->centroids.as<float>(),
-                               s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
-                               w.cand_hdr.as<uint2>(), dQ, w.ncand.as<int>(), w.scores.as<float>(), T, w.cand_cap,
-                               list, nlist, w.rowmask.as<unsigned long long>());
         } else
         switch (s->nbits) {
             case 1: launch_score_exact<1>(s, w, st, dQ, B, T, list, nlist, gx); break;

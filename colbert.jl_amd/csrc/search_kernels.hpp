@@ -528,20 +528,18 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
 //     strided dword gathers per lane -- the gathers alone held the kernel at 0.9 ms for 3.4 M embeddings (TA
 //     bound); 16-B chunk c of row r sits at slot c*16 + (r ^ (c & 15)), which makes both the b128 writes and
 //     the stride-4 b32 reads of lane (r, g) at most 2-way bank conflicted.
-// SUBSET (two-pass mode): `rowmask` ([B][cand_cap][4] x 64 bits, indexed by the position in `list`, written by
-// rescore_rows_kernel) names the embeddings of each listed passage that can hold a per-token maximum; only those
-// rows are decompressed and multiplied.  Passages longer than kMaxMaskedRows take every row.
+// This kernel scores EVERY embedding of a passage (single-pass mode, nbits 1/4, T > 32); the two-pass mode uses
+// score_exact_flat_kernel below, which multiplies only the rows named by the 256-bit row mask of each listed
+// passage (passages longer than kMaxMaskedRows embeddings take every row there too).
 constexpr int kMaxMaskedRows = 256;
 
-template <int NBITS, bool SUBSET = false>
-static __global__ __launch_bounds__(256, SUBSET ? 2 : 3) void score_exact_kernel(
+template <int NBITS>
+static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
     const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
     const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const float* __restrict__ Q,
     const int* __restrict__ ncand, float* __restrict__ scores, int T, size_t cand_cap,
-    const int* __restrict__ list /*optional*/, const int* __restrict__ nlist,
-    const unsigned long long* __restrict__ rowmask = nullptr) {
+    const int* __restrict__ list /*optional*/, const int* __restrict__ nlist) {
     constexpr int RD = NBITS * 4;  // residual dwords per embedding
-    __shared__ uint16_t rowlists[SUBSET ? 4 * kMaxMaskedRows : 4];
     __shared__ float tbl[weight_table_floats<NBITS>()];
     __shared__ __attribute__((aligned(16))) float qlds[16 * 64 * 4];    // 16 KB
     __shared__ __attribute__((aligned(16))) float ctiles[4 * 512 * 4];  // 4 waves x 8 KB
@@ -594,61 +592,25 @@ static __global__ __launch_bounds__(256, SUBSET ? 2 : 3) void score_exact_kernel
         __syncthreads();
         stage_q(tt);
         __syncthreads();
-        // The header (and mask) of the next passage and the slot of the one after are requested while the current
-        // passage is being scored: the list -> header -> codes -> rows chain of dependent loads otherwise leaves
-        // the wave idle for several memory round trips per passage.
+        // The header of the next passage and the slot of the one after are requested while the current passage is
+        // being scored: the list -> header -> codes -> rows chain of dependent loads otherwise leaves the wave idle
+        // for several memory round trips per passage.
         int slot_cur = wave_global < n ? (lst ? lst[wave_global] : wave_global) : 0;
         int slot_nxt = wave_global + nwaves < n ? (lst ? lst[wave_global + nwaves] : wave_global + nwaves) : 0;
         uint2 h_cur = hdr[slot_cur];
-        unsigned long long mk_cur[4] = {0, 0, 0, 0};
-        if (SUBSET && wave_global < n) {
-            const unsigned long long* mw = rowmask + ((size_t)b * cand_cap + wave_global) * 4;
-#pragma unroll
-            for (int wi = 0; wi < 4; ++wi) mk_cur[wi] = mw[wi];
-        }
         for (int j = wave_global; j < n; j += nwaves) {
             const int slot = slot_cur;  // index into the candidate array
             const uint32_t off = __builtin_amdgcn_readfirstlane(h_cur.x);
-            int len = (int)__builtin_amdgcn_readfirstlane(h_cur.y);   // SUBSET: becomes the number of selected rows
-            unsigned long long mk[4];
-#pragma unroll
-            for (int wi = 0; wi < 4; ++wi) mk[wi] = mk_cur[wi];
+            const int len = (int)__builtin_amdgcn_readfirstlane(h_cur.y);
             {
                 const int j1 = j + nwaves, j2 = j + 2 * nwaves;
                 slot_cur = slot_nxt;
-                if (j1 < n) {
-                    h_cur = hdr[slot_nxt];
-                    if (SUBSET) {
-                        const unsigned long long* mw = rowmask + ((size_t)b * cand_cap + j1) * 4;
-#pragma unroll
-                        for (int wi = 0; wi < 4; ++wi) mk_cur[wi] = mw[wi];
-                    }
-                }
+                if (j1 < n) h_cur = hdr[slot_nxt];
                 slot_nxt = j2 < n ? (lst ? lst[j2] : j2) : 0;
-            }
-            bool ident = true;
-            uint16_t* rowlist = rowlists + (SUBSET ? wave * kMaxMaskedRows : 0);
-            if (SUBSET && len <= kMaxMaskedRows) {
-                // expand the 256-bit mask into the ascending list of selected rows (lane L owns bit L of each word)
-                ident = false;
-                int prefix = 0;
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int wi = 0; wi < 4; ++wi) {
-                    const unsigned long long word = 64 * wi < len ? mk[wi] : 0ull;
-                    const unsigned long long below = word & ((1ull << lane) - 1ull);
-                    if ((word >> lane) & 1ull) rowlist[prefix + __popcll(below)] = (uint16_t)(64 * wi + lane);
-                    prefix += __popcll(word);
-                }
-                __builtin_amdgcn_wave_barrier();
-                len = __builtin_amdgcn_readfirstlane(prefix);
             }
             float m0 = kNegInf, m1 = kNegInf;
             // software prefetch, two steps deep for the codes (the row loads of step i+1 need code(i+1) early)
-            auto row_at = [&](int el) -> uint32_t {
-                const int idx = el < len ? el : len - 1;
-                return (SUBSET && !ident) ? (uint32_t)rowlist[idx] : (uint32_t)idx;
-            };
+            auto row_at = [&](int el) -> uint32_t { return (uint32_t)(el < len ? el : len - 1); };
             auto code_at = [&](int base) { return codes0[off + row_at(base + r)]; };
             uint32_t Rn[RD];
             auto load_res = [&](int base) {
@@ -1087,6 +1049,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
             const bool valid = i0 + c < n;                                                      \
             const int slot = cslot[c];                                                          \
             const uint32_t key = ckey[c];                                                       \
+            (void)slot;                                                                         \
             __VA_ARGS__                                                                         \
         }                                                                                       \
     } else {                                                                                    \
@@ -1094,6 +1057,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
             const bool valid = i0 + c < n;                                                      \
             const int slot = valid ? (lst ? lst[i0 + c] : i0 + c) : 0;                          \
             const uint32_t key = valid ? f32_order_key(sc[slot]) : 0u;                          \
+            (void)slot;                                                                         \
             __VA_ARGS__                                                                         \
         }                                                                                       \
     }
@@ -1110,7 +1074,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     __syncthreads();
     if (keff > 0) {
         int ngt = 0, neq = 0;
-        CLB_SEL_FOR_EACH((void)slot; ngt += valid && key > tau; neq += valid && key == tau;)
+        CLB_SEL_FOR_EACH(ngt += valid && key > tau; neq += valid && key == tau;)
         const int lane = tid & 63, wave = tid >> 6;
         int xg = ngt, xe = neq;
 #pragma unroll
