@@ -132,7 +132,8 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     w.topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
     CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * kDim));
-    CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
+    // the fp32 T x K score matrix is only materialised by the unfused S1/S2 path (nprobe > 2 or T > 32)
+    if (!(nprobe <= 2 && T <= 32)) CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
     CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * NPs));
     CLB_TRY(w.sel.ensure(sizeof(int) * B * Tpad * NPs));
     const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * w.W;
