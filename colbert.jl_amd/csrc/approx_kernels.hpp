@@ -678,7 +678,10 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
             }
         }
         const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
-        const uint32_t* c16 = cells16 + (size_t)b * K * 16 + r;
+        // uniform base + 32-bit per-lane byte offset (code*64 + 4r): one VALU op per gather address and the
+        // scalar-base form of global_load, instead of 64-bit per-lane pointer arithmetic
+        const char* c16 = reinterpret_cast<const char*>(cells16 + (size_t)b * K * 16);
+        const uint32_t r4 = 4u * (uint32_t)r;
         float* out = scores + (size_t)b * cand_cap;
         uint32_t* tmax = tokmax + (size_t)b * cand_cap * 16 + r;
         const int* lst = ROWS ? list + (size_t)b * cand_cap : nullptr;
@@ -741,7 +744,7 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
     }
 #define CLB_STAGE_G(CV, CELL)                                                                               \
     {                                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) CELL[q] = VARIANT == 3 ? CV[q] : c16[CV[q] * 16u];    \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) CELL[q] = VARIANT == 3 ? CV[q] : *reinterpret_cast<const uint32_t*>(c16 + ((CV[q] << 6) + r4)); \
     }
 #define CLB_STAGE_C(RB, IV, CELL, PM, TAG)                                                                  \
     {                                                                                                       \
