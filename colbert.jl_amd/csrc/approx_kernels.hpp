@@ -946,9 +946,9 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             const uint32_t key = ckey[c];                                                       \
             __VA_ARGS__                                                                         \
         }                                                                                       \
-    } else {                                                                                    \
+    } else {   /* too many for the registers: strided ownership, so that the re-reads are coalesced */ \
         for (int c = 0; c < chunk; ++c) {                                                       \
-            const int i = i0 + c;                                                               \
+            const int i = c * 1024 + tid;                                                       \
             const bool valid = i < n;                                                           \
             const uint32_t key = valid ? f32_order_key(sc[i]) : 0u;                             \
             __VA_ARGS__                                                                         \
@@ -962,7 +962,33 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     }
     // ordered compaction of the slots with approx >= thr (all of them when n <= k): one block-wide scan of the
     // per-thread counts places every chunk in order
-    {
+    if (!cached) {
+        // large inputs: the same compaction in blocks of 1024 consecutive slots (coalesced reads, one scan per block)
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            const bool take = i < n && sc[i] >= thr;
+            const int lane = tid & 63, wave = tid >> 6;
+            int xv = take ? 1 : 0;
+            const int v = xv;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(xv, o, 64);
+                if (lane >= o) xv += y;
+            }
+            if (lane == 63) sh_scan[wave] = xv;
+            __syncthreads();
+            int wbase = 0, tot = 0;
+            for (int w2 = 0; w2 < 16; ++w2) {
+                const int sv = sh_scan[w2];
+                if (w2 < wave) wbase += sv;
+                tot += sv;
+            }
+            if (take) lst[s_run + wbase + xv - v] = i;
+            __syncthreads();
+            if (tid == 0) s_run += tot;
+            __syncthreads();
+        }
+    } else {
         int cnt = 0;
         CLB_SEL_FOR_EACH((void)i; cnt += valid && f32_from_order_key(key) >= thr;)
         const int lane = tid & 63, wave = tid >> 6;

@@ -1065,7 +1065,25 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     // ---- radix select: tau = keff-th largest key -------------------------------------------------
     if (tid == 0) { s_prefix = 0u; s_remaining = keff; }
     __syncthreads();
-    if (keff > 0) CLB_RADIX_SELECT()
+    if (keff > 0) {
+        if (cached) {
+            CLB_RADIX_SELECT()
+        } else {
+            // too many keys for the registers: the radix passes do not care about order, so they read strided
+            // (coalesced) instead of the contiguous chunks the ordered compaction below needs
+#pragma push_macro("CLB_SEL_FOR_EACH")
+#undef CLB_SEL_FOR_EACH
+#define CLB_SEL_FOR_EACH(...)                                                                   \
+    for (int c = 0; c < chunk; ++c) {                                                           \
+        const int i_ = c * 1024 + tid;                                                          \
+        const bool valid = i_ < n;                                                              \
+        const uint32_t key = valid ? f32_order_key(sc[lst ? lst[i_] : i_]) : 0u;                \
+        __VA_ARGS__                                                                             \
+    }
+            CLB_RADIX_SELECT()
+#pragma pop_macro("CLB_SEL_FOR_EACH")
+        }
+    }
     const uint32_t tau = s_prefix;
     const int need_eq = s_remaining;  // how many of the == tau entries to take, lowest index first
 

@@ -283,6 +283,18 @@ def test_search_long_passages(oracle):
     check_search(oracle, idx, synthetic.make_queries(idx, 25, 9, T=20), k=30, modes=(1,))
 
 
+def test_search_many_candidates(oracle):
+    """More than 32 768 candidates per query: the selection kernels leave their register-cached path (strided
+    re-reads, block-wise compaction).  Few, huge IVF lists make almost every passage a candidate."""
+    idx = synthetic.make_index(seed=27, n_docs=45_000, K=32, doclen_mean=40, doclen_std=8)
+    Qs = synthetic.make_queries(idx, 28, 2)
+    s = clb.Searcher(index=idx)
+    s.search_embeddings(Qs[:, :, 0], 10, nprobe=2)
+    assert s.last_num_candidates > 32_768 + 1024
+    s.close()
+    check_search(oracle, idx, Qs, k=1000)
+
+
 def test_search_ties_keep_ascending_pid(oracle):
     """Duplicate passages score identically; the stable sortperm keeps the lower pid first."""
     idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
