@@ -661,6 +661,12 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
     int b_first, b_step, sub, nsub;
     if (B >= 8) { b_first = x; b_step = 8; sub = 0; nsub = 1; }
     else { b_first = x % B; b_step = B * 8 /* one query per group */; sub = x / B; nsub = (8 - b_first + B - 1) / B; }
+    // 2-D launch (grid = (G, B)): work-group blockIdx.x of query blockIdx.y -- used by the row-mask sweep, whose few
+    // passages per query are better spread over few, long-running waves than over every XCD group
+    const bool grid2d = gridDim.y > 1;
+    const int wg_count = grid2d ? (int)gridDim.x : wg_per_group;
+    const int wg_index = grid2d ? (int)blockIdx.x : wg;
+    if (grid2d) { b_first = blockIdx.y; b_step = B; sub = 0; nsub = 1; }
 
     for (int b = b_first; b < B; b += b_step) {
         // B operand: Q[t][32g + 8s + j] for token tiles 0/1, k-steps s = 0..3
@@ -688,13 +694,13 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         unsigned long long* rmask = ROWS ? rowmask + (size_t)b * cand_cap * 4 : nullptr;
         const float window = ROWS ? 2.f * eps_pair[b] : 0.f;
         const int n = ROWS ? nlist[b] : ncand[b];
-        const int stride = wg_per_group * 4 * nsub;
+        const int stride = wg_count * 4 * nsub;
         unsigned long long wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;   // ROWS: the current passage's mask (wave-uniform)
 
         // ---- wave-uniform iterator over the steps of passages j0, j0+stride, ... ------------------------------
         // The headers {first embedding, length} of the wave's next 64 passages sit in one VGPR pair (lane k =
         // k-th passage) and are extracted with v_readlane: no memory wait at a passage switch.
-        for (int j0 = (sub * wg_per_group + wg) * 4 + wave; j0 < n; j0 += 64 * stride) {
+        for (int j0 = (sub * wg_count + wg_index) * 4 + wave; j0 < n; j0 += 64 * stride) {
         const int jl = j0 + lane * stride;
         int slot_l = jl < n ? jl : j0;                       // candidate slot of this lane's passage
         if (ROWS) slot_l = lst[slot_l];

@@ -337,8 +337,9 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (subset) {
         Timed t(s, KID_ROWS, st);
         // the pass-1 pipeline again, over the listed passages only: marks the rows that can hold a token maximum
-        static const int rows_wgpg = getenv("CLB_DEBUG_ROWS_WGPG") ? atoi(getenv("CLB_DEBUG_ROWS_WGPG")) : 128;
-        hipLaunchKernelGGL(score_approx_kernel<kVariantRows>, dim3(8 * rows_wgpg), dim3(256), 0, st, s->weights.as<float>(),
+        static const int rows_gx = getenv("CLB_DEBUG_ROWS_GX") ? atoi(getenv("CLB_DEBUG_ROWS_GX")) : 1024;
+        const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 128);
+        hipLaunchKernelGGL(score_approx_kernel<kVariantRows>, rows_grid, dim3(256), 0, st, s->weights.as<float>(),
                            s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                            (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint32_t>(), list, nlist, w.eps_pair.as<float>(),
