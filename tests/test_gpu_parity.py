@@ -376,6 +376,30 @@ def test_search_bounds_error_and_padding(oracle):
     s.close()
 
 
+def test_batch_nprobe1_and_short_results(oracle):
+    """A batch of 9 (shared-tile centroid kernel, 2-D row sweep) with nprobe = 1 and with k above the number of
+    candidates of every query: padded tails, otherwise the oracle's result."""
+    idx = synthetic.make_index(seed=21, n_docs=300, K=64)
+    Qs = synthetic.make_queries(idx, 22, 9)
+    s = clb.Searcher(index=idx)
+    try:
+        for mode in (0, 1):
+            s.set_mode(mode)
+            for nprobe in (1, 2):
+                k = 280
+                bp, bs, bn = s.search_batch(Qs, k, nprobe=nprobe, pad_short=True)
+                for j in range(9):
+                    n = int(bn[j])
+                    rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe, min(k, n))
+                    assert rn == n
+                    kk = min(k, n)
+                    assert np.array_equal(bp[:kk, j], rp), (mode, nprobe, j)
+                    assert_same_f32(bs[:kk, j], rs, f"mode={mode} nprobe={nprobe} q={j}")
+                    assert np.all(bp[kk:, j] == 0) and np.all(np.isneginf(bs[kk:, j]))
+    finally:
+        s.close()
+
+
 def test_create_rejects_bad_codes():
     idx = synthetic.make_index(seed=21, n_docs=50, K=16)
     bad = dict(idx); bad["codes"] = idx["codes"].copy(); bad["codes"][3] = 17
