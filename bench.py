@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-at-a-time latency loop (profiling runs)")
     ap.add_argument("--force-gather", action="store_true", help="exercise the all-gather + merge path even with one rank (testing)")
+    ap.add_argument("--uniform-codes", action="store_true",
+                    help="passages draw their centroid codes uniformly (worst case for the candidate count) instead of topically")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): anything libraries print while we run (RCCL prints a version
@@ -77,7 +79,7 @@ def main():
     t0 = time.time()
     K = synthetic.num_partitions_for(args.docs, 80.0)
     shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks,
-                                 blocks=range(rank * per, (rank + 1) * per))
+                                 blocks=range(rank * per, (rank + 1) * per), topical=not args.uniform_codes)
     t_gen = time.time() - t0
     t0 = time.time()
     s = clb.Searcher(index=shard, device=local_rank, pid_offset=int(shard["pid_offset"]))
@@ -226,7 +228,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}), "
+               "config": {"workload": f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}"
+                                      f"{', uniform codes' if args.uniform_codes else ''}), "
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
                           "search_mode": "two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass"},
