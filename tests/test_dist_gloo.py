@@ -89,3 +89,31 @@ def test_shard_bounds_balance_embeddings():
         assert off == b[r] and sub["ivf_lengths"].sum() == sub["codes"].size == sub["doclens"].sum()
         tot += sub["codes"].size
     assert tot == idx["codes"].size
+
+
+def test_block_generated_shards_equal_the_full_index():
+    """bench.py builds each rank's shard directly from its generation blocks; it must be the same passages the
+    full index holds (codes, residuals, doclens), with the right pid offset and a local IVF over the same codes."""
+    sys.path.insert(0, ROOT)
+    import colbert_jl_amd as clb
+    syn = clb.synthetic
+    full = syn.make_index(seed=2024, n_docs=4001, K=256, n_blocks=8)
+    off = np.concatenate([[0], np.cumsum(full["doclens"])])
+    per = -(-4001 // 8)
+    covered = 0
+    for world in (2, 4, 8):
+        nb = 8 // world
+        for rank in range(world):
+            sh = syn.make_index(seed=2024, n_docs=4001, K=256, n_blocks=8, blocks=range(rank * nb, (rank + 1) * nb))
+            p0 = rank * nb * per
+            p1 = min(4001, (rank + 1) * nb * per)
+            assert sh["pid_offset"] == p0
+            assert np.array_equal(sh["doclens"], full["doclens"][p0:p1])
+            assert np.array_equal(sh["codes"], full["codes"][off[p0]:off[p1]])
+            assert np.array_equal(sh["residuals"], full["residuals"][:, off[p0]:off[p1]])
+            assert np.array_equal(sh["centroids"], full["centroids"])
+            assert np.array_equal(sh["bucket_weights"], full["bucket_weights"])
+            ivf, lens = syn.build_ivf(sh["codes"], 256)
+            assert np.array_equal(sh["ivf"], ivf) and np.array_equal(sh["ivf_lengths"], lens)
+            covered += p1 - p0 if world == 8 else 0
+    assert covered == 4001

@@ -358,6 +358,34 @@ def test_device_merge_kernel_matches_unsharded(oracle):
         s.close()
 
 
+def test_bench_sharding_path_matches_unsharded(oracle):
+    """The exact data path of `bench.py --gpus N` on one GPU: shards generated per block range, device search with
+    packed outputs, the packed blocks stacked as an all-gather would, merged -- equal to the oracle on the full index."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch, merge_packed
+    full = synthetic.make_index(seed=2024, n_docs=6000, K=512, n_blocks=8)
+    Qs = synthetic.make_topic_queries(full["centroids"], seed=77, n_queries=9)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    k, world = 200, 4
+    packed, keep = [], []
+    for rank in range(world):
+        sh = synthetic.make_index(seed=2024, n_docs=6000, K=512, n_blocks=8, blocks=range(2 * rank, 2 * rank + 2))
+        s = clb.Searcher(index=sh, pid_offset=int(sh["pid_offset"]))
+        run = DeviceSearch(s, 32, 9, k, 2)
+        run(Qdev)
+        torch.cuda.synchronize()
+        packed.append(run.packed.clone()); keep.append(s)
+    mp, ms = merge_packed(torch.stack(packed), 9, k)
+    torch.cuda.synchronize()
+    mp = mp.cpu().numpy(); ms = ms.cpu().numpy()
+    for j in range(9):
+        rp, rs, _ = oracle.search(full, Qs[:, :, j], 2, k)
+        assert np.array_equal(mp[j], rp)
+        assert_same_f32(ms[j], rs, "bench sharding path")
+    for s in keep:
+        s.close()
+
+
 def test_search_bounds_error_and_padding(oracle):
     idx = synthetic.make_index(seed=19, n_docs=300, K=64)
     Q = synthetic.make_queries(idx, 20, 1)
