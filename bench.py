@@ -64,8 +64,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # COLBERT_BENCH_BACKEND / COLBERT_BENCH_DEVICE: test hooks to run several ranks on ONE GPU over gloo
+        # (RCCL refuses two ranks on the same device); the measured configuration is always nccl, one GPU per rank
+        backend = os.environ.get("COLBERT_BENCH_BACKEND", "nccl")
+        if "COLBERT_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["COLBERT_BENCH_DEVICE"])
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
