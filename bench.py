@@ -55,7 +55,7 @@ def main():
     import torch
     import colbert_jl_amd as clb
     from colbert_jl_amd import synthetic
-    from colbert_jl_amd.distributed import DeviceSearch, all_gather_packed, merge_packed
+    from colbert_jl_amd.distributed import DeviceSearch, all_gather_packed, all_gather_scores, merge_packed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +106,30 @@ def main():
               for _ in range(2)]
     comm = torch.cuda.Stream(device=dev) if gather else None
     free_ev = [None, None]          # buffer set i may be overwritten once its exchange has finished
+    # With several shards the search runs in two phases around a second, small all-gather (every shard's k largest
+    # approximate scores): all shards then cut at the GLOBAL k-th score and re-score ~k/N passages each instead of
+    # ~k.  COLBERT_BENCH_TWO_PHASE=0/1 overrides.
+    two_phase = gather and s.mode == 1 and (world >= 2 if "COLBERT_BENCH_TWO_PHASE" not in os.environ
+                                            else os.environ["COLBERT_BENCH_TWO_PHASE"] == "1")
+    import torch.distributed as _dist
+    gath = [torch.empty((max(world, 1) * B, k), dtype=torch.float32, device=dev) for _ in range(2)] if two_phase else None
+
+    def search_shard(r, Qb, i):
+        """This rank's part of one batch on the main stream (results in r.packed)."""
+        if not two_phase:
+            r(Qb)
+            return
+        main = torch.cuda.current_stream(dev)
+        lt = r.phase1(Qb)
+        e1 = torch.cuda.Event()
+        e1.record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(e1)
+            _dist.all_gather_into_tensor(gath[i & 1], lt)
+            e2 = torch.cuda.Event()
+            e2.record(comm)
+        main.wait_event(e2)
+        r.phase2(Qb, gath[i & 1].view(world, B, k))
 
     def step(i):
         off = (i * B) % (n_queries - B + 1)
@@ -115,7 +139,7 @@ def main():
         main = torch.cuda.current_stream(dev)
         if free_ev[i & 1] is not None:
             main.wait_event(free_ev[i & 1])
-        r(Qdev[off:off + B])
+        search_shard(r, Qdev[off:off + B], i)
         done = torch.cuda.Event()
         done.record(main)
         with torch.cuda.stream(comm):
@@ -162,7 +186,10 @@ def main():
     for i in range(0 if args.no_latency else 40):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        p, sc = one(Qdev[i:i + 1])
+        if two_phase:
+            one.phase2(Qdev[i:i + 1], all_gather_scores(one.phase1(Qdev[i:i + 1])))
+        else:
+            one(Qdev[i:i + 1])
         if gather:
             merge_packed(all_gather_packed(one.packed), 1, k)
         torch.cuda.synchronize()
@@ -219,7 +246,7 @@ def main():
         emb2pid = orc.build_emb2pid(shard["doclens"])
         idx = dict(shard, emb2pid=emb2pid)
         nq_cpu, t_cpu, ok = 0, 0.0, True
-        p, sc = run(Qdev[0:B]); torch.cuda.synchronize()
+        search_shard(run, Qdev[0:B], 0); p, sc = run.out_p, run.out_s; torch.cuda.synchronize()
         gp_host = p.cpu().numpy(); gs_host = sc.cpu().numpy()
         while nq_cpu < B and (t_cpu < args.cpu_seconds or nq_cpu == 0):
             t1 = time.perf_counter()
@@ -240,7 +267,8 @@ def main():
                                       f"{', uniform codes' if args.uniform_codes else ''}), "
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
-                          "search_mode": "two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass"},
+                          "search_mode": ("two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass")
+                                         + (", global threshold exchange between the passes" if two_phase else "")},
                "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
                "hbm_bytes": s.device_bytes}

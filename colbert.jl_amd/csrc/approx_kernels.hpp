@@ -899,7 +899,8 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    size_t cand_cap, ApproxConsts ac,
                                                                    int* __restrict__ list, int* __restrict__ nlist,
                                                                    float* __restrict__ thresh,
-                                                                   float* __restrict__ eps_pair) {
+                                                                   float* __restrict__ eps_pair,
+                                                                   const float* __restrict__ tau_in = nullptr) {
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[16];
     __shared__ uint32_t s_prefix, s_kmin, s_kmax;
@@ -960,7 +961,13 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             __VA_ARGS__                                                                         \
         }                                                                                       \
     }
-    if (n > k) {
+    if (tau_in) {
+        // sharded search, phase 2: tau is the GLOBAL k-th approximate score over all shards (global_tau_kernel); -inf
+        // means fewer than k candidates exist anywhere, i.e. everything is listed
+        eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
+        tau_f = tau_in[b];
+        thr = tau_f == kNegInf ? kNegInf : tau_f - 2.f * eps;
+    } else if (n > k) {
         CLB_RADIX_SELECT()
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
         tau_f = f32_from_order_key(s_prefix);
@@ -1023,6 +1030,66 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         thresh[2 * b] = tau_f;
         thresh[2 * b + 1] = eps;
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Sharded search (one shard per GPU).  A shard has to hand the merge ITS k best passages, so on its own it must
+// cut at the shard-local k-th approximate score -- with 8 shards that lists (and re-scores exactly) 8x more
+// passages than the global top-k needs.  Exchange between the two phases: every shard publishes its k largest
+// approximate scores per query (local_top_kernel); the k-th largest of their union IS the global k-th approximate
+// score (the global top-k by approximate score is a subset of the union of the local ones), and the proof of the
+// two-pass mode then holds with that tau: every member of the exact global top-k has approx >= tau - 2 eps.
+// -------------------------------------------------------------------------------------------------------------
+// out[b][0..k): the approximate scores >= the local tau (at most k of them; ties beyond k are equal values and can be
+// dropped), padded with -inf.  grid = B, block = 1024.
+static __global__ __launch_bounds__(1024) void local_top_kernel(const float* __restrict__ scores,
+                                                               const int* __restrict__ list,
+                                                               const int* __restrict__ nlist,
+                                                               const float* __restrict__ thresh, int k,
+                                                               size_t cand_cap, float* __restrict__ out) {
+    __shared__ int s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const float tau = thresh[2 * b];                       // -inf when the shard has at most k candidates
+    const float* sc = scores + (size_t)b * cand_cap;
+    const int* lst = list + (size_t)b * cand_cap;
+    float* o = out + (size_t)b * k;
+    const int n = nlist[b];
+    for (int i = tid; i < n; i += 1024) {
+        const float v = sc[lst[i]];
+        if (v >= tau) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < k) o[pos] = v;
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt < k ? s_cnt : k;
+    for (int i = cnt + tid; i < k; i += 1024) o[i] = kNegInf;
+}
+
+// tau_glob[b] = the k-th largest of the n_shards * k gathered values all_top[shard][b][i] (-inf when fewer than k
+// finite values exist).  grid = B, block = 1024.
+static __global__ __launch_bounds__(1024) void global_tau_kernel(const float* __restrict__ all_top, int n_shards,
+                                                                int B, int k, float* __restrict__ tau_glob) {
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ uint32_t s_prefix, s_kmin, s_kmax;
+    __shared__ int s_remaining;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = n_shards * k;
+    const int chunk = (n + 1023) >> 10;
+#define CLB_SEL_FOR_EACH(...)                                                                   \
+    for (int c = 0; c < chunk; ++c) {                                                           \
+        const int i_ = c * 1024 + tid;                                                          \
+        const bool valid = i_ < n;                                                              \
+        const uint32_t key = valid ? f32_order_key(all_top[((size_t)(i_ / k) * B + b) * k + (i_ % k)]) : 0u; \
+        __VA_ARGS__                                                                             \
+    }
+    if (tid == 0) { s_prefix = 0u; s_remaining = k; }
+    __syncthreads();
+    CLB_RADIX_SELECT()
+#undef CLB_SEL_FOR_EACH
+    if (tid == 0) tau_glob[b] = f32_from_order_key(s_prefix);
 }
 
 static __global__ void max_abs_kernel(const float* __restrict__ v, int n, unsigned int* __restrict__ out_bits) {

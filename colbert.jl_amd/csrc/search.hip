@@ -54,7 +54,7 @@ struct Workspace {
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob;
 };
 
 struct clb_searcher {
@@ -297,14 +297,34 @@ int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int
 }
 
 // The whole search for B device-resident queries, enqueued on st.
+// phase 0: the whole search.  Sharded search in two calls (clb_search_shard_phase1/2, two-pass mode only):
+// phase 1 = candidate generation, pass 1, local selection, and the shard's k largest approximate scores per query
+// to `d_local_top`; phase 2 = global tau from the gathered scores `d_all_top` ([n_shards][B][k]), selection at that
+// tau, pass 2, top-k.  Phase 2 continues on the workspace phase 1 left behind.
 int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
-               int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr) {
-    CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
+               int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr, int phase = 0,
+               float* d_local_top = nullptr, const float* d_all_top = nullptr, int n_shards = 0) {
     const int kpow2 = next_pow2(k);
-    if (s->prof.counters) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
     const int* list = nullptr;
     const int* nlist = nullptr;
-    if (s->mode == 1 && s->approx_ok && T <= 32) {
+    const bool two_pass = s->mode == 1 && s->approx_ok && T <= 32;
+    if (phase != 0 && !two_pass) return fail(CLB_EUNSUPPORTED, "the two-phase sharded search needs the two-pass mode");
+    if (phase == 2) {
+        CLB_TRY(w.tau_glob.ensure(sizeof(float) * B));
+        hipLaunchKernelGGL(global_tau_kernel, dim3(B), dim3(1024), 0, st, d_all_top, n_shards, B, k,
+                           w.tau_glob.as<float>());
+        Timed t(s, KID_SELECT, st);
+        hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(),
+                           w.ncand.as<int>(), dQ, T, k, w.cand_cap, s->approx_consts, w.list.as<int>(),
+                           w.nlist.as<int>(), w.thresh.as<float>(), w.eps_pair.as<float>(),
+                           (const float*)w.tau_glob.as<float>());
+        list = w.list.as<int>();
+        nlist = w.nlist.as<int>();
+    }
+    if (phase != 2) {
+    CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
+    if (s->prof.counters) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
+    if (two_pass) {
         {
             Timed t(s, KID_SCORE_APPROX, st);
             static const int variant = getenv("CLB_DEBUG_APPROX_VARIANT") ? atoi(getenv("CLB_DEBUG_APPROX_VARIANT")) : 0;
@@ -331,6 +351,13 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         }
         list = w.list.as<int>();
         nlist = w.nlist.as<int>();
+    }
+    }   // phase != 2
+    if (phase == 1) {
+        hipLaunchKernelGGL(local_top_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), list, nlist,
+                           w.thresh.as<float>(), k, w.cand_cap, d_local_top);
+        CLB_HIP(hipGetLastError());
+        return CLB_OK;
     }
     static const bool no_subset = getenv("CLB_DEBUG_NO_SUBSET") != nullptr;
     const bool subset = list && !no_subset;   // two-pass mode (nbits 2, T <= 32): re-score only the rows that matter
@@ -510,7 +537,7 @@ int64_t clb_searcher_device_bytes(const clb_searcher* s) {
     int64_t tot = s->index_bytes;
     for (const auto& w : s->ws) {
         const DevBuf* bufs[] = {&w.Qdev, &w.cells, &w.cells_q, &w.partial, &w.sel, &w.bitmap, &w.blocksum, &w.ncand, &w.cand,
-                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax};
+                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax, &w.tau_glob};
         for (auto* b : bufs) tot += (int64_t)b->bytes;
     }
     return tot;
@@ -535,6 +562,30 @@ int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores, d_n_cand));
     return CLB_OK;
+}
+
+int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                            float* d_local_top, void* hip_stream) {
+    CLB_TRY(check_search_args(s, T, B, nprobe, k));
+    if (!d_local_top) return fail(CLB_EARGUMENT, "d_local_top is null");
+    CLB_TRY(use_device(s->device));
+    Workspace& w = s->ws[0];
+    CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
+    return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, nullptr, nullptr, nullptr,
+                      1, d_local_top);
+}
+
+int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                            const float* d_all_top, int64_t n_shards, int64_t* d_out_pids, float* d_out_scores,
+                            int64_t* d_n_cand, void* hip_stream) {
+    CLB_TRY(check_search_args(s, T, B, nprobe, k));
+    if (!d_all_top || n_shards < 1) return fail(CLB_EARGUMENT, "d_all_top is null or n_shards < 1");
+    CLB_TRY(use_device(s->device));
+    Workspace& w = s->ws[0];
+    if (B > w.Bcap || T > w.Tcap || nprobe > w.npcap || k > w.kcap)
+        return fail(CLB_EARGUMENT, "clb_search_shard_phase2 without a matching clb_search_shard_phase1");
+    return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores,
+                      d_n_cand, 2, nullptr, d_all_top, (int)n_shards);
 }
 
 int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,

@@ -64,6 +64,17 @@ def merge_packed(gathered, B: int, k: int, out_p=None, out_s=None):
     return out_p, out_s
 
 
+def all_gather_scores(local_top, group=None):
+    """(B, k) fp32 -> (world, B, k): the exchange between the two phases of the sharded search."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    B, k = local_top.shape
+    out = torch.empty((world * B, k), dtype=local_top.dtype, device=local_top.device)
+    dist.all_gather_into_tensor(out, local_top.contiguous(), group=group)
+    return out.view(world, B, k)
+
+
 def merge_gathered(gp, gs, k: int, device_index=None, out_p=None, out_s=None):
     """(world, B, k) gathered records -> (B, k) merged top-k.  GPU tensors go through the HIP merge
     kernel (clb_merge_topk_device) on torch's current stream; CPU tensors through the host merge."""
@@ -121,6 +132,29 @@ class DeviceSearch:
         self.out_p = self.packed[:B * k * 8].view(torch.int64).view(B, k)
         self.out_s = self.packed[B * k * 8:B * k * 12].view(torch.float32).view(B, k)
         self.ncand = torch.zeros(B, dtype=torch.int64, device=self.dev)
+
+    def phase1(self, Qdev):
+        """Two-phase sharded search, first half (clb_search_shard_phase1): everything up to pass 1 on this shard.
+        Returns the (B, k) tensor of the shard's k largest approximate scores per query, to be all-gathered."""
+        import torch
+        if not hasattr(self, "local_top"):
+            self.local_top = torch.empty((self.B, self.k), dtype=torch.float32, device=self.dev)
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        check(lib().clb_search_shard_phase1(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
+                                            i64(self.nprobe), i64(self.k), C.c_void_p(self.local_top.data_ptr()),
+                                            C.c_void_p(st)))
+        return self.local_top
+
+    def phase2(self, Qdev, all_top):
+        """Second half (clb_search_shard_phase2).  all_top: (n_shards, B, k) gathered `local_top` blocks."""
+        import torch
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        check(lib().clb_search_shard_phase2(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
+                                            i64(self.nprobe), i64(self.k), C.c_void_p(all_top.data_ptr()),
+                                            i64(all_top.shape[0]), C.c_void_p(self.out_p.data_ptr()),
+                                            C.c_void_p(self.out_s.data_ptr()), C.c_void_p(self.ncand.data_ptr()),
+                                            C.c_void_p(st)))
+        return self.out_p, self.out_s
 
     def __call__(self, Qdev):
         """Qdev: torch float32 tensor holding B queries laid out (B, T, dim) contiguous == Julia (dim, T, B)."""

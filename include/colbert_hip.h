@@ -77,6 +77,18 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                             void* hip_stream);
+/* Sharded (multi-GPU) search in two calls, so that every shard cuts at the GLOBAL k-th approximate score instead
+ * of its own (a shard must otherwise re-score ~k passages exactly however small it is).  Two-pass mode only
+ * (CLB_EUNSUPPORTED otherwise: use clb_search_batch_device).
+ *   phase 1: S1..pass 1 on this shard; d_local_top (B, k) = its k largest approximate scores per query (-Inf padded);
+ *   the caller all-gathers these blocks over the shards: d_all_top = [n_shards][B][k];
+ *   phase 2: selection at the k-th largest gathered score, exact pass, top-k -- outputs as clb_search_batch_device.
+ * Phase 2 must follow phase 1 of the same batch on the same handle and stream. */
+int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                            float* d_local_top, void* hip_stream);
+int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
+                            const float* d_all_top, int64_t n_shards, int64_t* d_out_pids, float* d_out_scores,
+                            int64_t* d_n_cand, void* hip_stream);
 /* 0: exact single pass (every candidate scored with the canonical fp32 arithmetic);
  * 1: two-pass (bf16-MFMA approximate pass with a proven error bound selects a superset of the top-k,
  *    which is then re-scored exactly) -- results are identical by construction.  Default 1 when the

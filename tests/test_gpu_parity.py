@@ -386,6 +386,46 @@ def test_bench_sharding_path_matches_unsharded(oracle):
         s.close()
 
 
+@pytest.mark.parametrize("world,k", [(4, 200), (8, 1000), (2, 5000)])
+def test_two_phase_sharded_search(oracle, world, k):
+    """clb_search_shard_phase1/2 on `world` shards of one index (the all-gather is simulated by stacking the shards'
+    score blocks): every shard cuts at the global k-th approximate score, the merged result equals the oracle's on
+    the full index, and the shards together list far fewer passages than with shard-local thresholds.  k = 5000
+    exceeds what some queries can return (padding, tau = -inf)."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch, merge_packed
+    full = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8)
+    Qs = synthetic.make_topic_queries(full["centroids"], seed=78, n_queries=9)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    per = 8 // world
+    kk = min(k, 4096)
+    runs, keep = [], []
+    for rank in range(world):
+        sh = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8, blocks=range(per * rank, per * rank + per))
+        s = clb.Searcher(index=sh, pid_offset=int(sh["pid_offset"]))
+        runs.append(DeviceSearch(s, 32, 9, kk, 2)); keep.append(s)
+    tops = torch.stack([r.phase1(Qdev).clone() for r in runs])           # (world, B, k) as an all-gather delivers
+    torch.cuda.synchronize()
+    packed = []
+    for r in runs:
+        r.phase2(Qdev, tops)
+        torch.cuda.synchronize()
+        packed.append(r.packed.clone())
+    mp, ms = merge_packed(torch.stack(packed), 9, kk)
+    torch.cuda.synchronize()
+    mp = mp.cpu().numpy(); ms = ms.cpu().numpy()
+    for j in range(9):
+        n_all = oracle.retrieve(full["ivf"], full["ivf_lengths"], full["centroids"],
+                                oracle.build_emb2pid(full["doclens"]), 2, Qs[:, :, j]).size
+        ke = min(kk, n_all)
+        rp, rs, _ = oracle.search(full, Qs[:, :, j], 2, ke)
+        assert np.array_equal(mp[j, :ke], rp), (world, j)
+        assert_same_f32(ms[j, :ke], rs, "two-phase sharded search")
+        assert np.all(mp[j, ke:] == 0)
+    for s in keep:
+        s.close()
+
+
 def test_search_bounds_error_and_padding(oracle):
     idx = synthetic.make_index(seed=19, n_docs=300, K=64)
     Q = synthetic.make_queries(idx, 20, 1)
