@@ -1020,6 +1020,10 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     const float* sc = scores + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
     const int keff = n < k ? n : k;
+    // sort only as many slots as this query fills: a shard of a multi-GPU run often holds far fewer than k
+    int kp = 1;
+    while (kp < keff) kp <<= 1;
+    kp = kp < kpow2 ? kp : kpow2;
     if (tid == 0) {
         short_flag[b] = n < k ? 1 : 0;
         if (n_cand_out) n_cand_out[b] = ncand[b];
@@ -1088,7 +1092,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     const int need_eq = s_remaining;  // how many of the == tau entries to take, lowest index first
 
     // ---- ordered compaction: one block-wide scan of the per-thread (#gt, #eq) counts ---------------
-    for (int i = tid; i < kpow2; i += 1024) skeys[i] = 0ull;
+    for (int i = tid; i < kp; i += 1024) skeys[i] = 0ull;
     __syncthreads();
     if (keff > 0) {
         int ngt = 0, neq = 0;
@@ -1122,11 +1126,11 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     // pair i of a step touches elements inside the 128-aligned tile of its wave whenever stride <= 64, so only the
     // wide strides need the block barrier (6 of the 55 steps at k = 1000)
     __syncthreads();   // the compaction above wrote skeys from arbitrary threads
-    for (int size = 2; size <= kpow2; size <<= 1) {
+    for (int size = 2; size <= kp; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 64 || (kpow2 >> 1) > 1024) __syncthreads();
+            if (stride >= 64 || (kp >> 1) > 1024) __syncthreads();
             else __builtin_amdgcn_wave_barrier();
-            for (int i = tid; i < (kpow2 >> 1); i += 1024) {
+            for (int i = tid; i < (kp >> 1); i += 1024) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool desc = (lo & size) == 0;
