@@ -32,6 +32,10 @@ struct Prof {
     bool counters = false;  // additionally count the work of each batch (one extra kernel per batch)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KID_COUNT];
     std::vector<hipEvent_t> pool;
+    // end event of the previous timed kernel: the next timed kernel on the same stream starts from it instead of
+    // recording its own start (half the event records per batch).  Cleared wherever untimed work is enqueued.
+    hipEvent_t chain = nullptr;
+    hipStream_t chain_stream = nullptr;
     double total_ms[KID_COUNT] = {0};
     int64_t launches[KID_COUNT] = {0};
     hipEvent_t get() {
@@ -92,15 +96,21 @@ struct Timed {
     hipEvent_t a = nullptr, b = nullptr;
     Timed(clb_searcher* s_, int id_, hipStream_t st_) : s(s_), id(id_), st(st_) {
         if (s->prof.on) {
-            a = s->prof.get();
+            if (s->prof.chain && s->prof.chain_stream == st) {
+                a = s->prof.chain;
+            } else {
+                a = s->prof.get();
+                (void)hipEventRecord(a, st);
+            }
             b = s->prof.get();
-            (void)hipEventRecord(a, st);
         }
     }
     ~Timed() {
         if (s->prof.on) {
             (void)hipEventRecord(b, st);
             s->prof.pending[id].push_back({a, b});
+            s->prof.chain = b;
+            s->prof.chain_stream = st;
         }
     }
 };
@@ -261,6 +271,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             else if (NPs == 8) launch_topn<8>(s, w, st, B, Tpad);
             else launch_topn<32>(s, w, st, B, Tpad);
         }
+        s->prof.chain = nullptr;   // untimed conversion below
         if (want_half)
             hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
                                w.cells.as<float>(), w.cells_q.as<uint32_t>(), (int)s->K);
@@ -307,6 +318,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     const int kpow2 = next_pow2(k);
     const int* list = nullptr;
     const int* nlist = nullptr;
+    s->prof.chain = nullptr;           // the first timed kernel of a call records its own start
     const bool two_pass = s->mode == 1 && s->approx_ok && T <= 32;
     if (phase != 0 && !two_pass) return fail(CLB_EUNSUPPORTED, "the two-phase sharded search needs the two-pass mode");
     if (phase == 2) {
@@ -323,7 +335,10 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     }
     if (phase != 2) {
     CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
-    if (s->prof.counters) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
+    if (s->prof.counters) {
+        CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
+        s->prof.chain = nullptr;
+    }
     if (two_pass) {
         {
             Timed t(s, KID_SCORE_APPROX, st);
@@ -738,6 +753,8 @@ int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int6
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     int n = 0;
+    std::vector<hipEvent_t> seen;       // chained kernels share events: every event goes back to the pool once
+    s->prof.chain = nullptr;
     for (int id = 0; id < KID_COUNT && n < cap; ++id) {
         for (auto& pr : s->prof.pending[id]) {
             float ms = 0.f;
@@ -745,8 +762,8 @@ int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int6
                 s->prof.total_ms[id] += ms;
                 s->prof.launches[id] += 1;
             }
-            s->prof.pool.push_back(pr.first);
-            s->prof.pool.push_back(pr.second);
+            seen.push_back(pr.first);
+            seen.push_back(pr.second);
         }
         s->prof.pending[id].clear();
         names[n] = kKernelNames[id];
@@ -756,6 +773,9 @@ int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int6
         s->prof.launches[id] = 0;
         ++n;
     }
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    s->prof.pool.insert(s->prof.pool.end(), seen.begin(), seen.end());
     return n;
 }
 
