@@ -13,7 +13,7 @@
 // The approximation (per query token t and embedding e, x = c + r the decompressed vector, den = ||x|| + eps32):
 //     S[t][e] = Q_t . x / den  =  ( Q_t . c  +  Q_t . r ) * inv_norm[e]
 //   * Q_t . c  = cells[t][code]  -- already computed exactly by centroid_scores_kernel (S1); stored for this
-//                pass as fp16 pairs [K][16]{t, t+16} (64 B per centroid) to halve the gather;
+//                pass as fp16 rows [K][32 tokens] (64 B per centroid) to halve the gather;
 //   * Q_t . r  -- r[d] = bucket_weight[idx[d]] takes only 2^nbits values: a 4-entry bf16 LUT applied with
 //                v_perm_b32 to 2 dims at a time (selector built from the packed nibble with one u24 multiply),
 //                fed as the A operand of v_mfma_f32_16x16x32_bf16 against bf16(Q) -- no centroid row is read,
@@ -25,7 +25,8 @@
 // Error bound (u = 2^-24; qn = max_t ||Q_t||2; cn = max ||c||2; rn = sqrt(dim) * max|w| >= ||r||2;
 // im = max inv_norm), per (t, e):
 //   cells:   bf16x3 MFMA value vs canonical fp32 chain <= 1.25*7.4e-5*qn*cn       (centroid_top_bf16x3_kernel)
-//            fp16 storage                            <= 2^-11 * qn*cn          (|cells| <= qn*cn < 65504)
+//            fp16 storage                            <= 2^-11 * qn*cn + 2^-25  (|cells| <= qn*cn < 65504: guarded in
+//                                                       select_margin_kernel; 2^-25: values below the normal range)
 //   Q.r:     bf16(Q), bf16(w) relative 2^-9 each     <= (2^-8 + 2^-18) * qn*rn
 //            fp32 accumulation in the MFMA           <= 2*128*u*qn*rn
 //   scaling: add, multiply, inv_norm rounding        <= 8*u*qn
@@ -262,10 +263,10 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (WRITE_HALF) {
-                const float other = __shfl_xor(acc[r], 16, 64);
-                if ((i & 16) == 0 && c < K) {
+                const float other = __shfl_xor(acc[r], 1, 64);     // token i ^ 1, same centroid row
+                if ((i & 1) == 0 && c < K) {                       // row of 32 fp16 in token order: pairs {i, i+1}
                     const __half2 hv = __floats2half2_rn(acc[r], other);
-                    cells16[((size_t)b * K + c) * 16 + i] = *reinterpret_cast<const uint32_t*>(&hv);
+                    cells16[((size_t)b * K + c) * 16 + (i >> 1)] = *reinterpret_cast<const uint32_t*>(&hv);
                 }
             }
         }
@@ -385,11 +386,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * tile + h);
         topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * tile + h);
         if (WRITE_HALF) {
-            // the tile's 32 x 32 scores leave as one contiguous 2-KB block of fp16 pairs {t, t+16}: transposed through
+            // the tile's 32 x 32 scores leave as one contiguous 2-KB block of fp16 rows [centroid][token]: transposed through
             // a per-wave LDS patch (16 ds_write_b16 + 2 ds_read_b128) so that the wave issues 2 full-width stores
             // instead of 16 quarter-filled ones
             unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 2048;
-            const int pos = 2 * (i & 15) + (i >> 4);           // halfword of token i inside its centroid's 64 B
+            const int pos = i;                                 // halfword of token i inside its centroid's 64 B
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 __builtin_amdgcn_wave_barrier();
@@ -568,7 +569,7 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
     }
 }
 
-// ---- cells fp32 [K][Tpad=32] -> fp16 pairs [K][16] {t, t+16}.  grid = (blocks, B), block = 256 -----------------
+// ---- cells fp32 [K][Tpad=32] -> fp16 [K][32] in token order.  grid = (blocks, B), block = 256 -----------------
 static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* __restrict__ cells,
                                                                   uint32_t* __restrict__ cells16, int K) {
     const int b = blockIdx.y;
@@ -578,40 +579,48 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t c = i >> 4;
         const int t = (int)(i & 15);
-        const float lo = src[c * 32 + t], hi = src[c * 32 + 16 + t];
+        const float lo = src[c * 32 + 2 * t], hi = src[c * 32 + 2 * t + 1];
         const __half2 h = __floats2half2_rn(lo, hi);
         dst[i] = *reinterpret_cast<const uint32_t*>(&h);
     }
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// Pass 1.  One wave per candidate passage, 16 embeddings per step:
-//   A (16 x 32 per k-step) = bf16 bucket weights of the embeddings, built in registers from 8 packed bytes/lane;
-//   B (32 x 16)            = bf16 query tokens, resident in registers (2 token tiles x 4 k-steps x 4 VGPRs);
-//   lane (r = lane&15, g = lane>>4) owns dims [32g, 32g+32) of embedding r (bytes 8g..8g+7 of its residual) --
-//   the k index of the MFMA is a permutation of the dims, applied identically to both operands.
-//   Epilogue: lane (c = lane&15, g') holds rows 4g'+reg: (acc + cells16[code][c]) * inv_norm, running max.
-// Work-groups are dealt to queries by `blockIdx.x % 8` (the label of the XCD they share under round-robin
-// placement -- a speed heuristic only): all work-groups of one XCD gather from ONE query's cells table at a
-// time, which keeps that table in the XCD's L2.
-// grid = 8 * wg_per_group, block = 256.
+// Pass 1.  A wave walks its candidate passages in steps of 32 embeddings; one step is one 32 x 32 tile
+// S[e][t] = ( X[code_e][t] + sum_d w[idx_e,d] * Q[t][d] ) * inv_norm[e]  on v_mfma_f32_32x32x16:
+//   * Q.r: A (32 embeddings x 16 dims per k-step) = bf16 bucket weights expanded from the packed residual through a
+//     2-KB LDS table (one ds_read_b64 per residual byte: 4 dims); lane (r = lane & 31, h = lane >> 5) owns bytes
+//     16h .. 16h+15 of embedding r -- ONE 16-byte load per lane and step -- i.e. dims 64h + 8s + j in k-step s;
+//     B = bf16(Q) resident in registers in the same dim order (8 k-steps x 4 VGPRs);
+//   * X (the fp16 centroid scores of S1, rows of 32 tokens = 64 B): two more MFMAs (f16 inputs) against a 0/1
+//     selection matrix ADD the gathered row into the accumulator: lane (r, h) fetches tokens 8h..8h+7 and
+//     16+8h..16+8h+7 of row code_r as two 16-byte loads, which are exactly the A fragments of those MFMAs (k = token).
+//     No fp16->fp32 conversion, no transposition, and 2 wide gather instructions per 32 embeddings where the 16-row
+//     kernel of round 1 issued 8 dword gathers (that kernel was bound by its request count, not its bytes);
+//   * inv_norm: one dword per lane (embedding r), moved to the accumulator layout (lane = token, register = row)
+//     through a 128-byte per-wave LDS patch: 1 ds_write_b32 + 4 ds_read_b128;
+//   * epilogue: 16 multiplies + 8 v_max3 per lane; at a passage's last step the two lane halves are combined and the
+//     32 per-token maxima summed.
+// Rows past the end of a passage (tail step) are DUPLICATES of the passage's last row -- the lane clamps its row
+// index before it forms any address, so residual, code, score row and inv_norm all belong to that row -- and a
+// duplicate cannot change a maximum: no masking anywhere, and no bytes fetched from behind the passage.
+// Software pipeline, three steps in flight per wave: A(i+2) residual + code loads; G(i+1) score-row gather + inv_norm
+// (both need A's data: the code, resp. nothing); C(i) compute.  The loop body is branch-free apart from the
+// end-of-passage store; steps past the end of the wave's work are redirected to embedding 0 and discarded.
+// Work-groups are dealt to queries by `blockIdx.x % 8` (the label of the XCD they share under round-robin placement
+// -- a speed heuristic only): the work-groups of one XCD gather from ONE query's score table at a time.
+// grid = 8 * wg_per_group (1-D) or (G, B) (2-D: few passages per query), block = 256.
 // -------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// Software pipeline, three 16-embedding steps in flight per wave (the code -> cells gather is a dependent
-// memory chain, and one step per wave leaves the kernel latency-bound):
-//   stage A(i+2): stream loads (8 residual bytes/lane, 4 codes, 4 inv_norms)
-//   stage G(i+1): gather the fp16 centroid scores of the 4 rows (needs A's codes)
-//   stage C(i)  : LUT expansion, 8 MFMAs, scale, running max; at a passage's last step reduce and store.
-// The loop body is branch-free apart from that store: steps past the end of the wave's work are redirected
-// to an always-valid dummy address and discarded, so the compiler can keep exact vmcnt counts.
 struct StepTag {      // wave-uniform description of a step
-    int j;            // candidate slot, -1 = dummy
-    int rows;         // valid rows (1..16)
+    int j;            // candidate slot (ROWS: list position), -1 = dummy
+    int rows;         // valid rows (1..32)
     int last;         // 1 = last step of its passage
     int base;         // index of the step's first embedding inside its passage
 };
 
-constexpr int kVariantRows = 6;
+constexpr int kStepRows = 32;      // embeddings per step; codes0 / residuals / inv_norm are padded by this many entries
 
 // fp32 -> fp16 rounded toward -inf (a lower bound of x that is at most one fp16 ulp away)
 __device__ __forceinline__ uint32_t f32_to_f16_floor(float x) {
@@ -621,75 +630,94 @@ __device__ __forceinline__ uint32_t f32_to_f16_floor(float x) {
     return bits;
 }
 
-// VARIANT 0: pass 1 as described above; besides the score it leaves tokmax[b][slot][16] = fp16 pairs {t, t+16} of
-//            the per-token maxima a_t = max_j A[t][j] of every candidate passage, rounded DOWN.
-// VARIANT kVariantRows: pass 2 preparation over the passages in `list` -- which embeddings of a listed passage can
-//            hold a per-token maximum?  With |A - S| <= e (e = eps_pair[b]) the exact argmax j* of token t satisfies
-//            A[t][j*] >= S[t][j*] - e >= S[t][ja] - e >= a_t - 2e (ja = the approximate argmax).  So the exact
-//            kernel only has to decompress and multiply the rows J = { j : exists t, A[t][j] >= a_t - 2e } --
-//            typically a third of the passage -- and still finds the identical per-token maxima, hence the identical
-//            fp32 score.  The sweep recomputes A with the same pipeline, compares against the stored (floored, so
-//            only more permissive) a_t and writes rowmask[b][list position][4] x 64 bits; passages longer than
-//            kMaxMaskedRows embeddings are ignored downstream (the exact kernel then takes every row).
-// VARIANTs 2..5 are the ablations quoted in DESIGN.md.
-template <int VARIANT>
-static __global__ __launch_bounds__(256) void score_approx_kernel(
+// (byte n of word R) * 8 -- the LDS table offset of that residual byte -- in ONE VALU op (SDWA byte select)
+template <int N>
+__device__ __forceinline__ uint32_t byte_times8(uint32_t R, uint32_t three) {
+    uint32_t a;
+    if (N == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(three), "v"(R));
+    if (N == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(three), "v"(R));
+    if (N == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(three), "v"(R));
+    if (N == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(three), "v"(R));
+    return a;
+}
+
+// ROWS = false: pass 1 over every candidate; besides the score it leaves tokmax[b][slot][32] = the per-token maxima
+//        a_t = max_j A[t][j] of every candidate passage as fp16 rounded DOWN.
+// ROWS = true:  pass 2 preparation over the passages in `list` -- which embeddings of a listed passage can hold a
+//        per-token maximum?  With |A - S| <= e (e = eps_pair[b]) the exact argmax j* of token t satisfies
+//        A[t][j*] >= S[t][j*] - e >= S[t][ja] - e >= a_t - 2e (ja = the approximate argmax).  So the exact kernel only
+//        has to decompress and multiply the rows J = { j : exists t, A[t][j] >= a_t - 2e } -- typically a third of the
+//        passage -- and still finds the identical per-token maxima, hence the identical fp32 score.  The sweep
+//        recomputes A with the same pipeline (bit-identical values), compares against the stored (floored, so only
+//        more permissive) a_t and writes rowmask[b][list position][4] x 64 bits; passages longer than kMaxMaskedRows
+//        embeddings are ignored downstream (the exact kernel then takes every row).  Comparisons are written
+//        !(v < lo): a NaN or an infinite window (guarded query, select_margin_kernel) selects the row.
+template <bool ROWS>
+static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
     const float* __restrict__ inv_norm, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
-    int B, size_t cand_cap, uint32_t* __restrict__ tokmax, const int* __restrict__ list,
+    int B, size_t cand_cap, uint16_t* __restrict__ tokmax, const int* __restrict__ list,
     const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask) {
-    constexpr bool ROWS = VARIANT == kVariantRows;
     const int lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = lane & 31, h = lane >> 5;
     const int x = blockIdx.x & 7;             // XCD group label
     const int wg = blockIdx.x >> 3;           // index inside the group
     const int wg_per_group = gridDim.x >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // byte LUT in LDS: blut[v] = bf16 bucket weights of the 4 dims packed in byte v (LSB-first 2-bit fields)
     __shared__ uint2 blut[256];
+    __shared__ __attribute__((aligned(16))) float invx[4][kStepRows];
     {
         const int v = threadIdx.x;
         blut[v] = make_uint2(pack_bf16(weights[v & 3], weights[(v >> 2) & 3]),
                              pack_bf16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
     }
     __syncthreads();
-    uint32_t kmask = 0x06060606u;
-    const uint32_t lane_res = (uint32_t)(r * 32 + 8 * g);   // byte offset of this lane's residual bytes in a step
-    const uint32_t lane_row = (uint32_t)(4 * g);            // first of the 4 rows this lane finishes
+    const char* lut = reinterpret_cast<const char*>(blut);
+    float* myinv = invx[wave];
+    uint32_t three = 3u;
+    asm volatile("" : "+v"(three));           // keep the SDWA shift amount in a VGPR
+
+    // selection matrices of the two score-row MFMAs: B1[k][col] = (col == k), B2[k][col] = (col == 16 + k), with
+    // k = 8h + j held by lane (col = r, h) in element j
+    f16x8 sel1, sel2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sel1[j] = (r == 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
+        sel2[j] = (r == 16 + 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    const uint32_t lane_res = (uint32_t)(r * 32 + 16 * h);   // byte offset of this lane's residual bytes in a step
 
     int b_first, b_step, sub, nsub;
     if (B >= 8) { b_first = x; b_step = 8; sub = 0; nsub = 1; }
     else { b_first = x % B; b_step = B * 8 /* one query per group */; sub = x / B; nsub = (8 - b_first + B - 1) / B; }
-    // 2-D launch (grid = (G, B)): work-group blockIdx.x of query blockIdx.y -- used by the row-mask sweep, whose few
-    // passages per query are better spread over few, long-running waves than over every XCD group
+    // 2-D launch (grid = (G, B)): work-group blockIdx.x of query blockIdx.y -- used when a query has few passages
+    // (the row-mask sweep; small shards), which are better spread over few, long-running waves
     const bool grid2d = gridDim.y > 1;
     const int wg_count = grid2d ? (int)gridDim.x : wg_per_group;
     const int wg_index = grid2d ? (int)blockIdx.x : wg;
     if (grid2d) { b_first = blockIdx.y; b_step = B; sub = 0; nsub = 1; }
 
     for (int b = b_first; b < B; b += b_step) {
-        // B operand: Q[t][32g + 8s + j] for token tiles 0/1, k-steps s = 0..3
-        u32x4 qb[2][4];
+        // B operand: bf16 Q[t = r][64h + 8s + j], k-steps s = 0..7
+        u32x4 qb[8];
+        {
+            const float* qrow = Q + ((size_t)b * T + (r < T ? r : T - 1)) * kDim + 64 * h;
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const int t = tl * 16 + r;
-            const float* qrow = Q + ((size_t)b * T + (t < T ? t : T - 1)) * kDim + 32 * g;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 8; ++s) {
                 float4 lo = *reinterpret_cast<const float4*>(qrow + 8 * s);
                 float4 hi = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
-                if (t >= T) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
-                qb[tl][s] = u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
+                if (r >= T) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+                qb[s] = u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
             }
         }
         const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
-        // uniform base + 32-bit per-lane byte offset (code*64 + 4r): one VALU op per gather address and the
-        // scalar-base form of global_load, instead of 64-bit per-lane pointer arithmetic
+        // uniform base + 32-bit per-lane byte offset (code * 64 + 16h): the scalar-base form of global_load
         const char* c16 = reinterpret_cast<const char*>(cells16 + (size_t)b * K * 16);
-        const uint32_t r4 = 4u * (uint32_t)r;
+        const uint32_t h16 = 16u * (uint32_t)h;
         float* out = scores + (size_t)b * cand_cap;
-        uint32_t* tmax = tokmax + (size_t)b * cand_cap * 16 + r;
+        uint16_t* tmax = tokmax + (size_t)b * cand_cap * 32 + r;
         const int* lst = ROWS ? list + (size_t)b * cand_cap : nullptr;
         unsigned long long* rmask = ROWS ? rowmask + (size_t)b * cand_cap * 4 : nullptr;
         const float window = ROWS ? 2.f * eps_pair[b] : 0.f;
@@ -712,33 +740,23 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
         int it_slot = __builtin_amdgcn_readlane(slot_l, 0);
         int it_base = 0;
 
+        // stage A: residual bytes (16 B / lane), code and inv_norm of the lane's row (dword each), ROWS: stored maximum
 #define CLB_STAGE_A(RB, CV, IV, PM, TAG)                                                                    \
     {                                                                                                       \
         const bool live = it_k < nd;                                                                        \
         const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
-        if (ROWS) PM = tmax[(size_t)(live ? it_slot : 0) * 16];   /* the passage's stored maxima {t, t+16} */ \
-        if (VARIANT == 5) {   /* ablation: no streaming loads */                                           \
-            RB = make_uint2(e0 * 2654435761u + lane_res, e0 ^ lane_res);                                    \
-            CV = u32x4{(e0 + lane_row) & 131071u, (e0 * 7u + lane_row) & 131071u, (e0 * 13u) & 131071u, (e0 * 29u) & 131071u}; \
-            IV = f32x4{1.f, 1.f, 1.f, 1.f};                                                                 \
-        } else {                                                                                            \
-        /* plain loads: non-temporal hints on these once-read streams were measured 7 % slower.         */ \
-        /* Rows past the end of the passage (tail step) are discarded later; their lanes re-read row 0 of */ \
-        /* the step instead of fetching the unrelated bytes behind the passage -- and, through the codes,  */ \
-        /* unrelated score rows: ~15 % of the kernel's traffic at 82 embeddings per passage.              */ \
-        const int left_ = it_len - it_base;                                                                 \
-        const uint32_t res_off = (live && r >= left_) ? (uint32_t)(8 * g) : lane_res;                       \
-        const uint32_t row_off = (live && 4 * g >= left_) ? 0u : lane_row;                                  \
-        RB = *reinterpret_cast<const uint2*>(residuals + (size_t)e0 * 32 + res_off);                        \
-        CV = *reinterpret_cast<const u32x4_a4*>(codes0 + (size_t)e0 + row_off);                             \
-        IV = *reinterpret_cast<const f32x4_a4*>(inv_norm + (size_t)e0 + row_off);                           \
-        }                                                                                                   \
-        const int left = it_len - it_base;                                                                  \
+        const int left = live ? it_len - it_base : kStepRows;                                               \
+        const int rows = left < kStepRows ? left : kStepRows;                                               \
+        if (ROWS) PM = tmax[(size_t)(live ? it_slot : 0) * 32];   /* the passage's stored maximum of token r */ \
+        const uint32_t rr = (uint32_t)(r < rows ? r : rows - 1);   /* tail lanes duplicate the last row */  \
+        RB = *reinterpret_cast<const u32x4*>(residuals + (size_t)e0 * 32 + (rr * 32u + h16));               \
+        CV = codes0[(size_t)e0 + rr];                                                                       \
+        IV = inv_norm[(size_t)e0 + rr];                                                                     \
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \
-        TAG.rows = left < 16 ? left : 16;                                                                   \
-        TAG.last = left <= 16;                                                                              \
+        TAG.rows = rows;                                                                                    \
+        TAG.last = left <= kStepRows;                                                                       \
         TAG.base = it_base;                                                                                 \
-        it_base += 16;                                                                                      \
+        it_base += kStepRows;                                                                               \
         if (TAG.last) {                                                                                     \
             it_k += 1;                                                                                      \
             const int kk = it_k < 64 ? it_k : 63;                                                           \
@@ -748,82 +766,67 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
             it_base = 0;                                                                                    \
         }                                                                                                   \
     }
-#define CLB_STAGE_G(CV, CELL)                                                                               \
+        // stage G: the score row of the lane's embedding: tokens 8h..8h+7 and 16+8h..16+8h+7 (fp16), 2 x 16 B
+#define CLB_STAGE_G(CV, X0, X1)                                                                             \
     {                                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) CELL[q] = VARIANT == 3 ? CV[q] : *reinterpret_cast<const uint32_t*>(c16 + ((CV[q] << 6) + r4)); \
+        const char* row_ = c16 + ((CV << 6) + h16);                                                         \
+        X0 = *reinterpret_cast<const u32x4*>(row_);                                                         \
+        X1 = *reinterpret_cast<const u32x4*>(row_ + 32);                                                    \
     }
-#define CLB_STAGE_C(RB, IV, CELL, PM, TAG)                                                                  \
+#define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + byte_times8<N>(W, three)))
+#define CLB_STAGE_C(RB, IV, X0, X1, PM, TAG)                                                                \
     {                                                                                                       \
-        u32x4 a[4];                                                                                         \
-        /* byte -> 4 bf16 bucket weights through the 2-KB LDS table: 8 ds_read_b64 replace 64 VALU ops.   */ \
-        /* (byte << 3) is one v_bfe_u32 on a word whose other bytes are masked out.                      */ \
+        /* inv_norm: lane layout (row = r) -> accumulator layout (register i = row (i&3) + 8(i>>2) + 4h)  */ \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        myinv[r] = IV;                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        f32x4 iq[4];                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                       \
+            iq[q] = *reinterpret_cast<const f32x4*>(myinv + 8 * q + 4 * h);                                 \
+        f32x16 acc;                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X0), sel1, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, acc, 0, 0, 0);    \
+        /* residual byte -> 4 bf16 bucket weights through the 2-KB LDS table; k-step s = bytes 2s, 2s+1   */ \
         {                                                                                                   \
-            const uint32_t e0 = RB.x & 0x00ff00ffu, o0 = RB.x & 0xff00ff00u;                                \
-            const uint32_t e1 = RB.y & 0x00ff00ffu, o1 = RB.y & 0xff00ff00u;                                \
-            const uint2 t0 = blut[e0 & 0xffu];                                                  \
-            const uint2 t1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o0, 5, 11));  \
-            const uint2 t2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(e0, 13, 11)); \
-            const uint2 t3 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o0, 21, 11)); \
-            const uint2 t4 = blut[e1 & 0xffu];                                                              \
-            const uint2 t5 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o1, 5, 11));  \
-            const uint2 t6 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(e1, 13, 11)); \
-            const uint2 t7 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blut) + __builtin_amdgcn_ubfe(o1, 21, 11)); \
-            a[0] = u32x4{t0.x, t0.y, t1.x, t1.y};                                                           \
-            a[1] = u32x4{t2.x, t2.y, t3.x, t3.y};                                                           \
-            a[2] = u32x4{t4.x, t4.y, t5.x, t5.y};                                                           \
-            a[3] = u32x4{t6.x, t6.y, t7.x, t7.y};                                                           \
+            const uint2 t0 = CLB_LUT(RB[0], 0), t1 = CLB_LUT(RB[0], 1);                                     \
+            const uint2 t2 = CLB_LUT(RB[0], 2), t3 = CLB_LUT(RB[0], 3);                                     \
+            const uint2 t4 = CLB_LUT(RB[1], 0), t5 = CLB_LUT(RB[1], 1);                                     \
+            const uint2 t6 = CLB_LUT(RB[1], 2), t7 = CLB_LUT(RB[1], 3);                                     \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t0.x, t0.y, t1.x, t1.y}), __builtin_bit_cast(bf16x8, qb[0]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t2.x, t2.y, t3.x, t3.y}), __builtin_bit_cast(bf16x8, qb[1]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t4.x, t4.y, t5.x, t5.y}), __builtin_bit_cast(bf16x8, qb[2]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t6.x, t6.y, t7.x, t7.y}), __builtin_bit_cast(bf16x8, qb[3]), acc, 0, 0, 0); \
         }                                                                                                   \
-        if (VARIANT == 4) {   /* ablation: 64 extra independent VALU ops per step */                        \
-            uint32_t junk = 0;                                                                              \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
-                    uint32_t t = a[s][q];                                                                   \
-                    asm volatile("v_xor_b32 %0, %1, %2\n\tv_add_u32 %0, %0, %1\n\tv_xor_b32 %0, %0, %2\n\tv_add_u32 %0, %0, %2" : "=&v"(t) : "v"(a[s][q]), "v"(kmask)); \
-                    junk ^= t;                                                                              \
-                }                                                                                           \
-            asm volatile("" :: "v"(junk));                                                                  \
+        {                                                                                                   \
+            const uint2 t0 = CLB_LUT(RB[2], 0), t1 = CLB_LUT(RB[2], 1);                                     \
+            const uint2 t2 = CLB_LUT(RB[2], 2), t3 = CLB_LUT(RB[2], 3);                                     \
+            const uint2 t4 = CLB_LUT(RB[3], 0), t5 = CLB_LUT(RB[3], 1);                                     \
+            const uint2 t6 = CLB_LUT(RB[3], 2), t7 = CLB_LUT(RB[3], 3);                                     \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t0.x, t0.y, t1.x, t1.y}), __builtin_bit_cast(bf16x8, qb[4]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t2.x, t2.y, t3.x, t3.y}), __builtin_bit_cast(bf16x8, qb[5]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t4.x, t4.y, t5.x, t5.y}), __builtin_bit_cast(bf16x8, qb[6]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t6.x, t6.y, t7.x, t7.y}), __builtin_bit_cast(bf16x8, qb[7]), acc, 0, 0, 0); \
         }                                                                                                   \
-        f32x4 acc0, acc1;                                                                                   \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-            const float2 cf = __half22float2(*reinterpret_cast<const __half2*>(&CELL[q]));                  \
-            acc0[q] = cf.x;                                                                                 \
-            acc1[q] = cf.y;                                                                                 \
-        }                                                                                                   \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
-            if (VARIANT == 2) { acc0[s] += __uint_as_float(a[s][0] ^ a[s][2]); acc1[s] += __uint_as_float(a[s][1] ^ a[s][3]); continue; } \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),                \
-                                                           __builtin_bit_cast(bf16x8, qb[0][s]), acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]),                \
-                                                           __builtin_bit_cast(bf16x8, qb[1][s]), acc1, 0, 0, 0); \
-        }                                                                                                   \
-        float v0[4], v1[4];                                                                                 \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-            v0[q] = acc0[q] * IV[q];                                                                        \
-            v1[q] = acc1[q] * IV[q];                                                                        \
-        }                                                                                                   \
-        if (TAG.rows < 16) {   /* tail step: rows past the passage belong to the next one */               \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
-                const bool ok = (int)lane_row + q < TAG.rows;                                               \
-                v0[q] = ok ? v0[q] : kNegInf;                                                               \
-                v1[q] = ok ? v1[q] : kNegInf;                                                               \
-            }                                                                                               \
-        }                                                                                                   \
+        float v[16];                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = acc[i] * iq[i >> 2][i & 3];                   \
         if (ROWS) {                                                                                         \
-            const float2 pm = __half22float2(*reinterpret_cast<const __half2*>(&PM));                       \
-            const float lo0 = r < T ? pm.x - window : __builtin_inff();   /* tokens past T select nothing */ \
-            const float lo1 = 16 + r < T ? pm.y - window : __builtin_inff();                                \
-            unsigned long long bits = 0;                                                                    \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(v0[q] >= lo0 || v1[q] >= lo1);   \
-                _Pragma("unroll") for (int gg = 0; gg < 4; ++gg)                                            \
-                    if ((bal >> (16 * gg)) & 0xffffull) bits |= 1ull << (4 * gg + q);                       \
+            const __half pmh = *reinterpret_cast<const __half*>(&PM);                                       \
+            const float lo = r < T ? __half2float(pmh) - window : __builtin_inff();   /* tokens past T select nothing */ \
+            uint32_t bits = 0;                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                \
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(!(v[i] < lo));                   \
+                const int row0 = (i & 3) + 8 * (i >> 2);                                                    \
+                if ((uint32_t)bal) bits |= 1u << row0;                                                      \
+                if ((uint32_t)(bal >> 32)) bits |= 1u << (row0 + 4);                                        \
             }                                                                                               \
-            bits <<= (TAG.base & 63);                                                                       \
-            const int wi = (TAG.base >> 6) & 3;                                                             \
-            wm0 |= wi == 0 ? bits : 0ull;                                                                   \
-            wm1 |= wi == 1 ? bits : 0ull;                                                                   \
-            wm2 |= wi == 2 ? bits : 0ull;                                                                   \
-            wm3 |= wi == 3 ? bits : 0ull;                                                                   \
+            if (TAG.rows < kStepRows) bits &= (1u << TAG.rows) - 1u;   /* duplicates of the last row */     \
+            const unsigned long long wbits = (unsigned long long)bits << (TAG.base & 32);                   \
+            const int wi = TAG.base >> 6;                                                                   \
+            wm0 |= wi == 0 ? wbits : 0ull;                                                                  \
+            wm1 |= wi == 1 ? wbits : 0ull;                                                                  \
+            wm2 |= wi == 2 ? wbits : 0ull;                                                                  \
+            wm3 |= wi == 3 ? wbits : 0ull;                                                                  \
             if (TAG.last) {                                                                                 \
                 if (lane == 0 && TAG.j >= 0) {                                                              \
                     unsigned long long* o = rmask + (size_t)TAG.j * 4;                                      \
@@ -832,54 +835,54 @@ static __global__ __launch_bounds__(256) void score_approx_kernel(
                 wm0 = wm1 = wm2 = wm3 = 0;                                                                  \
             }                                                                                               \
         } else {                                                                                            \
-        m0 = max3f(m0, v0[0], v0[1]);                                                                       \
-        m0 = max3f(m0, v0[2], v0[3]);                                                                       \
-        m1 = max3f(m1, v1[0], v1[1]);                                                                       \
-        m1 = max3f(m1, v1[2], v1[3]);                                                                       \
-        if (TAG.last) {                                                                                     \
-            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));                                                         \
-            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));                                                         \
-            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));                                                         \
-            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));                                                         \
-            float sum = (r < T ? m0 : 0.f) + (16 + r < T ? m1 : 0.f);                                       \
-            sum += __shfl_xor(sum, 1, 64);                                                                  \
-            sum += __shfl_xor(sum, 2, 64);                                                                  \
-            sum += __shfl_xor(sum, 4, 64);                                                                  \
-            sum += __shfl_xor(sum, 8, 64);                                                                  \
-            if (lane == 0 && TAG.j >= 0) out[TAG.j] = sum;                                                  \
-            if (VARIANT == 0 && g == 0 && TAG.j >= 0)                                                       \
-                tmax[(size_t)TAG.j * 16] = f32_to_f16_floor(m0) | (f32_to_f16_floor(m1) << 16);             \
-            m0 = kNegInf;                                                                                   \
-            m1 = kNegInf;                                                                                   \
-        }                                                                                                   \
+            float m01 = fmaxf(fmaxf(v[0], v[1]), v[2]);                                                     \
+            float m23 = fmaxf(fmaxf(v[3], v[4]), v[5]);                                                     \
+            float m45 = fmaxf(fmaxf(v[6], v[7]), v[8]);                                                     \
+            float m67 = fmaxf(fmaxf(v[9], v[10]), v[11]);                                                   \
+            float m89 = fmaxf(fmaxf(v[12], v[13]), v[14]);                                                  \
+            m01 = fmaxf(fmaxf(m01, m23), m45);                                                              \
+            m67 = fmaxf(fmaxf(m67, m89), v[15]);                                                            \
+            mx = fmaxf(fmaxf(mx, m01), m67);                                                                \
+            if (TAG.last) {                                                                                 \
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                     \
+                float sum = r < T ? mx : 0.f;                                                               \
+                sum += __shfl_xor(sum, 1, 64);                                                              \
+                sum += __shfl_xor(sum, 2, 64);                                                              \
+                sum += __shfl_xor(sum, 4, 64);                                                              \
+                sum += __shfl_xor(sum, 8, 64);                                                              \
+                sum += __shfl_xor(sum, 16, 64);                                                             \
+                if (lane == 0 && TAG.j >= 0) out[TAG.j] = sum;                                              \
+                if (h == 0 && TAG.j >= 0) tmax[(size_t)TAG.j * 32] = (uint16_t)f32_to_f16_floor(mx);       \
+                mx = kNegInf;                                                                               \
+            }                                                                                               \
         }                                                                                                   \
     }
 
-        float m0 = kNegInf, m1 = kNegInf;
-        uint2 rb0, rb1, rb2;
-        u32x4 cv0, cv1, cv2;
-        f32x4 iv0, iv1, iv2;
-        uint32_t ce0[4], ce1[4], ce2[4];
-        uint32_t pm0 = 0, pm1 = 0, pm2 = 0;
+        float mx = kNegInf;
+        u32x4 rb0, rb1, rb2, xa0, xa1, xa2, xb0, xb1, xb2;
+        uint32_t cv0, cv1, cv2;
+        float iv0, iv1, iv2;
+        uint16_t pm0 = 0, pm1 = 0, pm2 = 0;
         StepTag t0, t1, t2;
         CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
         CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
-        CLB_STAGE_G(cv0, ce0);
+        CLB_STAGE_G(cv0, xa0, xb0);
         while (t0.j >= 0) {
             CLB_STAGE_A(rb2, cv2, iv2, pm2, t2);
-            CLB_STAGE_G(cv1, ce1);
-            CLB_STAGE_C(rb0, iv0, ce0, pm0, t0);
+            CLB_STAGE_G(cv1, xa1, xb1);
+            CLB_STAGE_C(rb0, iv0, xa0, xb0, pm0, t0);
             CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
-            CLB_STAGE_G(cv2, ce2);
-            CLB_STAGE_C(rb1, iv1, ce1, pm1, t1);
+            CLB_STAGE_G(cv2, xa2, xb2);
+            CLB_STAGE_C(rb1, iv1, xa1, xb1, pm1, t1);
             CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
-            CLB_STAGE_G(cv0, ce0);
-            CLB_STAGE_C(rb2, iv2, ce2, pm2, t2);
+            CLB_STAGE_G(cv0, xa0, xb0);
+            CLB_STAGE_C(rb2, iv2, xa2, xb2, pm2, t2);
         }
         }   // chunk of 64 passages
 #undef CLB_STAGE_A
 #undef CLB_STAGE_G
 #undef CLB_STAGE_C
+#undef CLB_LUT
     }
 }
 
@@ -930,10 +933,16 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     // bound on |approx - canonical| of ONE (token, embedding) score; see the header of this file
     const float u = 5.9604645e-08f;  // 2^-24
     const float qn = s_qn;
-    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max;
+    // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
+    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
     const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
     const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
-    if (tid == 0) eps_pair[b] = kEpsSafety * eps_t;
+    // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
+    // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
+    // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
+    // scored by the exact kernel alone, exactly as in mode 0.  (NaN-safe: written with negated comparisons.)
+    const bool unsafe = !(qn * ac.cn_max < 3.0e4f) || !(eps_t < 1.0e30f);
+    if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * eps_t;
     // thread t owns the contiguous slots [t*chunk, (t+1)*chunk); up to kSelCache order keys stay in registers for the
     // radix passes and the compaction (the approximate scores are read once)
     const int chunk = (n + 1023) >> 10;
@@ -961,7 +970,9 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             __VA_ARGS__                                                                         \
         }                                                                                       \
     }
-    if (tau_in) {
+    if (unsafe) {
+        eps = __builtin_inff();          // thr stays -inf: everything is listed
+    } else if (tau_in) {
         // sharded search, phase 2: tau is the GLOBAL k-th approximate score over all shards (global_tau_kernel); -inf
         // means fewer than k candidates exist anywhere, i.e. everything is listed
         eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
@@ -979,7 +990,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         // large inputs: the same compaction in blocks of 1024 consecutive slots (coalesced reads, one scan per block)
         for (int base = 0; base < n; base += 1024) {
             const int i = base + tid;
-            const bool take = i < n && sc[i] >= thr;
+            const bool take = i < n && !(sc[i] < thr);   // NaN (unsafe query) is listed
             const int lane = tid & 63, wave = tid >> 6;
             int xv = take ? 1 : 0;
             const int v = xv;
@@ -1003,7 +1014,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         }
     } else {
         int cnt = 0;
-        CLB_SEL_FOR_EACH((void)i; cnt += valid && f32_from_order_key(key) >= thr;)
+        CLB_SEL_FOR_EACH((void)i; cnt += valid && !(f32_from_order_key(key) < thr);)
         const int lane = tid & 63, wave = tid >> 6;
         int xv = cnt;
 #pragma unroll
@@ -1020,7 +1031,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
             tot += sv;
         }
         int pos = wbase + xv - cnt;
-        CLB_SEL_FOR_EACH(if (valid && f32_from_order_key(key) >= thr) lst[pos++] = i;)
+        CLB_SEL_FOR_EACH(if (valid && !(f32_from_order_key(key) < thr)) lst[pos++] = i;)
         if (tid == 0) s_run = tot;
         __syncthreads();
     }

@@ -36,7 +36,7 @@ template <int MODE>
 int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim, int K, const float* dX, int64_t n,
                       uint32_t* dOut, NearestScratch* scratch = nullptr) {
     if (n == 0) return CLB_OK;
-    static const bool force_fp32 = getenv("CLB_DEBUG_NEAREST_FP32") != nullptr;
+    const bool force_fp32 = CLB_KNOB("CLB_DEBUG_NEAREST_FP32", 0) != 0;
     if (dim == kDim && K >= 32 && scratch && !force_fp32) {
         NearestScratch& w = *scratch;
         const size_t cel = (size_t)K * kDim;

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -90,6 +91,18 @@ inline int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st = nu
 }
 
 constexpr float kNegInf = -__builtin_huge_valf();
+
+// Launch-geometry knobs used while tuning: the shipped library compiles them to their defaults; a build with
+// -DCLB_ABLATIONS reads CLB_DEBUG_* from the environment instead (make ABLATIONS=1).
+#ifdef CLB_ABLATIONS
+inline int tuning_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#define CLB_KNOB(NAME, DFLT) ([] { static const int v_ = clb::tuning_knob(NAME, DFLT); return v_; }())
+#else
+#define CLB_KNOB(NAME, DFLT) (DFLT)
+#endif
 
 // ---- device helpers ------------------------------------------------------------------------------
 // float -> unsigned key with the same ordering (larger float <=> larger key); -0.0 < +0.0 here, which

@@ -38,14 +38,15 @@ struct Prof {
     hipStream_t chain_stream = nullptr;
     double total_ms[KID_COUNT] = {0};
     int64_t launches[KID_COUNT] = {0};
+    bool failed = false;    // an event could not be created: that kernel goes untimed, clb_profile_read reports it
     hipEvent_t get() {
         if (!pool.empty()) {
             hipEvent_t e = pool.back();
             pool.pop_back();
             return e;
         }
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { failed = true; return nullptr; }
         return e;
     }
 };
@@ -57,6 +58,8 @@ struct Workspace {
     int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
+    // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
+    struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
         outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob;
 };
@@ -100,17 +103,20 @@ struct Timed {
                 a = s->prof.chain;
             } else {
                 a = s->prof.get();
-                (void)hipEventRecord(a, st);
+                if (a && hipEventRecord(a, st) != hipSuccess) { s->prof.pool.push_back(a); a = nullptr; s->prof.failed = true; }
             }
-            b = s->prof.get();
+            b = a ? s->prof.get() : nullptr;
         }
     }
     ~Timed() {
-        if (s->prof.on) {
-            (void)hipEventRecord(b, st);
+        if (!s->prof.on) return;
+        if (a && b && hipEventRecord(b, st) == hipSuccess) {
             s->prof.pending[id].push_back({a, b});
             s->prof.chain = b;
             s->prof.chain_stream = st;
+        } else {                       // untimed launch: the next timed kernel records its own start
+            s->prof.failed = true;
+            s->prof.chain = nullptr;
         }
     }
 };
@@ -166,7 +172,7 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
         CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
         CLB_TRY(w.rowmask.ensure(sizeof(unsigned long long) * 4 * B * w.cand_cap));
         CLB_TRY(w.eps_pair.ensure(sizeof(float) * B));
-        CLB_TRY(w.tokmax.ensure(sizeof(uint32_t) * 16 * B * w.cand_cap));
+        CLB_TRY(w.tokmax.ensure(sizeof(uint16_t) * 32 * B * w.cand_cap));
     }
     w.Bcap = B; w.Tcap = T; w.npcap = nprobe; w.kcap = k;
     CLB_HIP(hipStreamSynchronize(s->stream));
@@ -203,7 +209,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         const int groups = (B + kMqQueries - 1) / kMqQueries;
         int gx = mq ? std::max(1, std::min(n_tiles, std::min(256, std::max(512 / groups, 16))))
                           : std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
-        static const int gx_dbg = getenv("CLB_DEBUG_S1_GX") ? atoi(getenv("CLB_DEBUG_S1_GX")) : 0;
+        const int gx_dbg = CLB_KNOB("CLB_DEBUG_S1_GX", 0);
         if (gx_dbg > 0 && !mq) gx = std::min(gx_dbg, n_tiles / 2 + 1);
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
@@ -342,29 +348,20 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (two_pass) {
         {
             Timed t(s, KID_SCORE_APPROX, st);
-            static const int variant = getenv("CLB_DEBUG_APPROX_VARIANT") ? atoi(getenv("CLB_DEBUG_APPROX_VARIANT")) : 0;
-            static const int wgpg = getenv("CLB_DEBUG_APPROX_WGPG") ? atoi(getenv("CLB_DEBUG_APPROX_WGPG")) : 128;
+            const int wgpg = CLB_KNOB("CLB_DEBUG_APPROX_WGPG", 128);
             // Grid: XCD-affine 1-D launch (all work-groups of an XCD share one query's score table in L2) for
             // large candidate sets; for small ones (a shard of a multi-GPU run: < ~6 k candidate passages per
             // query, estimated from the mean IVF list) a (G, B) launch whose few waves per query each get a long
-            // run of passages -- the pipeline fill otherwise dominates (0.156 -> 0.130 ms on a 1/8 shard).
-            static const int approx_2d = getenv("CLB_DEBUG_APPROX_2D") ? atoi(getenv("CLB_DEBUG_APPROX_2D")) : -1;
+            // run of passages -- the pipeline fill otherwise dominates.
+            const int approx_2d = CLB_KNOB("CLB_DEBUG_APPROX_2D", -1);
             const double est_cand = 0.5 * T * nprobe * (double)s->n_emb / (double)std::max<int64_t>(1, s->K);
             const int gx2d = approx_2d >= 0 ? approx_2d : (est_cand < 6000.0 ? 1024 : 0);
             const dim3 approx_grid = gx2d > 0 && B > 1 ? dim3(std::max(1, gx2d / B), B) : dim3(8 * wgpg);
-#define CLB_LAUNCH_APPROX(V)                                                                                         \
-    hipLaunchKernelGGL(score_approx_kernel<V>, approx_grid, dim3(256), 0, st, s->weights.as<float>(),              \
-                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
-                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(), \
-                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint32_t>(), (const int*)nullptr,                    \
-                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
-            if (variant == 1) CLB_LAUNCH_APPROX(1);
-            else if (variant == 2) CLB_LAUNCH_APPROX(2);
-            else if (variant == 3) CLB_LAUNCH_APPROX(3);
-            else if (variant == 4) CLB_LAUNCH_APPROX(4);
-            else if (variant == 5) CLB_LAUNCH_APPROX(5);
-            else CLB_LAUNCH_APPROX(0);
-#undef CLB_LAUNCH_APPROX
+            hipLaunchKernelGGL(score_approx32_kernel<false>, approx_grid, dim3(256), 0, st, s->weights.as<float>(),
+                               s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
+                               w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                               (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                               (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
         }
         {
             Timed t(s, KID_SELECT, st);
@@ -382,24 +379,23 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         CLB_HIP(hipGetLastError());
         return CLB_OK;
     }
-    static const bool no_subset = getenv("CLB_DEBUG_NO_SUBSET") != nullptr;
-    const bool subset = list && !no_subset;   // two-pass mode (nbits 2, T <= 32): re-score only the rows that matter
+    const bool subset = list && !CLB_KNOB("CLB_DEBUG_NO_SUBSET", 0);   // two-pass mode: re-score only the rows that matter
     if (subset) {
         Timed t(s, KID_ROWS, st);
         // the pass-1 pipeline again, over the listed passages only: marks the rows that can hold a token maximum
-        static const int rows_gx = getenv("CLB_DEBUG_ROWS_GX") ? atoi(getenv("CLB_DEBUG_ROWS_GX")) : 1024;
+        const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 1024);
         const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 128);
-        hipLaunchKernelGGL(score_approx_kernel<kVariantRows>, rows_grid, dim3(256), 0, st, s->weights.as<float>(),
+        hipLaunchKernelGGL(score_approx32_kernel<true>, rows_grid, dim3(256), 0, st, s->weights.as<float>(),
                            s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                           (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint32_t>(), list, nlist, w.eps_pair.as<float>(),
+                           (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
                            w.rowmask.as<unsigned long long>());
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
-        static const int gxl = getenv("CLB_DEBUG_EXACT_GX") ? atoi(getenv("CLB_DEBUG_EXACT_GX")) : 1024;
+        const int gxl = CLB_KNOB("CLB_DEBUG_EXACT_GX", 1024);
         const int gx = list ? std::max(1, gxl / B) : std::max(1, 2048 / B);
-        static const int flat_gx = getenv("CLB_DEBUG_FLAT_GX") ? atoi(getenv("CLB_DEBUG_FLAT_GX")) : 768;   // one resident round at 3 work-groups per CU
+        const int flat_gx = CLB_KNOB("CLB_DEBUG_FLAT_GX", 768);   // one resident round at 3 work-groups per CU
         if (subset) {
             hipLaunchKernelGGL(score_exact_flat_kernel, dim3(std::max(1, flat_gx / B), B), dim3(256), 0, st, s->centroids.as<float>(),
                                s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
@@ -488,8 +484,8 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     int rc;
     if ((rc = upload(s->centroids, centroids, sizeof(float) * dim * K, s->stream))) return bail(rc);
     if ((rc = upload(s->weights, bucket_weights, sizeof(float) * ((size_t)1 << nbits), s->stream))) return bail(rc);
-    // steps of 16 embeddings are loaded unclamped: pad the per-embedding arrays by one step
-    constexpr int64_t kPad = 16;
+    // pad the per-embedding arrays by one step (dummy steps read embeddings 0 .. kStepRows-1 even of a tiny index)
+    constexpr int64_t kPad = kStepRows;
     if ((rc = s->codes0.alloc(sizeof(uint32_t) * (n_emb + kPad)))) return bail(rc);
     if ((rc = s->residuals.alloc(rows * (n_emb + kPad)))) return bail(rc);
     if (hipMemsetAsync(s->codes0.p, 0, s->codes0.bytes, s->stream) != hipSuccess ||
@@ -527,7 +523,7 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     }
     s->approx_ok = approx_supported((int)dim, nbits);
     if (s->approx_ok) {
-        if ((rc = s->inv_norm.alloc(sizeof(float) * (n_emb + 16)))) return bail(rc);
+        if ((rc = s->inv_norm.alloc(sizeof(float) * (n_emb + kStepRows)))) return bail(rc);
         if (hipMemsetAsync(s->inv_norm.p, 0, s->inv_norm.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
     }
     if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
@@ -575,6 +571,21 @@ int clb_searcher_set_mode(clb_searcher* s, int mode) {
 }
 int clb_searcher_get_mode(const clb_searcher* s) { return s ? s->mode : -1; }
 
+int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {
+    if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
+    consts[0] = s->approx_consts.cn_max; consts[1] = s->approx_consts.rn_max; consts[2] = s->approx_consts.inv_max;
+    return CLB_OK;
+}
+int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts) {
+    if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
+    for (int i = 0; i < 3; ++i)
+        if (!(consts[i] >= 0.f)) return fail(CLB_EARGUMENT, "bound constants must be non-negative numbers");
+    s->approx_consts.cn_max = std::max(s->approx_consts.cn_max, consts[0]);
+    s->approx_consts.rn_max = std::max(s->approx_consts.rn_max, consts[1]);
+    s->approx_consts.inv_max = std::max(s->approx_consts.inv_max, consts[2]);
+    return CLB_OK;
+}
+
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                             void* hip_stream) {
@@ -582,6 +593,7 @@ int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_
     CLB_TRY(use_device(s->device));
     hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
     Workspace& w = s->ws[0];
+    w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores, d_n_cand));
     return CLB_OK;
@@ -594,8 +606,12 @@ int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
-    return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, nullptr, nullptr, nullptr,
-                      1, d_local_top);
+    w.pending.valid = false;
+    CLB_TRY(run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, nullptr, nullptr, nullptr,
+                       1, d_local_top));
+    w.pending.valid = true; w.pending.dQ = d_Q; w.pending.T = T; w.pending.B = B; w.pending.nprobe = nprobe;
+    w.pending.k = k; w.pending.stream = hip_stream;
+    return CLB_OK;
 }
 
 int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
@@ -605,8 +621,11 @@ int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_
     if (!d_all_top || n_shards < 1) return fail(CLB_EARGUMENT, "d_all_top is null or n_shards < 1");
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
-    if (B > w.Bcap || T > w.Tcap || nprobe > w.npcap || k > w.kcap)
-        return fail(CLB_EARGUMENT, "clb_search_shard_phase2 without a matching clb_search_shard_phase1");
+    const auto& pd = w.pending;
+    if (!pd.valid || pd.dQ != d_Q || pd.T != T || pd.B != B || pd.nprobe != nprobe || pd.k != k || pd.stream != hip_stream)
+        return fail(CLB_EARGUMENT, "clb_search_shard_phase2 without a matching clb_search_shard_phase1 "
+                                   "(same queries, T, B, nprobe, k and stream, and no other search in between)");
+    w.pending.valid = false;
     return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores,
                       d_n_cand, 2, nullptr, d_all_top, (int)n_shards);
 }
@@ -616,6 +635,7 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
+    w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     hipStream_t st = s->stream;
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * B * T * kDim, hipMemcpyHostToDevice, st));
@@ -650,6 +670,7 @@ int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int
     CLB_TRY(check_search_args(s, T, 1, nprobe, 1));
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
+    w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, 1));
     hipStream_t st = s->stream;
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
@@ -704,15 +725,16 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     if (!s->approx_ok || T > 32) return fail(CLB_EUNSUPPORTED, "two-pass mode not available for this index/query");
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
+    w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, k));
     hipStream_t st = s->stream;
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
-    hipLaunchKernelGGL(score_approx_kernel<0>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
+    hipLaunchKernelGGL(score_approx32_kernel<false>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                       (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint32_t>(), (const int*)nullptr,
+                       (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ,
                        (int)T, (int)k, w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(),
@@ -776,6 +798,11 @@ int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int6
     std::sort(seen.begin(), seen.end());
     seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
     s->prof.pool.insert(s->prof.pool.end(), seen.begin(), seen.end());
+    if (s->prof.failed) {               // some launches went untimed: the totals above are incomplete
+        s->prof.failed = false;
+        (void)fail(CLB_EHIP, "HIP event creation/record failed while profiling: timings are incomplete");
+        return -1;
+    }
     return n;
 }
 

@@ -243,10 +243,10 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
             const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;   // ascending in r for a fixed half
             if (c < K) topn_insert<2>(bv, bi, acc[r], c);
             if (WRITE_HALF) {
-                const float other = __shfl_xor(acc[r], 16, 64);  // token i ^ 16, same centroid row
-                if ((i & 16) == 0 && c < K) {
+                const float other = __shfl_xor(acc[r], 1, 64);   // token i ^ 1, same centroid row
+                if ((i & 1) == 0 && c < K) {                     // row of 32 fp16 in token order: pairs {i, i+1}
                     const __half2 hv = __floats2half2_rn(acc[r], other);
-                    cells16[((size_t)b * K + c) * 16 + i] = *reinterpret_cast<const uint32_t*>(&hv);
+                    cells16[((size_t)b * K + c) * 16 + (i >> 1)] = *reinterpret_cast<const uint32_t*>(&hv);
                 }
             }
         }
@@ -689,7 +689,7 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
 // only ~2.4 steps of 16 rows, so a per-passage loop spends most of its time in the start-up chain of dependent
 // loads (list -> header -> codes -> centroid rows).  Here each wave walks a wave-uniform iterator over the steps
 // of ITS passages (headers and row masks of 64 passages at a time sit in VGPRs and are extracted with v_readlane,
-// as in score_approx_kernel) and keeps three steps in flight across passage boundaries:
+// as in score_approx32_kernel) and keeps three steps in flight across passage boundaries:
 //   stage A (step i+2): row index of lane r = the (base + r)-th set bit of the passage's 256-bit mask (a
 //                       branch-free popcount search), then its code and 32-B residual are requested;
 //   stage G (step i+1): the 16 centroid rows are requested as whole 512-B rows;

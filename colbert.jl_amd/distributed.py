@@ -64,6 +64,28 @@ def merge_packed(gathered, B: int, k: int, out_p=None, out_s=None):
     return out_p, out_s
 
 
+def sync_bound_consts(searcher, group=None):
+    """The two-phase sharded search cuts every shard at one global threshold tau - 2 eps, so eps must be the same
+    (the largest) on every shard: all-reduce MAX of the three constants of the error bound, once, at load time.
+    Without it a shard whose own embeddings give a smaller eps could skip a member of the global top-k."""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", searcher.device) if backend == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(searcher.bound_consts.copy()).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    searcher.raise_bound_consts(t.cpu().numpy())
+    return searcher.bound_consts
+
+
+def share_bound_consts(searchers):
+    """The same for several shards held by ONE process (tests, tools/shard_breakdown.py)."""
+    m = np.max(np.stack([s.bound_consts for s in searchers]), axis=0)
+    for s in searchers:
+        s.raise_bound_consts(m)
+    return m
+
+
 def all_gather_scores(local_top, group=None):
     """(B, k) fp32 -> (world, B, k): the exchange between the two phases of the sharded search."""
     import torch

@@ -73,6 +73,19 @@ class Searcher:
     def mode(self) -> int:
         return int(lib().clb_searcher_get_mode(self._h))
 
+    @property
+    def bound_consts(self) -> np.ndarray:
+        """{max ||centroid||, sqrt(dim) * max |bucket weight|, max 1/(||c+r|| + eps)} of this handle's error bound."""
+        out = np.zeros(3, dtype=np.float32)
+        check(lib().clb_searcher_get_bound_consts(self._h, fptr(out)))
+        return out
+
+    def raise_bound_consts(self, consts):
+        """Element-wise maximum with `consts` (sharded search: one bound on every shard, distributed.sync_bound_consts)."""
+        c = np.ascontiguousarray(consts, dtype=np.float32)
+        assert c.shape == (3,)
+        check(lib().clb_searcher_set_bound_consts(self._h, fptr(c)))
+
     # -- search -----------------------------------------------------------------------------------
     def search_embeddings(self, Q, k: int, nprobe: Optional[int] = None):
         """search() after encode_queries (searching.jl:102-127).  Q: (dim, T) Float32.
@@ -137,6 +150,8 @@ class Searcher:
         cap = 16
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); cnt = (C.c_int64 * cap)()
         n = lib().clb_profile_read(self._h, names, ms, cnt, cap)
+        if n < 0:
+            check(10)
         return {names[i].decode(): {"ms": ms[i], "launches": cnt[i]} for i in range(n)}
 
     def last_batch_stats(self) -> dict:

@@ -64,7 +64,8 @@ def _block(seed: int, block: int, n_docs: int, K: int, dim: int, nbits: int, doc
 
 def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbits: int = 2,
                doclen_mean: float = 80.0, doclen_std: float = 16.0, constant_doclen: bool = False,
-               topical: bool = True, n_blocks: int = 1, blocks=None, doclen_max: int = 220):
+               topical: bool = True, n_blocks: int = 1, blocks=None, doclen_max: int = 220,
+               ivf_on_device: bool = False):
     """A compressed index of `n_docs` passages.  `topical`: each passage draws 80 % of its tokens
     from the 16 centroids nearest (by id, a cheap stand-in for similarity) to 4 per-passage topic
     centroids, the rest uniformly -- uniform codes are the worst case for candidate counts.
@@ -92,7 +93,11 @@ def make_index(seed: int, n_docs: int, K: int | None = None, dim: int = 128, nbi
         wr = np.random.default_rng([seed, 1])
         weights = np.sort(wr.normal(0, 0.03, 1 << nbits).astype(np.float32))
         cutoffs = ((weights[1:] + weights[:-1]) / 2).astype(np.float32)
-    ivf, ivf_lengths = build_ivf(codes, K)
+    if ivf_on_device:      # 10 M-passage corpora: numpy's stable argsort of 8e8 keys takes minutes, clb_build_ivf seconds
+        from . import codec
+        ivf, ivf_lengths = codec.build_ivf(codes, K)
+    else:
+        ivf, ivf_lengths = build_ivf(codes, K)
     return {"dim": dim, "nbits": nbits, "centroids": _centroids(seed, K, dim), "bucket_weights": weights,
             "bucket_cutoffs": cutoffs, "doclens": doclens, "codes": codes, "residuals": residuals,
             "ivf": ivf, "ivf_lengths": ivf_lengths, "pid_offset": blocks[0] * per if blocks else 0}

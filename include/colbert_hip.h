@@ -95,6 +95,12 @@ int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_
  *    index shape supports it (dim 128, nbits 2), else 0. */
 int clb_searcher_set_mode(clb_searcher* s, int mode);
 int clb_searcher_get_mode(const clb_searcher* s);
+/* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, consts[1] = sqrt(dim) * max
+ * |bucket weight|, consts[2] = max over the shard's embeddings of 1/(||c + r|| + eps).  Sharded search with a global
+ * threshold (clb_search_shard_phase1/2) needs ONE bound on every shard: take the element-wise maximum over the
+ * shards (an all-reduce MAX of three floats at load time) and set it on each handle.  `set` never lowers a value. */
+int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts /* 3 */);
+int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts /* 3 */);
 
 /* retrieve()  (src/search/ranking.jl:23-44) on its own -- test hook.  out_pids needs n_docs entries. */
 int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
