@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcolbert_hip.so")
+# COLBERT_HIP_LIB: another build of the same library (e.g. the tuning build `make ABLATIONS=1`)
+LIB_PATH = os.environ.get("COLBERT_HIP_LIB") or os.path.join(CSRC, "libcolbert_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "colbert_hip.h"))
 
 

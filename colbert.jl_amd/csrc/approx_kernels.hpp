@@ -609,9 +609,10 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 // end-of-passage store; steps past the end of the wave's work are redirected to embedding 0 and discarded.
 // Work-groups are dealt to queries by `blockIdx.x % 8` (the label of the XCD they share under round-robin placement
 // -- a speed heuristic only): the work-groups of one XCD gather from ONE query's score table at a time.
-// grid = 8 * wg_per_group (1-D) or (G, B) (2-D: few passages per query), block = 256.
+// grid = 8 * wg_per_group (1-D) or (G, B) (2-D: few passages per query), block = kApproxThreads (12 waves).
 // -------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct StepTag {      // wave-uniform description of a step
     int j;            // candidate slot (ROWS: list position), -1 = dummy
@@ -630,16 +631,30 @@ __device__ __forceinline__ uint32_t f32_to_f16_floor(float x) {
     return bits;
 }
 
-// (byte n of word R) * 8 -- the LDS table offset of that residual byte -- in ONE VALU op (SDWA byte select)
+// LDS table offset of residual byte N of word R: (byte << 8) | lane8 in ONE VALU op (v_perm_b32: byte N of R into
+// byte 1, byte 0 of lane8 into byte 0, zeros above)
 template <int N>
-__device__ __forceinline__ uint32_t byte_times8(uint32_t R, uint32_t three) {
-    uint32_t a;
-    if (N == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(three), "v"(R));
-    if (N == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(three), "v"(R));
-    if (N == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(three), "v"(R));
-    if (N == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(three), "v"(R));
-    return a;
+__device__ __forceinline__ uint32_t lut_offset(uint32_t R, uint32_t lane8) {
+    return __builtin_amdgcn_perm(R, lane8, 0x0c0c0000u | ((4u + N) << 8));
 }
+
+// wave64 helpers on DPP / permlane (no LDS traffic): sum of lanes 0..31 delivered in lanes 16..31; max over the two
+// lane halves delivered in every lane
+#define CLB_DPP_F(V, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (V)), (CTRL), 0xf, 0xf, true))
+__device__ __forceinline__ float sum_lanes_0_31(float s) {
+    s += CLB_DPP_F(s, 0xB1);     // quad_perm [1,0,3,2]: lane ^ 1
+    s += CLB_DPP_F(s, 0x4E);     // quad_perm [2,3,0,1]: lane ^ 2
+    s += CLB_DPP_F(s, 0x141);    // row_half_mirror: the other quad of the 8
+    s += CLB_DPP_F(s, 0x140);    // row_mirror: the other 8 of the row; every lane of a row now holds the row's sum
+    // row_bcast15 into rows 1 and 3: lanes 16..31 receive row 0's sum (lanes of rows 0 and 2 receive 0)
+    const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x142, 0xa, 0xf, false));
+    return s + below;
+}
+// (hipcc drops the second result of __builtin_amdgcn_permlane32_swap(m, m): one ds_bpermute per passage instead)
+__device__ __forceinline__ float max_lane_halves(float m) { return fmaxf(m, __shfl_xor(m, 32, 64)); }
+
+constexpr int kApproxThreads = 768;                 // 12 waves per work-group = 3 per SIMD, one work-group per CU
+constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slots x 8 B
 
 // ROWS = false: pass 1 over every candidate; besides the score it leaves tokmax[b][slot][32] = the per-token maxima
 //        a_t = max_j A[t][j] of every candidate passage as fp16 rounded DOWN.
@@ -652,8 +667,11 @@ __device__ __forceinline__ uint32_t byte_times8(uint32_t R, uint32_t three) {
 //        more permissive) a_t and writes rowmask[b][list position][4] x 64 bits; passages longer than kMaxMaskedRows
 //        embeddings are ignored downstream (the exact kernel then takes every row).  Comparisons are written
 //        !(v < lo): a NaN or an infinite window (guarded query, select_margin_kernel) selects the row.
-template <bool ROWS>
-static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
+// ABL != 0: ablation variants for the roofline analysis (instantiated only in -DCLB_ABLATIONS builds; results are
+// wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
+// stream; 4 non-temporal stream loads; 5 no LUT expansion / MFMA; 7 no memory access in the loop at all.
+template <bool ROWS, int ABL = 0>
+static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
     const float* __restrict__ inv_norm, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
@@ -665,19 +683,21 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
     const int wg = blockIdx.x >> 3;           // index inside the group
     const int wg_per_group = gridDim.x >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // byte LUT in LDS: blut[v] = bf16 bucket weights of the 4 dims packed in byte v (LSB-first 2-bit fields)
-    __shared__ uint2 blut[256];
-    __shared__ __attribute__((aligned(16))) float invx[4][kStepRows];
-    {
-        const int v = threadIdx.x;
-        blut[v] = make_uint2(pack_bf16(weights[v & 3], weights[(v >> 2) & 3]),
-                             pack_bf16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
+    // byte LUT in LDS: entry v = bf16 bucket weights of the 4 dims packed in residual byte v (LSB-first 2-bit fields),
+    // replicated once per lane slot (lane & 31) at v * 256 + slot * 8: every lane of a ds_read_b64 group reads its own
+    // bank pair, so the 16 table reads of a step are conflict-free whatever the bytes are (a single 2-KB table costs
+    // ~2 extra LDS cycles per read on random bytes and made the LDS pipe the busiest unit of the kernel)
+    __shared__ __attribute__((aligned(16))) unsigned char lut_s[kApproxLdsLut];
+    __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][kStepRows];
+    for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
+        const int v = i >> 5;
+        *reinterpret_cast<uint2*>(lut_s + (size_t)i * 8) =
+            make_uint2(pack_bf16(weights[v & 3], weights[(v >> 2) & 3]), pack_bf16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
     }
     __syncthreads();
-    const char* lut = reinterpret_cast<const char*>(blut);
+    const char* lut = reinterpret_cast<const char*>(lut_s);
     float* myinv = invx[wave];
-    uint32_t three = 3u;
-    asm volatile("" : "+v"(three));           // keep the SDWA shift amount in a VGPR
+    const uint32_t lane8 = 8u * (uint32_t)r;
 
     // selection matrices of the two score-row MFMAs: B1[k][col] = (col == k), B2[k][col] = (col == 16 + k), with
     // k = 8h + j held by lane (col = r, h) in element j
@@ -687,7 +707,6 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
         sel1[j] = (r == 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
         sel2[j] = (r == 16 + 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
     }
-    const uint32_t lane_res = (uint32_t)(r * 32 + 16 * h);   // byte offset of this lane's residual bytes in a step
 
     int b_first, b_step, sub, nsub;
     if (B >= 8) { b_first = x; b_step = 8; sub = 0; nsub = 1; }
@@ -722,13 +741,13 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
         unsigned long long* rmask = ROWS ? rowmask + (size_t)b * cand_cap * 4 : nullptr;
         const float window = ROWS ? 2.f * eps_pair[b] : 0.f;
         const int n = ROWS ? nlist[b] : ncand[b];
-        const int stride = wg_count * 4 * nsub;
+        const int stride = wg_count * (kApproxThreads / 64) * nsub;
         unsigned long long wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;   // ROWS: the current passage's mask (wave-uniform)
 
         // ---- wave-uniform iterator over the steps of passages j0, j0+stride, ... ------------------------------
         // The headers {first embedding, length} of the wave's next 64 passages sit in one VGPR pair (lane k =
         // k-th passage) and are extracted with v_readlane: no memory wait at a passage switch.
-        for (int j0 = (sub * wg_count + wg_index) * 4 + wave; j0 < n; j0 += 64 * stride) {
+        for (int j0 = (sub * wg_count + wg_index) * (kApproxThreads / 64) + wave; j0 < n; j0 += 64 * stride) {
         const int jl = j0 + lane * stride;
         int slot_l = jl < n ? jl : j0;                       // candidate slot of this lane's passage
         if (ROWS) slot_l = lst[slot_l];
@@ -748,10 +767,18 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
         const int left = live ? it_len - it_base : kStepRows;                                               \
         const int rows = left < kStepRows ? left : kStepRows;                                               \
         if (ROWS) PM = tmax[(size_t)(live ? it_slot : 0) * 32];   /* the passage's stored maximum of token r */ \
-        const uint32_t rr = (uint32_t)(r < rows ? r : rows - 1);   /* tail lanes duplicate the last row */  \
-        RB = *reinterpret_cast<const u32x4*>(residuals + (size_t)e0 * 32 + (rr * 32u + h16));               \
-        CV = codes0[(size_t)e0 + rr];                                                                       \
-        IV = inv_norm[(size_t)e0 + rr];                                                                     \
+        const uint32_t rr = min((uint32_t)r, (uint32_t)(rows - 1));   /* tail lanes duplicate the last row */ \
+        /* wave-uniform 64-bit bases + 32-bit lane offsets: the scalar-base form of global_load        */ \
+        const uint8_t* rbase_ = residuals + (size_t)e0 * 32;                                                \
+        const uint32_t* cbase_ = codes0 + (size_t)e0;                                                       \
+        const float* ibase_ = inv_norm + (size_t)e0;                                                        \
+        const uint32_t roff_ = rr * 32u + h16;                                                              \
+        if (ABL == 3 || ABL == 7) RB = u32x4{e0 * 2654435761u + rr, e0 ^ h16, e0 + 77u * rr, e0 * 40503u};  \
+        else if (ABL == 4) RB = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rbase_ + roff_)); \
+        else RB = *reinterpret_cast<const u32x4*>(rbase_ + roff_);                                          \
+        if (ABL == 7) { CV = (e0 * 97u + rr) & 131071u; IV = 1.f; }                                         \
+        else if (ABL == 4) { CV = __builtin_nontemporal_load(cbase_ + rr); IV = __builtin_nontemporal_load(ibase_ + rr); } \
+        else { CV = cbase_[rr]; IV = ibase_[rr]; }                                                          \
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \
         TAG.rows = rows;                                                                                    \
         TAG.last = left <= kStepRows;                                                                       \
@@ -769,17 +796,31 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
         // stage G: the score row of the lane's embedding: tokens 8h..8h+7 and 16+8h..16+8h+7 (fp16), 2 x 16 B
 #define CLB_STAGE_G(CV, X0, X1)                                                                             \
     {                                                                                                       \
-        const char* row_ = c16 + ((CV << 6) + h16);                                                         \
+        const char* row_ = c16 + (((ABL == 2 ? (CV & 1023u) : CV) << 6) + h16);                             \
+        if (ABL == 1 || ABL == 7) { X0 = u32x4{CV, CV, CV, CV}; X1 = X0; }                                  \
+        else {                                                                                              \
         X0 = *reinterpret_cast<const u32x4*>(row_);                                                         \
         X1 = *reinterpret_cast<const u32x4*>(row_ + 32);                                                    \
+        }                                                                                                   \
     }
-#define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + byte_times8<N>(W, three)))
+#define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + lut_offset<N>(W, lane8)))
 #define CLB_STAGE_C(RB, IV, X0, X1, PM, TAG)                                                                \
     {                                                                                                       \
         /* inv_norm: lane layout (row = r) -> accumulator layout (register i = row (i&3) + 8(i>>2) + 4h)  */ \
         __builtin_amdgcn_wave_barrier();                                                                    \
         myinv[r] = IV;                                                                                      \
         __builtin_amdgcn_wave_barrier();                                                                    \
+        /* residual byte -> 4 bf16 bucket weights through the LDS table; k-step s = bytes 2s, 2s+1.  All 16  */ \
+        /* reads are issued before the first MFMA (an LDS read takes longer than an MFMA: interleaved one  */ \
+        /* pair ahead, as the compiler schedules them on its own, the MFMA chain runs at the LDS latency)   */ \
+        uint2 tl[16];                                                                                       \
+        if (ABL != 5) {                                                                                     \
+            tl[0] = CLB_LUT(RB[0], 0); tl[1] = CLB_LUT(RB[0], 1); tl[2] = CLB_LUT(RB[0], 2); tl[3] = CLB_LUT(RB[0], 3);     \
+            tl[4] = CLB_LUT(RB[1], 0); tl[5] = CLB_LUT(RB[1], 1); tl[6] = CLB_LUT(RB[1], 2); tl[7] = CLB_LUT(RB[1], 3);     \
+            tl[8] = CLB_LUT(RB[2], 0); tl[9] = CLB_LUT(RB[2], 1); tl[10] = CLB_LUT(RB[2], 2); tl[11] = CLB_LUT(RB[2], 3);   \
+            tl[12] = CLB_LUT(RB[3], 0); tl[13] = CLB_LUT(RB[3], 1); tl[14] = CLB_LUT(RB[3], 2); tl[15] = CLB_LUT(RB[3], 3); \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
         f32x4 iq[4];                                                                                        \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                       \
             iq[q] = *reinterpret_cast<const f32x4*>(myinv + 8 * q + 4 * h);                                 \
@@ -787,29 +828,18 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
         _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                        \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X0), sel1, acc, 0, 0, 0);    \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, acc, 0, 0, 0);    \
-        /* residual byte -> 4 bf16 bucket weights through the 2-KB LDS table; k-step s = bytes 2s, 2s+1   */ \
-        {                                                                                                   \
-            const uint2 t0 = CLB_LUT(RB[0], 0), t1 = CLB_LUT(RB[0], 1);                                     \
-            const uint2 t2 = CLB_LUT(RB[0], 2), t3 = CLB_LUT(RB[0], 3);                                     \
-            const uint2 t4 = CLB_LUT(RB[1], 0), t5 = CLB_LUT(RB[1], 1);                                     \
-            const uint2 t6 = CLB_LUT(RB[1], 2), t7 = CLB_LUT(RB[1], 3);                                     \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t0.x, t0.y, t1.x, t1.y}), __builtin_bit_cast(bf16x8, qb[0]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t2.x, t2.y, t3.x, t3.y}), __builtin_bit_cast(bf16x8, qb[1]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t4.x, t4.y, t5.x, t5.y}), __builtin_bit_cast(bf16x8, qb[2]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t6.x, t6.y, t7.x, t7.y}), __builtin_bit_cast(bf16x8, qb[3]), acc, 0, 0, 0); \
-        }                                                                                                   \
-        {                                                                                                   \
-            const uint2 t0 = CLB_LUT(RB[2], 0), t1 = CLB_LUT(RB[2], 1);                                     \
-            const uint2 t2 = CLB_LUT(RB[2], 2), t3 = CLB_LUT(RB[2], 3);                                     \
-            const uint2 t4 = CLB_LUT(RB[3], 0), t5 = CLB_LUT(RB[3], 1);                                     \
-            const uint2 t6 = CLB_LUT(RB[3], 2), t7 = CLB_LUT(RB[3], 3);                                     \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t0.x, t0.y, t1.x, t1.y}), __builtin_bit_cast(bf16x8, qb[4]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t2.x, t2.y, t3.x, t3.y}), __builtin_bit_cast(bf16x8, qb[5]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t4.x, t4.y, t5.x, t5.y}), __builtin_bit_cast(bf16x8, qb[6]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{t6.x, t6.y, t7.x, t7.y}), __builtin_bit_cast(bf16x8, qb[7]), acc, 0, 0, 0); \
+        if (ABL == 5) { acc[0] += __uint_as_float(RB[0] ^ RB[1]); acc[1] += __uint_as_float(RB[2] ^ RB[3]); } \
+        else {                                                                                              \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                              \
+                    __builtin_bit_cast(bf16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
+                    __builtin_bit_cast(bf16x8, qb[s_]), acc, 0, 0, 0);                                      \
         }                                                                                                   \
         float v[16];                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = acc[i] * iq[i >> 2][i & 3];                   \
+        _Pragma("unroll") for (int i = 0; i < 16; i += 2) {    /* v_pk_mul_f32: two rows per instruction */ \
+            const f32x2 p_ = f32x2{acc[i], acc[i + 1]} * f32x2{iq[i >> 2][i & 3], iq[i >> 2][(i & 3) + 1]}; \
+            v[i] = p_[0]; v[i + 1] = p_[1];                                                                 \
+        }                                                                                                   \
         if (ROWS) {                                                                                         \
             const __half pmh = *reinterpret_cast<const __half*>(&PM);                                       \
             const float lo = r < T ? __half2float(pmh) - window : __builtin_inff();   /* tokens past T select nothing */ \
@@ -844,14 +874,9 @@ static __global__ __launch_bounds__(256, 2) void score_approx32_kernel(
             m67 = fmaxf(fmaxf(m67, m89), v[15]);                                                            \
             mx = fmaxf(fmaxf(mx, m01), m67);                                                                \
             if (TAG.last) {                                                                                 \
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                     \
-                float sum = r < T ? mx : 0.f;                                                               \
-                sum += __shfl_xor(sum, 1, 64);                                                              \
-                sum += __shfl_xor(sum, 2, 64);                                                              \
-                sum += __shfl_xor(sum, 4, 64);                                                              \
-                sum += __shfl_xor(sum, 8, 64);                                                              \
-                sum += __shfl_xor(sum, 16, 64);                                                             \
-                if (lane == 0 && TAG.j >= 0) out[TAG.j] = sum;                                              \
+                mx = max_lane_halves(mx);                                                                   \
+                const float sum = sum_lanes_0_31(r < T ? mx : 0.f);     /* valid in lanes 16..31 */         \
+                if (lane == 16 && TAG.j >= 0) out[TAG.j] = sum;                                             \
                 if (h == 0 && TAG.j >= 0) tmax[(size_t)TAG.j * 32] = (uint16_t)f32_to_f16_floor(mx);       \
                 mx = kNegInf;                                                                               \
             }                                                                                               \

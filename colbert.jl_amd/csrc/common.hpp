@@ -99,7 +99,7 @@ inline int tuning_knob(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-#define CLB_KNOB(NAME, DFLT) ([] { static const int v_ = clb::tuning_knob(NAME, DFLT); return v_; }())
+#define CLB_KNOB(NAME, DFLT) (clb::tuning_knob(NAME, DFLT))      // re-read on every call: a sweep can change it
 #else
 #define CLB_KNOB(NAME, DFLT) (DFLT)
 #endif

@@ -348,20 +348,35 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (two_pass) {
         {
             Timed t(s, KID_SCORE_APPROX, st);
-            const int wgpg = CLB_KNOB("CLB_DEBUG_APPROX_WGPG", 128);
+            const int wgpg = CLB_KNOB("CLB_DEBUG_APPROX_WGPG", 32);   // x 8 XCD groups: one 12-wave work-group per CU
             // Grid: XCD-affine 1-D launch (all work-groups of an XCD share one query's score table in L2) for
             // large candidate sets; for small ones (a shard of a multi-GPU run: < ~6 k candidate passages per
             // query, estimated from the mean IVF list) a (G, B) launch whose few waves per query each get a long
             // run of passages -- the pipeline fill otherwise dominates.
             const int approx_2d = CLB_KNOB("CLB_DEBUG_APPROX_2D", -1);
             const double est_cand = 0.5 * T * nprobe * (double)s->n_emb / (double)std::max<int64_t>(1, s->K);
-            const int gx2d = approx_2d >= 0 ? approx_2d : (est_cand < 6000.0 ? 1024 : 0);
+            const int gx2d = approx_2d >= 0 ? approx_2d : (est_cand < 6000.0 ? 256 : 0);
             const dim3 approx_grid = gx2d > 0 && B > 1 ? dim3(std::max(1, gx2d / B), B) : dim3(8 * wgpg);
-            hipLaunchKernelGGL(score_approx32_kernel<false>, approx_grid, dim3(256), 0, st, s->weights.as<float>(),
-                               s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
-                               w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                               (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
-                               (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
+#define CLB_LAUNCH_APPROX(ABL)                                                                                        \
+    hipLaunchKernelGGL((score_approx32_kernel<false, ABL>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(), \
+                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
+                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(), \
+                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,                    \
+                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
+#ifdef CLB_ABLATIONS
+            switch (CLB_KNOB("CLB_DEBUG_APPROX_VARIANT", 0)) {
+                case 1: CLB_LAUNCH_APPROX(1); break;
+                case 2: CLB_LAUNCH_APPROX(2); break;
+                case 3: CLB_LAUNCH_APPROX(3); break;
+                case 4: CLB_LAUNCH_APPROX(4); break;
+                case 5: CLB_LAUNCH_APPROX(5); break;
+                case 7: CLB_LAUNCH_APPROX(7); break;
+                default: CLB_LAUNCH_APPROX(0);
+            }
+#else
+            CLB_LAUNCH_APPROX(0);
+#endif
+#undef CLB_LAUNCH_APPROX
         }
         {
             Timed t(s, KID_SELECT, st);
@@ -383,9 +398,9 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (subset) {
         Timed t(s, KID_ROWS, st);
         // the pass-1 pipeline again, over the listed passages only: marks the rows that can hold a token maximum
-        const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 1024);
-        const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 128);
-        hipLaunchKernelGGL(score_approx32_kernel<true>, rows_grid, dim3(256), 0, st, s->weights.as<float>(),
+        const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 256);
+        const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 32);
+        hipLaunchKernelGGL(score_approx32_kernel<true>, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                            s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                            (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
@@ -731,7 +746,7 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
-    hipLaunchKernelGGL(score_approx32_kernel<false>, dim3(8 * 128), dim3(256), 0, st, s->weights.as<float>(),
+    hipLaunchKernelGGL(score_approx32_kernel<false>, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                        s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                        (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
