@@ -370,6 +370,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 case 3: CLB_LAUNCH_APPROX(3); break;
                 case 4: CLB_LAUNCH_APPROX(4); break;
                 case 5: CLB_LAUNCH_APPROX(5); break;
+                case 6: CLB_LAUNCH_APPROX(6); break;
                 case 7: CLB_LAUNCH_APPROX(7); break;
                 default: CLB_LAUNCH_APPROX(0);
             }
