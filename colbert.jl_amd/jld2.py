@@ -1,0 +1,366 @@
+"""JLD2 files of the reference's index directory, without Julia: `save_object` / `load_object`.
+
+The reference persists every array with `JLD2.save_object(path, x)` / `JLD2.load_object(path)`
+(src/savers.jl:16-29,52-84; src/loaders.jl:10-38,76-140; src/indexing.jl:82-85,140-143).  JLD2 is an HDF5
+subset: a 512-byte text header, an HDF5 version-2 superblock with base address 512, a root group whose
+object header carries one hard link named "single_stored_object", and one dataset object header
+(dataspace, datatype, data-layout messages) with compact or contiguous raw data.  Julia arrays are
+column-major, so the dataspace lists the dimensions reversed.
+
+Only what the index needs is implemented: Float32/Float64/Int and UInt 8..64 scalars and dense arrays
+(`Matrix{Float32}`, `Vector{Float32}`, `Vector{UInt32}`, `Matrix{UInt8}`, `Vector{Int64}`, `Float32`).
+The reader accepts superblock versions 2/3 at offsets 0, 512, 1024, ...; object headers version 2 (with
+continuation blocks) and version 1; dataspace versions 1/2; data layout versions 3/4, compact or contiguous,
+no filters.  Every structure the writer emits is checksummed as HDF5 requires (Jenkins lookup3).
+
+COMPATIBILITY IS UNVERIFIED against JLD2.jl itself: neither Julia nor an HDF5 library exists in the build
+image.  The layout follows the HDF5 file-format specification and JLD2's conventions as documented; files
+written here round-trip through this reader (tests/test_jld2.py)."""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+FILE_HEADER_LENGTH = 512
+REQUIRED_FILE_HEADER = b"HDF5-based Julia Data Format, version "
+FORMAT_VERSION = b"0.1.1"
+H5_SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEFINED = 0xFFFFFFFFFFFFFFFF
+OBJECT_NAME = "single_stored_object"
+COMPACT_LIMIT = 8192          # raw data below this size is stored inside the object header (compact layout)
+
+# header message types (HDF5 spec IV.A.2)
+HM_NIL, HM_DATASPACE, HM_LINK_INFO, HM_DATATYPE, HM_FILL_OLD, HM_FILL, HM_LINK = 0, 1, 2, 3, 4, 5, 6
+HM_LAYOUT, HM_GROUP_INFO, HM_FILTER, HM_ATTRIBUTE, HM_CONTINUATION, HM_SYMBOL_TABLE = 8, 10, 11, 12, 16, 17
+
+
+class JLD2Error(ValueError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# Jenkins lookup3 `hashlittle` (HDF5's H5_checksum_lookup3, initval 0)
+# ---------------------------------------------------------------------------------------------------
+def _rot(x, k):
+    return ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF
+
+
+def lookup3(data: bytes, initval: int = 0) -> int:
+    n = len(data)
+    a = b = c = (0xDEADBEEF + n + initval) & 0xFFFFFFFF
+    i = 0
+    M = 0xFFFFFFFF
+    while n > 12:
+        a = (a + int.from_bytes(data[i:i + 4], "little")) & M
+        b = (b + int.from_bytes(data[i + 4:i + 8], "little")) & M
+        c = (c + int.from_bytes(data[i + 8:i + 12], "little")) & M
+        a = (a - c) & M; a ^= _rot(c, 4); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 6); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 8); b = (b + a) & M
+        a = (a - c) & M; a ^= _rot(c, 16); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 19); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 4); b = (b + a) & M
+        i += 12; n -= 12
+    if n == 0:
+        return c
+    tail = data[i:] + b"\x00" * (12 - n)
+    a = (a + int.from_bytes(tail[0:4], "little")) & M
+    b = (b + int.from_bytes(tail[4:8], "little")) & M
+    c = (c + int.from_bytes(tail[8:12], "little")) & M
+    c ^= b; c = (c - _rot(b, 14)) & M
+    a ^= c; a = (a - _rot(c, 11)) & M
+    b ^= a; b = (b - _rot(a, 25)) & M
+    c ^= b; c = (c - _rot(b, 16)) & M
+    a ^= c; a = (a - _rot(c, 4)) & M
+    b ^= a; b = (b - _rot(a, 14)) & M
+    c ^= b; c = (c - _rot(b, 24)) & M
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------
+# datatypes
+# ---------------------------------------------------------------------------------------------------
+_DT_VERSION = 3      # JLD2 tags its datatype messages with version 3; any version 1..3 is read
+
+
+def _datatype_message(dt: np.dtype) -> bytes:
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        # class 1: little-endian, mantissa normalisation "implied", sign bit = MSB
+        if dt.itemsize == 4:
+            return struct.pack("<BBBBIHHBBBBI", (_DT_VERSION << 4) | 1, 0x20, 31, 0, 4, 0, 32, 23, 8, 0, 23, 127)
+        return struct.pack("<BBBBIHHBBBBI", (_DT_VERSION << 4) | 1, 0x20, 63, 0, 8, 0, 64, 52, 11, 0, 52, 1023)
+    if dt.kind in "iu" and dt.itemsize in (1, 2, 4, 8):
+        return struct.pack("<BBBBIHH", (_DT_VERSION << 4) | 0, 0x08 if dt.kind == "i" else 0x00, 0, 0, dt.itemsize, 0,
+                           8 * dt.itemsize)
+    raise JLD2Error(f"unsupported element type {dt}")
+
+
+def _parse_datatype(msg: bytes) -> np.dtype:
+    cls = msg[0] & 0x0F
+    bits0 = msg[1]
+    size = struct.unpack_from("<I", msg, 4)[0]
+    if bits0 & 1:
+        raise JLD2Error("big-endian data is not supported")
+    if cls == 0:
+        signed = bool(bits0 & 0x08)
+        off, prec = struct.unpack_from("<HH", msg, 8)
+        if off != 0 or prec != 8 * size or size not in (1, 2, 4, 8):
+            raise JLD2Error("unsupported fixed-point layout")
+        return np.dtype(f"<{'i' if signed else 'u'}{size}")
+    if cls == 1:
+        if size == 4:
+            return np.dtype("<f4")
+        if size == 8:
+            return np.dtype("<f8")
+        if size == 2:
+            return np.dtype("<f2")
+    raise JLD2Error(f"unsupported datatype class {cls} (only plain numbers are stored in a ColBERT index)")
+
+
+# ---------------------------------------------------------------------------------------------------
+# writer
+# ---------------------------------------------------------------------------------------------------
+def _header_message(mtype: int, body: bytes, flags: int = 0) -> bytes:
+    return struct.pack("<BHB", mtype, len(body), flags) + body
+
+
+def _object_header(messages: list[bytes]) -> bytes:
+    """Version-2 object header, one chunk, 4-byte chunk size, no times / attribute phase change."""
+    payload = b"".join(messages)
+    head = b"OHDR" + struct.pack("<BB", 2, 0x02) + struct.pack("<I", len(payload))     # flags: chunk#0 size is 4 bytes
+    blob = head + payload
+    return blob + struct.pack("<I", lookup3(blob))
+
+
+def save_object(path: str, obj) -> None:
+    """JLD2.save_object(path, obj) for a number or a dense numeric array (Julia shape = numpy shape, column-major)."""
+    a = np.asarray(obj)
+    if a.dtype.byteorder == ">":
+        a = a.astype(a.dtype.newbyteorder("<"))
+    dtmsg = _datatype_message(a.dtype)
+    raw = np.asfortranarray(a).tobytes(order="F")       # column-major element order == Julia's memory
+    if a.ndim == 0:
+        dataspace = struct.pack("<BBBB", 2, 0, 0, 0)    # version 2, rank 0, flags 0, type 0 = scalar
+    else:
+        dims = tuple(reversed(a.shape))                 # HDF5 is row-major: fastest dimension last
+        dataspace = struct.pack("<BBBB", 2, len(dims), 0, 1) + b"".join(struct.pack("<Q", int(d)) for d in dims)
+    compact = len(raw) < COMPACT_LIMIT
+    base = FILE_HEADER_LENGTH
+    superblock_size = 48
+    ds_addr = superblock_size                            # addresses are relative to the base address
+    msgs = [_header_message(HM_DATASPACE, dataspace), _header_message(HM_DATATYPE, dtmsg, flags=1)]
+    if compact:
+        layout = struct.pack("<BBH", 3, 0, len(raw)) + raw
+        msgs.append(_header_message(HM_LAYOUT, layout))
+        dataset = _object_header(msgs)
+        data_addr, tail = None, b""
+    else:
+        # the header's size does not depend on the address, so it can be sized first
+        probe = _object_header(msgs + [_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, 0, len(raw)))])
+        data_addr = (ds_addr + len(probe) + 7) // 8 * 8
+        msgs.append(_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, data_addr, len(raw))))
+        dataset = _object_header(msgs)
+        tail = b"\x00" * (data_addr - ds_addr - len(dataset)) + raw
+    root_addr = (ds_addr + len(dataset) + len(tail) + 7) // 8 * 8
+    name = OBJECT_NAME.encode()
+    link = struct.pack("<BBB", 1, 0x00, len(name)) + name + struct.pack("<Q", ds_addr)   # hard link, 1-byte name length
+    root = _object_header([
+        _header_message(HM_LINK_INFO, struct.pack("<BBQQ", 0, 0, UNDEFINED, UNDEFINED)),
+        _header_message(HM_GROUP_INFO, struct.pack("<BB", 0, 0)),
+        _header_message(HM_LINK, link)])
+    eof = root_addr + len(root)
+    sb = H5_SIGNATURE + struct.pack("<BBBB", 2, 8, 8, 0) + struct.pack("<QQQQ", base, UNDEFINED, eof, root_addr)
+    sb += struct.pack("<I", lookup3(sb))
+    assert len(sb) == superblock_size
+    text = (REQUIRED_FILE_HEADER + FORMAT_VERSION + b"\x00 (colbert.jl_amd python writer, 64-bit little-endian)")
+    body = sb + dataset + tail
+    body += b"\x00" * (root_addr - len(body)) + root
+    with open(path, "wb") as f:
+        f.write(text + b"\x00" * (FILE_HEADER_LENGTH - len(text)))
+        f.write(body)
+
+
+# ---------------------------------------------------------------------------------------------------
+# reader
+# ---------------------------------------------------------------------------------------------------
+class _File:
+    def __init__(self, path: str):
+        with open(path, "rb") as f:
+            self.buf = f.read()
+        self.base = None
+        off = 0
+        while off + 8 <= len(self.buf):
+            if self.buf[off:off + 8] == H5_SIGNATURE:
+                self.sb = off
+                break
+            off = 512 if off == 0 else off * 2
+        else:
+            raise JLD2Error(f"{path}: no HDF5 superblock found")
+        ver = self.buf[self.sb + 8]
+        if ver not in (2, 3):
+            raise JLD2Error(f"{path}: superblock version {ver} is not supported (JLD2 writes version 2)")
+        so, sl = self.buf[self.sb + 9], self.buf[self.sb + 10]
+        if so != 8 or sl != 8:
+            raise JLD2Error("only 8-byte offsets and lengths are supported")
+        self.base, _ext, self.eof, self.root = struct.unpack_from("<QQQQ", self.buf, self.sb + 12)
+        stored = struct.unpack_from("<I", self.buf, self.sb + 44)[0]
+        if stored != lookup3(self.buf[self.sb:self.sb + 44]):
+            raise JLD2Error(f"{path}: superblock checksum mismatch")
+
+    def at(self, addr: int) -> int:
+        return self.base + addr
+
+    # -- object headers ---------------------------------------------------------------------------
+    def messages(self, addr: int):
+        """[(type, flags, body bytes)] of the object header at `addr` (relative address)."""
+        p = self.at(addr)
+        if self.buf[p:p + 4] == b"OHDR":
+            return self._messages_v2(p)
+        return self._messages_v1(p)
+
+    def _messages_v2(self, p: int):
+        if self.buf[p + 4] != 2:
+            raise JLD2Error("unsupported object header version")
+        flags = self.buf[p + 5]
+        q = p + 6
+        if flags & 0x20:
+            q += 16
+        if flags & 0x10:
+            q += 4
+        nsz = 1 << (flags & 3)
+        size = int.from_bytes(self.buf[q:q + nsz], "little")
+        q += nsz
+        if struct.unpack_from("<I", self.buf, q + size)[0] != lookup3(self.buf[p:q + size]):
+            raise JLD2Error("object header checksum mismatch")
+        out = []
+        blocks = [(q, q + size)]
+        while blocks:
+            lo, hi = blocks.pop(0)
+            while lo + 4 <= hi:
+                mtype = self.buf[lo]
+                msize, mflags = struct.unpack_from("<HB", self.buf, lo + 1)
+                lo += 4
+                if flags & 0x04:
+                    lo += 2                                  # creation order
+                body = self.buf[lo:lo + msize]
+                lo += msize
+                if mtype == HM_CONTINUATION:
+                    caddr, clen = struct.unpack_from("<QQ", body, 0)
+                    cp = self.at(caddr)
+                    if self.buf[cp:cp + 4] != b"OCHK":
+                        raise JLD2Error("bad continuation block")
+                    if struct.unpack_from("<I", self.buf, cp + clen - 4)[0] != lookup3(self.buf[cp:cp + clen - 4]):
+                        raise JLD2Error("continuation block checksum mismatch")
+                    blocks.append((cp + 4, cp + clen - 4))
+                elif mtype != HM_NIL:
+                    out.append((mtype, mflags, body))
+        return out
+
+    def _messages_v1(self, p: int):
+        if self.buf[p] != 1:
+            raise JLD2Error("unsupported object header")
+        nmsg = struct.unpack_from("<H", self.buf, p + 2)[0]
+        size = struct.unpack_from("<I", self.buf, p + 8)[0]
+        out = []
+        blocks = [(p + 16, p + 16 + size)]
+        while blocks and len(out) < nmsg + 64:
+            lo, hi = blocks.pop(0)
+            while lo + 8 <= hi:
+                mtype, msize, mflags = struct.unpack_from("<HHB", self.buf, lo)
+                lo += 8
+                body = self.buf[lo:lo + msize]
+                lo += msize
+                if mtype == HM_CONTINUATION:
+                    caddr, clen = struct.unpack_from("<QQ", body, 0)
+                    blocks.append((self.at(caddr), self.at(caddr) + clen))
+                elif mtype != HM_NIL:
+                    out.append((mtype, mflags, body))
+        return out
+
+    # -- groups -----------------------------------------------------------------------------------
+    def links(self, addr: int) -> dict:
+        out = {}
+        for mtype, _f, body in self.messages(addr):
+            if mtype == HM_LINK:
+                lflags = body[1]
+                q = 2
+                ltype = 0
+                if lflags & 0x08:
+                    ltype = body[q]; q += 1
+                if lflags & 0x04:
+                    q += 8
+                if lflags & 0x10:
+                    q += 1
+                nsz = 1 << (lflags & 3)
+                nlen = int.from_bytes(body[q:q + nsz], "little")
+                q += nsz
+                name = body[q:q + nlen].decode()
+                q += nlen
+                if ltype == 0:
+                    out[name] = struct.unpack_from("<Q", body, q)[0]
+            elif mtype == HM_SYMBOL_TABLE:
+                raise JLD2Error("old-style (symbol table) groups are not supported")
+            elif mtype == HM_LINK_INFO:
+                heap = struct.unpack_from("<Q", body, 2 + (8 if body[1] & 1 else 0))[0]
+                if heap != UNDEFINED:
+                    raise JLD2Error("dense link storage (fractal heap) is not supported")
+        return out
+
+    # -- datasets ---------------------------------------------------------------------------------
+    def dataset(self, addr: int):
+        shape = dtype = None
+        raw = None
+        for mtype, _f, body in self.messages(addr):
+            if mtype == HM_DATASPACE:
+                ver, rank = body[0], body[1]
+                if ver == 2:
+                    kind = body[3]
+                    q = 4
+                elif ver == 1:
+                    kind = 1 if rank else 0
+                    q = 8
+                else:
+                    raise JLD2Error("unsupported dataspace version")
+                if kind == 2:
+                    raise JLD2Error("null dataspace")
+                shape = tuple(struct.unpack_from("<Q", body, q + 8 * i)[0] for i in range(rank))
+            elif mtype == HM_DATATYPE:
+                dtype = _parse_datatype(body)
+            elif mtype == HM_FILTER:
+                raise JLD2Error("compressed datasets are not supported")
+            elif mtype == HM_LAYOUT:
+                ver, cls = body[0], body[1]
+                if ver not in (3, 4):
+                    raise JLD2Error(f"unsupported data layout version {ver}")
+                if cls == 0:
+                    n = struct.unpack_from("<H", body, 2)[0]
+                    raw = body[4:4 + n]
+                elif cls == 1:
+                    daddr, n = struct.unpack_from("<QQ", body, 2)
+                    raw = b"" if daddr == UNDEFINED else self.buf[self.at(daddr):self.at(daddr) + n]
+                else:
+                    raise JLD2Error("chunked datasets are not supported")
+        if shape is None or dtype is None or raw is None:
+            raise JLD2Error("dataset lacks a dataspace, datatype or layout message")
+        count = int(np.prod(shape)) if shape else 1
+        if len(raw) < count * dtype.itemsize:
+            raise JLD2Error("dataset is truncated")
+        flat = np.frombuffer(raw, dtype=dtype, count=count)
+        if not shape:
+            return flat[0]
+        # HDF5 dims are the Julia dims reversed; the bytes are Julia's column-major memory
+        return np.asfortranarray(flat.reshape(tuple(reversed(shape)), order="F"))
+
+
+def load_object(path: str):
+    """JLD2.load_object(path): the array (Julia shape, column-major) or number stored in the file."""
+    f = _File(path)
+    links = f.links(f.root)
+    if OBJECT_NAME in links:
+        return f.dataset(links[OBJECT_NAME])
+    data = [a for n, a in links.items() if not n.startswith("_")]
+    if len(data) == 1:                         # JLD2.load_object accepts any file with exactly one dataset
+        return f.dataset(data[0])
+    raise JLD2Error(f"{path}: expected one dataset named {OBJECT_NAME!r}, found {sorted(links)}")

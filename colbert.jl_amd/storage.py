@@ -1,6 +1,6 @@
-"""Index directory I/O.  The reference writes JLD2 (HDF5) + JSON files (src/savers.jl, src/loaders.jl);
-this host driver keeps the reference's file stems and JSON files but stores arrays as .npy (the Julia
-shim goes through JLD2.jl instead).  A JLD2-compatible reader/writer is listed as next work in DESIGN.md.
+"""Index directory I/O with the reference's layout: JLD2 (HDF5 subset) + JSON files (src/savers.jl,
+src/loaders.jl, src/indexing.jl:82-85,140-143).  Arrays go through `jld2.save_object` / `jld2.load_object`, the
+Python counterparts of `JLD2.save_object` / `JLD2.load_object` (see jld2.py for what is and is not verified).
 
 Files: config.json, plan.json, centroids / bucket_cutoffs / bucket_weights /
 avg_residual, <i>.codes, <i>.residuals, doclens.<i>, <i>.metadata.json, ivf, ivf_lengths (chunks 1-based)."""
@@ -11,13 +11,17 @@ import os
 
 import numpy as np
 
+from . import jld2
+
+EXT = ".jld2"
+
 
 def _save(path: str, a) -> None:
-    np.save(path + ".npy", np.asarray(a))
+    jld2.save_object(path + EXT, a)
 
 
 def _load(path: str):
-    return np.load(path + ".npy")
+    return jld2.load_object(path + EXT)
 
 
 def save_codec(index_path, centroids, bucket_cutoffs, bucket_weights, avg_residual) -> None:
@@ -54,10 +58,10 @@ def check_all_files_are_saved(index_path: str) -> bool:
     if not os.path.isfile(os.path.join(index_path, "plan.json")):
         return False
     plan = load_json(index_path, "plan.json")
-    files = ["config.json"] + [s + ".npy" for s in ("centroids", "bucket_cutoffs", "bucket_weights", "avg_residual",
-                                                    "ivf", "ivf_lengths")]
+    files = ["config.json"] + [s + EXT for s in ("centroids", "bucket_cutoffs", "bucket_weights", "avg_residual",
+                                                  "ivf", "ivf_lengths")]
     for i in range(1, plan["num_chunks"] + 1):
-        files += [f"{i}.codes.npy", f"{i}.residuals.npy", f"doclens.{i}.npy", f"{i}.metadata.json"]
+        files += [f"{i}.codes{EXT}", f"{i}.residuals{EXT}", f"doclens.{i}{EXT}", f"{i}.metadata.json"]
     return all(os.path.isfile(os.path.join(index_path, f)) for f in files)
 
 
@@ -74,7 +78,7 @@ def load_index(index_path: str) -> dict:
             "centroids": _load(os.path.join(index_path, "centroids")),
             "bucket_cutoffs": _load(os.path.join(index_path, "bucket_cutoffs")),
             "bucket_weights": _load(os.path.join(index_path, "bucket_weights")),
-            "avg_residual": _load(os.path.join(index_path, "avg_residual")),
+            "avg_residual": np.float32(_load(os.path.join(index_path, "avg_residual"))),
             "codes": np.concatenate(codes), "residuals": np.asfortranarray(np.concatenate(res, axis=1)),
             "doclens": np.concatenate(dl), "ivf": _load(os.path.join(index_path, "ivf")),
             "ivf_lengths": _load(os.path.join(index_path, "ivf_lengths"))}
