@@ -1,234 +1,31 @@
-# ColBERT.jl shim over libcolbert_hip.so (include/colbert_hip.h).
+# ColBERT.jl over libcolbert_hip.so (include/colbert_hip.h) -- the MI355X-native hot path behind the
+# reference's public surface: ColBERTConfig, Indexer, index, Searcher, search (JuliaGenAI/ColBERT.jl
+# src/ColBERT.jl:21,35,40), so that examples/indexing.jl and examples/searching.jl run unchanged.
 #
-# Keeps the reference's public surface -- ColBERTConfig, Indexer, index, Searcher, search
-# (JuliaGenAI/ColBERT.jl src/ColBERT.jl:21,35,40) -- and replaces the bodies of the hot-path functions
-# with one `ccall` each.  Pure marshalling: pointers, lengths, status codes.  Julia arrays are passed as
-# Ptr{T} under GC.@preserve; they are column-major and 1-based exactly as the C ABI expects, so nothing is
-# copied or re-indexed on the Julia side.  This file cannot be executed in the build image (no `julia`);
-# every code path it drives is exercised through the Python ctypes driver over the same ABI.
+# What stays Julia: configuration, the index directory (JLD2 + JSON, the reference's file layout), text ->
+# token ids, the orchestration of index().  What becomes one `ccall` each: the BERT + Dense forward and its
+# epilogues, k-means, codec statistics, compress, the IVF build, and everything search() does after the encoder.
+# Flux / Transformers.jl / CUDA.jl are not needed: the weights are read from the flat export that
+# tools/export_checkpoint.py writes next to the HuggingFace checkpoint.
+#
+# This package cannot be executed in the build image (no `julia`); it is kept to marshalling and host glue, and
+# every device code path it drives is exercised through the Python ctypes driver over the same ABI.
 module ColBERT
+
+using JLD2
+using JSON
+using Logging
+using Random
+using Unicode
 
 export ColBERTConfig, Indexer, index, Searcher, search
 
-const libcolbert = get(ENV, "COLBERT_HIP_LIB", "libcolbert_hip.so")
-
-# ---- errors: codes 1..4 map 1:1 onto the exceptions the reference throws -------------------------------
-function _check(rc::Cint)
-    rc == 0 && return nothing
-    msg = unsafe_string(ccall((:clb_last_error, libcolbert), Cstring, ()))
-    rc == 1 && throw(DimensionMismatch(msg))
-    rc == 2 && throw(DomainError(msg))
-    rc == 3 && throw(BoundsError(msg))
-    rc == 4 && throw(ArgumentError(msg))
-    error("libcolbert_hip error $rc: $msg")
-end
-
-# ---- config: the reference's struct, verbatim field names and defaults (src/infra/config.jl:54-90) ------
-Base.@kwdef struct ColBERTConfig
-    use_gpu::Bool = false
-    rank::Int = 0
-    nranks::Int = 1
-    query_token_id::String = "[unused0]"
-    doc_token_id::String = "[unused1]"
-    query_token::String = "[Q]"
-    doc_token::String = "[D]"
-    checkpoint::String = "colbert-ir/colbertv2.0"
-    collection::Union{String, Vector{String}} = ""
-    dim::Int = 128
-    doc_maxlen::Int = 300
-    mask_punctuation::Bool = true
-    query_maxlen::Int = 32
-    attend_to_mask_tokens::Bool = false
-    index_path::String = ""
-    index_bsize::Int = 64
-    chunksize::Union{Missing, Int} = 25000
-    passages_batch_size::Int = 5000
-    nbits::Int = 2
-    kmeans_niters::Int = 20
-    nprobe::Int = 2
-    ncandidates::Int = 8192
-end
-
-# ---- Searcher: the index lives in HBM behind an opaque handle (reference: src/searching.jl:1-80) --------
-mutable struct Searcher
-    config::ColBERTConfig
-    handle::Ptr{Cvoid}
-    encode_queries::Function      # (queries::Vector{String}) -> Array{Float32,3} (dim, query_maxlen, n)
-    function Searcher(config, handle, enc)
-        s = new(config, handle, enc)
-        finalizer(s -> ccall((:clb_searcher_destroy, libcolbert), Cint, (Ptr{Cvoid},), s.handle), s)
-    end
-end
-
-"""
-    Searcher(config, centroids, bucket_weights, doclens, codes, residuals, ivf, ivf_lengths; device, pid_offset)
-
-Replaces the array-holding part of `Searcher(index_path)` (src/searching.jl:44-59): the arrays
-`load_codec`, `load_doclens`, `load_compressed_embs` and the ivf files return are uploaded once.
-"""
-function Searcher(config::ColBERTConfig, centroids::Matrix{Float32}, bucket_weights::Vector{Float32},
-        doclens::Vector{Int}, codes::Vector{UInt32}, residuals::Matrix{UInt8}, ivf::Vector{Int},
-        ivf_lengths::Vector{Int}; device::Int = 0, pid_offset::Int = 0, encode_queries = q -> error("no encoder"))
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve centroids bucket_weights doclens codes residuals ivf ivf_lengths begin
-        _check(ccall((:clb_searcher_create, libcolbert), Cint,
-            (Cint, Int64, Cint, Int64, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Int64}, Int64, Ptr{UInt32},
-                Ptr{UInt8}, Ptr{Int64}, Ptr{Int64}, Int64, Ref{Ptr{Cvoid}}),
-            device, size(centroids, 1), config.nbits, size(centroids, 2), centroids, bucket_weights,
-            length(doclens), doclens, length(codes), codes, residuals, ivf, ivf_lengths, pid_offset, h))
-    end
-    Searcher(config, h[], encode_queries)
-end
-
-"""
-    search(searcher, query::String, k) -> (pids::Vector{Int}, scores::Vector{Float32})
-
-Same contract as src/searching.jl:93-128; everything after `encode_queries` is one library call.
-"""
-function search(searcher::Searcher, query::String, k::Int)
-    Q = searcher.encode_queries([query])
-    @assert size(Q, 3) == 1 "size(Q): $(size(Q))"
-    @assert size(Q, 2) == searcher.config.query_maxlen
-    search(searcher, reshape(Q, size(Q, 1), size(Q, 2)), k)
-end
-
-function search(searcher::Searcher, Q::Matrix{Float32}, k::Int)
-    pids = Vector{Int}(undef, k)
-    scores = Vector{Float32}(undef, k)
-    ncand = Ref{Int64}(0)
-    GC.@preserve Q pids scores begin
-        _check(ccall((:clb_search, libcolbert), Cint,
-            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float32}, Ref{Int64}),
-            searcher.handle, Q, size(Q, 2), searcher.config.nprobe, k, pids, scores, ncand))
-    end
-    pids, scores
-end
-
-# ---- codec / index-build call sites (src/indexing/codecs/residual.jl, src/utils.jl, collection_indexer.jl)
-function compress(centroids::Matrix{Float32}, bucket_cutoffs::Vector{Float32}, dim::Int, nbits::Int,
-        embs::AbstractMatrix{Float32}; device::Int = 0)
-    embs = Matrix{Float32}(embs)
-    codes = zeros(UInt32, size(embs, 2))
-    residuals = Matrix{UInt8}(undef, div(dim, 8) * nbits, size(embs, 2))
-    GC.@preserve centroids bucket_cutoffs embs codes residuals begin
-        _check(ccall((:clb_compress, libcolbert), Cint,
-            (Cint, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Int64, Cint, Ptr{Float32}, Int64, Ptr{UInt32}, Ptr{UInt8}),
-            device, centroids, size(centroids, 2), bucket_cutoffs, length(bucket_cutoffs), dim, nbits, embs,
-            size(embs, 2), codes, residuals))
-    end
-    codes, residuals
-end
-
-function decompress(dim::Int, nbits::Int, centroids::Matrix{Float32}, bucket_weights::Vector{Float32},
-        codes::Vector{UInt32}, residuals::AbstractMatrix{UInt8}; device::Int = 0)
-    residuals = Matrix{UInt8}(residuals)
-    out = Matrix{Float32}(undef, dim, length(codes))
-    GC.@preserve centroids bucket_weights codes residuals out begin
-        _check(ccall((:clb_decompress, libcolbert), Cint,
-            (Cint, Int64, Cint, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Ptr{UInt32}, Int64, Ptr{UInt8}, Int64, Int64, Ptr{Float32}),
-            device, dim, nbits, centroids, size(centroids, 2), bucket_weights, length(bucket_weights), codes,
-            length(codes), residuals, size(residuals, 1), size(residuals, 2), out))
-    end
-    out
-end
-
-"kmeans_gpu_onehot! (src/utils.jl:253-318); `centroids` holds the initial centroids and is updated in place."
-function kmeans_gpu_onehot!(data::Matrix{Float32}, centroids::Matrix{Float32}, k::Int; max_iters::Int = 10,
-        tol::Float32 = 1.0f-4, point_bsize::Int = 1000, device::Int = 0)
-    size(centroids, 2) == k || throw(DimensionMismatch("size(centroids, 2) must be k!"))
-    assignments = Vector{Int32}(undef, size(data, 2))
-    iters = Ref{Int64}(0)
-    GC.@preserve data centroids assignments begin
-        _check(ccall((:clb_kmeans, libcolbert), Cint,
-            (Cint, Ptr{Float32}, Int64, Int64, Ptr{Float32}, Int64, Int64, Float32, Int64, Ptr{Int32}, Ref{Int64}),
-            device, data, size(data, 1), size(data, 2), centroids, k, max_iters, tol, point_bsize, assignments, iters))
-    end
-    assignments
-end
-
-function _compute_avg_residuals!(nbits::Int, centroids::Matrix{Float32}, heldout::Matrix{Float32},
-        codes::Vector{UInt32}; device::Int = 0)
-    cutoffs = Vector{Float32}(undef, (1 << nbits) - 1)
-    weights = Vector{Float32}(undef, 1 << nbits)
-    avg = Ref{Float32}(0)
-    GC.@preserve centroids heldout codes cutoffs weights begin
-        _check(ccall((:clb_compute_avg_residuals, libcolbert), Cint,
-            (Cint, Cint, Ptr{Float32}, Int64, Int64, Ptr{Float32}, Int64, Ptr{UInt32}, Int64, Ptr{Float32}, Ptr{Float32}, Ref{Float32}),
-            device, nbits, centroids, size(centroids, 1), size(centroids, 2), heldout, size(heldout, 2), codes,
-            length(codes), cutoffs, weights, avg))
-    end
-    cutoffs, weights, avg[]
-end
-
-function _build_ivf(codes::Vector{UInt32}, num_partitions::Int; device::Int = 0)
-    ivf = Vector{Int}(undef, length(codes))
-    ivf_lengths = Vector{Int}(undef, num_partitions)
-    GC.@preserve codes ivf ivf_lengths begin
-        _check(ccall((:clb_build_ivf, libcolbert), Cint, (Cint, Ptr{UInt32}, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
-            device, codes, length(codes), num_partitions, ivf, ivf_lengths))
-    end
-    ivf, ivf_lengths
-end
-
-# ---- encoder: the BERT + Dense weights live on the device (reference: src/modelling/checkpoint.jl) ---------------
-mutable struct Checkpoint
-    handle::Ptr{Cvoid}
-    dim::Int
-    function Checkpoint(weights::Vector{Float32}; vocab::Int, hidden::Int, layers::Int, heads::Int,
-            intermediate::Int, max_pos::Int, type_vocab::Int = 2, dim::Int = 128, ln_eps::Float32 = 1.0f-12,
-            device::Int = 0)
-        h = Ref{Ptr{Cvoid}}(C_NULL)
-        GC.@preserve weights _check(ccall((:clb_encoder_create, libcolbert), Cint,
-            (Cint, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Float32, Ptr{Float32}, Int64, Ref{Ptr{Cvoid}}),
-            device, vocab, hidden, layers, heads, intermediate, max_pos, type_vocab, dim, ln_eps, weights,
-            length(weights), h))
-        c = new(h[], dim)
-        finalizer(c -> ccall((:clb_encoder_destroy, libcolbert), Cint, (Ptr{Cvoid},), c.handle), c)
-    end
-end
-
-"doc(bert, linear, integer_ids, bitmask) (src/modelling/checkpoint.jl:21-25)"
-function doc(ckpt::Checkpoint, integer_ids::Matrix{Int32}, bitmask::AbstractMatrix{Bool})
-    L, N = size(integer_ids)
-    mask = Matrix{UInt8}(bitmask)
-    out = Array{Float32, 3}(undef, ckpt.dim, L, N)
-    GC.@preserve integer_ids mask out _check(ccall((:clb_encode, libcolbert), Cint,
-        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Float32}), ckpt.handle, integer_ids, mask, L, N, out))
-    out
-end
-
-"_doc_embeddings_and_doclens (checkpoint.jl:27-52)"
-function _doc_embeddings_and_doclens(ckpt::Checkpoint, skiplist::Vector{Int}, integer_ids::Matrix{Int32},
-        bitmask::AbstractMatrix{Bool})
-    L, N = size(integer_ids)
-    mask = Matrix{UInt8}(bitmask)
-    out = Matrix{Float32}(undef, ckpt.dim, L * N)
-    doclens = Vector{Int}(undef, N)
-    n_out = Ref{Int64}(0)
-    GC.@preserve integer_ids mask skiplist out doclens _check(ccall((:clb_encode_docs, libcolbert), Cint,
-        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32}, Ptr{Int64}, Ref{Int64}),
-        ckpt.handle, integer_ids, mask, L, N, skiplist, length(skiplist), out, doclens, n_out))
-    out[:, 1:n_out[]], doclens
-end
-
-"_query_embeddings (checkpoint.jl:54-71)"
-function _query_embeddings(ckpt::Checkpoint, skiplist::Vector{Int}, integer_ids::Matrix{Int32},
-        bitmask::AbstractMatrix{Bool})
-    L, N = size(integer_ids)
-    mask = Matrix{UInt8}(bitmask)
-    out = Array{Float32, 3}(undef, ckpt.dim, L, N)
-    GC.@preserve integer_ids mask skiplist out _check(ccall((:clb_encode_queries, libcolbert), Cint,
-        (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32}),
-        ckpt.handle, integer_ids, mask, L, N, skiplist, length(skiplist), out))
-    out
-end
-
-# Indexer / index: the reference's orchestration (src/indexing.jl:63-147) is unchanged host glue; only the
-# calls above (train -> kmeans_gpu_onehot! + _compute_avg_residuals!, compress, _build_ivf) change body.
-struct Indexer
-    config::ColBERTConfig
-    collection::Vector{String}
-    encode_passages::Function     # (passages) -> (embs::Matrix{Float32}, doclens::Vector{Int})
-end
+include("config.jl")
+include("capi.jl")
+include("storage.jl")
+include("tokenizer.jl")
+include("checkpoint.jl")
+include("indexing.jl")
+include("searching.jl")
 
 end # module
