@@ -78,6 +78,52 @@ def kmeans(data, init_centroids, max_iters: int = 10, tol: float = 1e-4, point_b
     return c, assign, iters.value
 
 
+class KMeansShard:
+    """One rank's points of a sharded k-means (clb_kmeans_shard_*): uploaded once, one `pass_` per iteration."""
+
+    def __init__(self, data, K: int, point_bsize: int = 1000, device: int = 0):
+        x = colmajor(data, np.float32)
+        self.dim, self.n = x.shape
+        self.K, self.device = int(K), device
+        self._h = C.c_void_p()
+        check(lib().clb_kmeans_shard_create(device, fptr(x), i64(self.dim), i64(self.n), i64(K), i64(point_bsize),
+                                            C.byref(self._h)))
+
+    def pass_(self, centroids, want_assignments: bool = False):
+        """-> (sums (dim,K) fp32, counts int64[K][, assignments int32 1-based])"""
+        c = colmajor(centroids, np.float32)
+        sums = np.zeros((self.dim, self.K), dtype=np.float32, order="F"); counts = np.zeros(self.K, dtype=np.int64)
+        assign = np.zeros(self.n, dtype=np.int32) if want_assignments else None
+        check(lib().clb_kmeans_shard_pass(self._h, fptr(c), fptr(sums), fptr(counts),
+                                          fptr(assign) if want_assignments else None))
+        return (sums, counts, assign) if want_assignments else (sums, counts)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().clb_kmeans_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def kmeans_reduce_update(centroids, gathered_sums, gathered_counts, tol: float = 1e-4, device: int = 0):
+    """Rank-ordered reduction of the shards' partial sums + centroid update (clb_kmeans_reduce_update).
+    gathered_sums: (world, dim*K) (each block a (dim,K) column-major matrix), gathered_counts: (world, K).
+    Returns (centroids, delta, converged)."""
+    c = colmajor(centroids, np.float32).copy(order="F")
+    dim, K = c.shape
+    gs = np.ascontiguousarray(np.asarray(gathered_sums, dtype=np.float32).reshape(-1, dim * K))
+    gc = np.ascontiguousarray(np.asarray(gathered_counts, dtype=np.int64).reshape(gs.shape[0], K))
+    delta = C.c_float(0); conv = C.c_int(0)
+    check(lib().clb_kmeans_reduce_update(device, fptr(c), fptr(gs), fptr(gc), i64(gs.shape[0]), i64(dim), i64(K),
+                                         C.c_float(tol), C.byref(delta), C.byref(conv)))
+    return c, delta.value, bool(conv.value)
+
+
 def compute_avg_residuals(nbits: int, centroids, heldout, device: int = 0, n_codes=None):
     """_compute_avg_residuals!  (collection_indexer.jl:177-195) -> (cutoffs, weights, avg_residual, codes)"""
     c = colmajor(centroids, np.float32); h = colmajor(heldout, np.float32)

@@ -298,6 +298,118 @@ int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* cen
     return CLB_OK;
 }
 
+// ---- sharded k-means: the points of one shard stay on the device across iterations ----------------------------
+struct clb_kmeans_shard {
+    int device = 0;
+    int64_t dim = 0, n = 0, K = 0, point_bsize = 0;
+    int end_bit = 1;
+    Stream s;
+    DevBuf dX, dC, dNew, dC2, dAssign, dOrder, dIota, dKeys, dCounts, dStart, dErr, dCnt32, dCnt64;
+    NearestScratch nscratch;
+};
+
+int clb_kmeans_shard_create(int device, const float* data, int64_t dim, int64_t n, int64_t K, int64_t point_bsize,
+                            clb_kmeans_shard** out) {
+    if (!out) return fail(CLB_EARGUMENT, "out is null");
+    *out = nullptr;
+    if (K < 1 || dim < 1 || point_bsize < 1 || n < 0) return fail(CLB_EDIMENSION, "size(centroids, 2) must be k!");
+    if (n >= (int64_t)0xffffffffll) return fail(CLB_EUNSUPPORTED, "n too large");
+    CLB_TRY(use_device(device));
+    auto* h = new clb_kmeans_shard();
+    h->device = device; h->dim = dim; h->n = n; h->K = K; h->point_bsize = point_bsize;
+    auto bail = [&](int rc) { delete h; return rc; };
+    int rc;
+    if ((rc = h->s.init())) return bail(rc);
+    const int64_t n1 = std::max<int64_t>(n, 1);
+    if ((rc = upload(h->dX, data, sizeof(float) * dim * n1, h->s.st))) return bail(rc);
+    if ((rc = h->dC.alloc(sizeof(float) * dim * K)) || (rc = h->dNew.alloc(sizeof(float) * dim * K)) ||
+        (rc = h->dC2.alloc(sizeof(float) * K)) || (rc = h->dAssign.alloc(sizeof(uint32_t) * n1)) ||
+        (rc = h->dOrder.alloc(sizeof(uint32_t) * n1)) || (rc = h->dIota.alloc(sizeof(uint32_t) * n1)) ||
+        (rc = h->dKeys.alloc(sizeof(uint32_t) * n1)) || (rc = h->dCounts.alloc(sizeof(uint32_t) * (K + 1))) ||
+        (rc = h->dStart.alloc(sizeof(uint32_t) * (K + 2))) || (rc = h->dCnt32.alloc(sizeof(int) * K)) ||
+        (rc = h->dCnt64.alloc(sizeof(long long) * K)) || (rc = h->dErr.alloc(sizeof(int))))
+        return bail(rc);
+    if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, h->s.st, h->dIota.as<uint32_t>(), n);
+    while (((int64_t)1 << h->end_bit) <= K) ++h->end_bit;
+    if (hipStreamSynchronize(h->s.st) != hipSuccess) return bail(fail(CLB_EHIP, "shard upload failed"));
+    *out = h;
+    return CLB_OK;
+}
+
+int clb_kmeans_shard_destroy(clb_kmeans_shard* h) {
+    if (!h) return CLB_OK;
+    (void)hipSetDevice(h->device);
+    if (h->s.st) (void)hipStreamSynchronize(h->s.st);
+    delete h;
+    return CLB_OK;
+}
+
+int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids, float* sums, int64_t* counts,
+                          int32_t* assignments) {
+    if (!h || !centroids || !sums || !counts) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(h->device));
+    hipStream_t st = h->s.st;
+    const int64_t n = h->n, K = h->K, dim = h->dim;
+    CLB_HIP(hipMemcpyAsync(h->dC.p, centroids, sizeof(float) * dim * K, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(centroid_sumsq_kernel, dim3(blocks_for(K, 64)), dim3(64), 0, st, h->dC.as<float>(), (int)dim,
+                       (int)K, h->dC2.as<float>());
+    CLB_TRY(nearest_centroids<1>(st, h->dC.as<float>(), h->dC2.as<float>(), (int)dim, (int)K, h->dX.as<float>(), n,
+                                 h->dAssign.as<uint32_t>(), &h->nscratch));
+    CLB_HIP(hipMemsetAsync(h->dCounts.p, 0, sizeof(uint32_t) * (K + 1), st));
+    CLB_HIP(hipMemsetAsync(h->dErr.p, 0, sizeof(int), st));
+    if (n > 0) {
+        hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, st, h->dAssign.as<uint32_t>(), n,
+                           (uint32_t)K, h->dCounts.as<unsigned int>(), h->dErr.as<int>());
+        CLB_TRY(sort_pairs_u32(h->dAssign.as<uint32_t>(), h->dKeys.as<uint32_t>(), h->dIota.as<uint32_t>(),
+                               h->dOrder.as<uint32_t>(), (size_t)n, h->end_bit, st));
+    }
+    CLB_TRY(exclusive_scan_u32(h->dCounts.as<uint32_t>(), h->dStart.as<uint32_t>(), (size_t)K, st));
+    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, st, h->dX.as<float>(),
+                       (int)dim, h->dOrder.as<uint32_t>(), h->dStart.as<uint32_t>(), (int)K, (int)h->point_bsize,
+                       h->dNew.as<float>(), h->dCnt32.as<int>());
+    hipLaunchKernelGGL(widen_counts_kernel, dim3(blocks_for(K)), dim3(256), 0, st, h->dCnt32.as<int>(),
+                       h->dCnt64.as<long long>(), (int)K);
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(sums, h->dNew.p, sizeof(float) * dim * K, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(counts, h->dCnt64.p, sizeof(int64_t) * K, hipMemcpyDeviceToHost, st));
+    if (assignments && n > 0)
+        CLB_HIP(hipMemcpyAsync(assignments, h->dAssign.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+int clb_kmeans_reduce_update(int device, float* centroids, const float* gathered_sums, const int64_t* gathered_counts,
+                             int64_t world, int64_t dim, int64_t K, float tol, float* delta_out, int* converged) {
+    if (!centroids || !gathered_sums || !gathered_counts) return fail(CLB_EARGUMENT, "null argument");
+    if (world < 1 || K < 1 || dim < 1) return fail(CLB_EDIMENSION, "world, dim and K must be >= 1");
+    CLB_TRY(use_device(device));
+    Stream s; CLB_TRY(s.init());
+    DevBuf dS, dCt, dOld, dNew, dDelta;
+    CLB_TRY(upload(dS, gathered_sums, sizeof(float) * world * dim * K, s.st));
+    CLB_TRY(upload(dCt, gathered_counts, sizeof(int64_t) * world * K, s.st));
+    CLB_TRY(upload(dOld, centroids, sizeof(float) * dim * K, s.st));
+    CLB_TRY(dNew.alloc(sizeof(float) * dim * K));
+    CLB_TRY(dDelta.alloc(sizeof(unsigned int)));
+    CLB_HIP(hipMemsetAsync(dDelta.p, 0, sizeof(unsigned int), s.st));
+    hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, s.st, dS.as<float>(),
+                       dCt.as<long long>(), (int)world, dOld.as<float>(), (int)dim, (int)K, dNew.as<float>(),
+                       dDelta.as<unsigned int>());
+    CLB_HIP(hipGetLastError());
+    unsigned int bits = 0;
+    CLB_HIP(hipMemcpyAsync(&bits, dDelta.p, sizeof bits, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    float delta;
+    memcpy(&delta, &bits, sizeof delta);
+    if (delta_out) *delta_out = delta;
+    const int conv = delta < tol;      // utils.jl:308-311: the previous centroids stay
+    if (converged) *converged = conv;
+    if (!conv) {
+        CLB_HIP(hipMemcpyAsync(centroids, dNew.p, sizeof(float) * dim * K, hipMemcpyDeviceToHost, s.st));
+        CLB_HIP(hipStreamSynchronize(s.st));
+    }
+    return CLB_OK;
+}
+
 int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int64_t dim, int64_t K,
                               const float* heldout, int64_t n, uint32_t* codes, int64_t n_codes,
                               float* bucket_cutoffs, float* bucket_weights, float* avg_residual) {

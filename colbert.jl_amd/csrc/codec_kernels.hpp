@@ -317,6 +317,33 @@ static __global__ void kmeans_finalize_kernel(float* __restrict__ newc, const in
     if ((threadIdx.x & 63) == 0) atomicMax(delta_bits, __float_as_uint(diff));  // diff >= 0: bits order like floats
 }
 
+// Sharded k-means (one shard per GPU): total = ((p_0 + p_1) + p_2) + ... over the ranks' partial sums in RANK order
+// (deterministic whatever order the exchange delivered them in), counts added, then the centroid update of
+// utils.jl:302-306.  gathered_sums: [world][K*dim], gathered_counts: [world][K].
+static __global__ void kmeans_reduce_update_kernel(const float* __restrict__ gathered_sums,
+                                                   const long long* __restrict__ gathered_counts, int world,
+                                                   const float* __restrict__ oldc, int dim, int K,
+                                                   float* __restrict__ newc, unsigned int* __restrict__ delta_bits) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float diff = 0.f;
+    if (gid < (int64_t)K * dim) {
+        const int c = (int)(gid / dim);
+        long long cnt = 0;
+        for (int r = 0; r < world; ++r) cnt += gathered_counts[(size_t)r * K + c];
+        float total = gathered_sums[gid];
+        for (int r = 1; r < world; ++r) total = total + gathered_sums[(size_t)r * K * dim + gid];
+        const float v = total / (float)(cnt > 1 ? cnt : 1);
+        newc[gid] = v;
+        diff = fabsf(oldc[gid] - v);
+    }
+    for (int o = 32; o > 0; o >>= 1) diff = fmaxf(diff, __shfl_down(diff, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(delta_bits, __float_as_uint(diff));
+}
+static __global__ void widen_counts_kernel(const int* __restrict__ c32, long long* __restrict__ c64, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) c64[i] = c32[i];
+}
+
 static __global__ void iota_kernel(uint32_t* __restrict__ v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;

@@ -167,6 +167,23 @@ int clb_normalize_columns(int device, float* X, int64_t dim, int64_t n);
 int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* centroids, int64_t K,
                int64_t max_iters, float tol, int64_t point_bsize, int32_t* assignments,
                int64_t* iters_done);
+/* The same iteration split for a point set sharded over several GPUs (BASELINE config 5).  Each rank
+ * holds its points on its device (`clb_kmeans_shard`); per iteration it computes the un-normalised per-cluster sums
+ * (dim,K) and counts of ITS points with the current centroids (clb_kmeans_shard_pass: the batch loop of utils.jl:271-300
+ * over the shard, batches counted from the shard's first point), the ranks all-gather these blocks (RCCL), and
+ * clb_kmeans_reduce_update adds them in RANK ORDER -- total = ((p_0 + p_1) + p_2) + ..., deterministic and identical
+ * on every rank -- and applies utils.jl:302-314: new = total ./ max.(counts,1), delta = max|old - new|; `delta < tol`
+ * leaves `centroids` untouched and sets *converged.  With one shard the result equals clb_kmeans bit for bit. */
+typedef struct clb_kmeans_shard clb_kmeans_shard;
+int clb_kmeans_shard_create(int device, const float* data /* (dim, n) */, int64_t dim, int64_t n, int64_t K,
+                            int64_t point_bsize, clb_kmeans_shard** out);
+int clb_kmeans_shard_destroy(clb_kmeans_shard* h);
+int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids /* (dim,K) */, float* sums /* (dim,K) */,
+                          int64_t* counts /* K */, int32_t* assignments /* n, 1-based; may be NULL */);
+int clb_kmeans_reduce_update(int device, float* centroids /* (dim,K) in/out */,
+                             const float* gathered_sums /* [world][dim*K] */,
+                             const int64_t* gathered_counts /* [world][K] */, int64_t world, int64_t dim, int64_t K,
+                             float tol, float* delta_out, int* converged);
 /* _compute_avg_residuals!  (collection_indexer.jl:177-195) incl. _bucket_cutoffs_and_weights :141-152 */
 int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int64_t dim, int64_t K,
                               const float* heldout, int64_t n, uint32_t* codes, int64_t n_codes,

@@ -270,6 +270,89 @@ int orc_kmeans(const float* data, int64_t dim, int64_t n, float* centroids, int6
     return ORC_OK;
 }
 
+/* Sharded k-means (the reference has no multi-GPU build; this is the canonical order the
+ * multi-GPU index build is checked against).  One iteration of utils.jl:271-306 splits into
+ *   (1) per shard: the body of the batch loop over the shard's own points (batches counted from the shard's
+ *       first point) -> un-normalised per-cluster sums (dim,K) and counts;
+ *   (2) reduction in RANK ORDER: total = ((p_0 + p_1) + p_2) + ..., counts added;
+ *   (3) utils.jl:302-314: new = total ./ max.(counts,1); delta = max|old - new|; delta < tol keeps the old centroids.
+ * With one shard this is orc_kmeans' iteration bit for bit. */
+int orc_kmeans_shard_pass(const float* data, int64_t dim, int64_t n, const float* centroids, int64_t K,
+                          int64_t point_bsize, float* sums, int64_t* counts, int32_t* assignments) {
+    if (K <= 0 || dim <= 0 || point_bsize <= 0) return ORC_EDIMENSION;
+    float* part = (float*)malloc(sizeof(float) * (size_t)(dim * K));
+    float* c2 = (float*)malloc(sizeof(float) * (size_t)K);
+    int64_t* touched = (int64_t*)malloc(sizeof(int64_t) * (size_t)point_bsize);
+    int32_t* assign = assignments ? assignments : (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    memset(sums, 0, sizeof(float) * (size_t)(dim * K));
+    memset(counts, 0, sizeof(int64_t) * (size_t)K);
+    for (int64_t c = 0; c < K; ++c) c2[c] = orc_sumsq(centroids + c * dim, dim);
+    for (int64_t start = 0; start < n; start += point_bsize) {
+        int64_t end = start + point_bsize < n ? start + point_bsize : n;
+#pragma omp parallel for schedule(static) if ((end - start) * K > 4096)
+        for (int64_t i = start; i < end; ++i) {
+            const float* x = data + i * dim;
+            float x2 = orc_sumsq(x, dim);
+            int64_t best = 0;
+            float bestd = 0.0f;
+            for (int64_t c = 0; c < K; ++c) {
+                float d = -2.0f * orc_dot(centroids + c * dim, x, dim);
+                d = d + c2[c];
+                d = d + x2;
+                if (c == 0 || d < bestd) { bestd = d; best = c; }
+            }
+            assign[i] = (int32_t)(best + 1);
+        }
+        int64_t nt = 0;
+        for (int64_t i = start; i < end; ++i) {
+            int64_t c = assign[i] - 1;
+            int seen = 0;
+            for (int64_t j = 0; j < nt; ++j)
+                if (touched[j] == c) { seen = 1; break; }
+            if (!seen) {
+                touched[nt++] = c;
+                for (int64_t d = 0; d < dim; ++d) part[d + c * dim] = 0.0f;
+            }
+            for (int64_t d = 0; d < dim; ++d) part[d + c * dim] = part[d + c * dim] + data[d + i * dim];
+            counts[c] += 1;
+        }
+        for (int64_t j = 0; j < nt; ++j) {
+            int64_t c = touched[j];
+            for (int64_t d = 0; d < dim; ++d) sums[d + c * dim] = sums[d + c * dim] + part[d + c * dim];
+        }
+    }
+    free(part); free(c2); free(touched);
+    if (!assignments) free(assign);
+    return ORC_OK;
+}
+
+int orc_kmeans_reduce_update(float* centroids, const float* gathered_sums, const int64_t* gathered_counts,
+                             int64_t world, int64_t dim, int64_t K, float tol, float* delta_out,
+                             int* converged) {
+    if (world < 1 || K <= 0 || dim <= 0) return ORC_EDIMENSION;
+    float delta = 0.0f;
+    float* newc = (float*)malloc(sizeof(float) * (size_t)(dim * K));
+    for (int64_t c = 0; c < K; ++c) {
+        int64_t cnt = 0;
+        for (int64_t r = 0; r < world; ++r) cnt += gathered_counts[r * K + c];
+        float cs = (float)(cnt > 1 ? cnt : 1);
+        for (int64_t d = 0; d < dim; ++d) {
+            float total = gathered_sums[d + c * dim];
+            for (int64_t r = 1; r < world; ++r) total = total + gathered_sums[r * dim * K + d + c * dim];
+            float v = total / cs;
+            newc[d + c * dim] = v;
+            float diff = fabsf(centroids[d + c * dim] - v);
+            if (diff > delta) delta = diff;
+        }
+    }
+    if (delta_out) *delta_out = delta;
+    int conv = delta < tol;
+    if (converged) *converged = conv;
+    if (!conv) memcpy(centroids, newc, sizeof(float) * (size_t)(dim * K));
+    free(newc);
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* codec  src/indexing/codecs/residual.jl                                                       */
 /* ------------------------------------------------------------------------------------------- */

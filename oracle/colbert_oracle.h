@@ -71,6 +71,16 @@ int orc_kmeans(const float* data, int64_t dim, int64_t n, float* centroids, int6
                int64_t max_iters, float tol, int64_t point_bsize, int32_t* assignments,
                int64_t* iters_done);
 
+/* One k-means iteration (utils.jl:271-314) split for passage/point shards -- the canonical order of the multi-GPU
+ * build: shard pass = the batch loop over the shard's own points (un-normalised sums (dim,K), counts[K], 1-based
+ * assignments or NULL); reduce_update = sums added in rank order, ./ max(count,1), delta, `delta < tol` keeps the
+ * old centroids (*converged = 1). */
+int orc_kmeans_shard_pass(const float* data, int64_t dim, int64_t n, const float* centroids, int64_t K,
+                          int64_t point_bsize, float* sums, int64_t* counts, int32_t* assignments);
+int orc_kmeans_reduce_update(float* centroids, const float* gathered_sums, const int64_t* gathered_counts,
+                             int64_t world, int64_t dim, int64_t K, float tol, float* delta_out,
+                             int* converged);
+
 /* ---- src/indexing/codecs/residual.jl --------------------------------------------------------- */
 /* compress_into_codes!  residual.jl:67-81 ; argmax inner product, first index on ties, 1-based */
 int orc_compress_into_codes(uint32_t* codes, int64_t n_codes, const float* centroids, int64_t dim,

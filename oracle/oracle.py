@@ -158,6 +158,32 @@ def kmeans(data, init_centroids, max_iters: int = 10, tol: float = 1e-4, point_b
     return c, assign, iters.value
 
 
+def kmeans_shard_pass(data, centroids, point_bsize: int = 1000):
+    """One iteration's pass over one shard's points -> (sums (dim,K) fp32, counts int64[K], assignments int32 1-based)."""
+    x = _f(data, np.float32); c = _f(centroids, np.float32)
+    dim, n = x.shape
+    K = c.shape[1]
+    sums = np.zeros((dim, K), dtype=np.float32, order="F"); counts = np.zeros(K, dtype=np.int64)
+    assign = np.zeros(n, dtype=np.int32)
+    _chk(lib().orc_kmeans_shard_pass(_p(x), i64(dim), i64(n), _p(c), i64(K), i64(point_bsize), _p(sums), _p(counts),
+                                     _p(assign)))
+    return sums, counts, assign
+
+
+def kmeans_reduce_update(centroids, gathered_sums, gathered_counts, tol: float = 1e-4):
+    """Rank-ordered reduction of the shards' partial sums + the centroid update.  gathered_sums: (world, K*dim)
+    or (world, dim, K)-shaped, gathered_counts: (world, K).  Returns (centroids, delta, converged)."""
+    c = _f(centroids, np.float32).copy(order="F")
+    dim, K = c.shape
+    gs = np.ascontiguousarray(np.stack([np.asfortranarray(np.asarray(g, dtype=np.float32).reshape(dim, K, order="F")).ravel(order="F")
+                                        for g in gathered_sums]))
+    gc = np.ascontiguousarray(np.asarray(gathered_counts, dtype=np.int64).reshape(len(gs), K))
+    delta = C.c_float(0); conv = C.c_int(0)
+    _chk(lib().orc_kmeans_reduce_update(_p(c), _p(gs), _p(gc), i64(len(gs)), i64(dim), i64(K), C.c_float(tol),
+                                        C.byref(delta), C.byref(conv)))
+    return c, delta.value, bool(conv.value)
+
+
 # ---- src/indexing/codecs/residual.jl -----------------------------------------------------------------
 def compress_into_codes(centroids, embs, n_codes=None):
     c = _f(centroids, np.float32); x = _f(embs, np.float32)

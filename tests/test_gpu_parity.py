@@ -619,3 +619,38 @@ def test_index_then_search_end_to_end(oracle, tmp_path):
         assert np.array_equal(pids, rp) and pids[0] == p + 1       # the passage itself wins
         assert_same_f32(scores, rs, "end-to-end scores")
     s.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-GPU index build: the shard-level entry points vs the oracle's sharded restatement (one GPU, two shards)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,n0,n1,K,bsize", [(128, 2600, 1900, 48, 1000), (128, 700, 1, 64, 100), (16, 300, 450, 9, 1000)])
+def test_sharded_kmeans_matches_oracle(oracle, dim, n0, n1, K, bsize):
+    rng = np.random.default_rng(dim + n0)
+    X = np.asfortranarray(rng.standard_normal((dim, n0 + n1)).astype(np.float32))
+    X /= np.linalg.norm(X, axis=0, keepdims=True)
+    shards = [np.asfortranarray(X[:, :n0]), np.asfortranarray(X[:, n0:])]
+    c = np.asfortranarray(X[:, rng.choice(n0 + n1, K, replace=False)])
+    hs = [codec.KMeansShard(x, K, bsize) for x in shards]
+    cr = c.copy(order="F")
+    for _ in range(4):
+        parts = [h.pass_(c, want_assignments=True) for h in hs]
+        refs = [oracle.kmeans_shard_pass(x, cr, bsize) for x in shards]
+        for (s, n, a), (rs, rn, ra) in zip(parts, refs):
+            assert np.array_equal(a, ra) and np.array_equal(n, rn)
+            assert_same_f32(s, rs, "shard sums")
+        gs = np.stack([p[0].ravel(order="F") for p in parts]); gc = np.stack([p[1] for p in parts])
+        c, d, conv = codec.kmeans_reduce_update(c, gs, gc)
+        cr, rd, rconv = oracle.kmeans_reduce_update(cr, [p[0] for p in refs], [p[1] for p in refs])
+        assert conv == rconv and bits(np.float32(d)) == bits(np.float32(rd))
+        assert_same_f32(c, cr, "sharded centroids")
+    # one shard == clb_kmeans
+    one = codec.KMeansShard(X, K, bsize)
+    c1 = np.asfortranarray(X[:, :K].copy())
+    for _ in range(2):
+        s, n = one.pass_(c1)
+        c1, _, _ = codec.kmeans_reduce_update(c1, s.ravel(order="F")[None, :], n[None, :])
+    ref, _, _ = codec.kmeans(X, np.asfortranarray(X[:, :K].copy()), max_iters=2, point_bsize=bsize)
+    assert_same_f32(c1, ref, "one shard vs clb_kmeans")
+    for h in hs + [one]:
+        h.close()
