@@ -5,7 +5,9 @@
 #include <numeric>
 
 #include "approx_kernels.hpp"
+#include "generic_kernels.hpp"
 #include "search_kernels.hpp"
+#include "sort.hpp"
 
 using namespace clb;
 
@@ -62,6 +64,7 @@ struct Workspace {
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
         outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob;
+    DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch;   // general-shape path (generic_kernels.hpp)
 };
 
 struct clb_searcher {
@@ -70,6 +73,8 @@ struct clb_searcher {
     int nbits = 0;
     int mode = 0;
     bool approx_ok = false;
+    bool generic = false;      // dim != 128 or nbits == 8: every query takes the general-shape path
+    int64_t max_doclen = 0;
     hipStream_t stream = nullptr;
     // resident index (HBM)
     DevBuf centroids;   // fp32 [K][128]
@@ -146,12 +151,13 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     w.W = (int)((s->n_docs + 31) / 32);
     w.nblk_bitmap = (w.W + kScanBlock * kWordsPerThread - 1) / (kScanBlock * kWordsPerThread);
     w.topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
-    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
-    CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * kDim));
+    const int64_t NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
+    const bool general = s->generic || T > 128;
+    CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * s->dim));
     // the fp32 T x K score matrix is only materialised by the unfused S1/S2 path (nprobe > 2 or T > 32)
-    if (!(nprobe <= 2 && T <= 32)) CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
-    CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * NPs));
-    CLB_TRY(w.sel.ensure(sizeof(int) * B * Tpad * NPs));
+    if (!general && !(nprobe <= 2 && T <= 32)) CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
+    if (!general) CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * std::min<int64_t>(NPs, 32)));
+    CLB_TRY(w.sel.ensure(sizeof(int) * B * std::max<int64_t>(Tpad, T) * NPs));
     const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * w.W;
     const bool bm_new = bm_bytes > w.bitmap.bytes || !w.bitmap.p;
     CLB_TRY(w.bitmap.ensure(bm_bytes));
@@ -196,10 +202,13 @@ void launch_score_exact(clb_searcher* s, Workspace& w, hipStream_t st, const flo
                        nlist);
 }
 
+int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* cells, size_t stride_t, size_t stride_c,
+                   int T, int nprobe, int NP, int* sel_b);
+
 // Candidate generation S1-S3 for B queries on stream st; leaves cand/ncand on the device.
 int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
     const int TT = token_tiles(T), Tpad = TT * 32;
-    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : 32;
+    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
     const int n_tiles = (int)((s->K + 31) / 32);
     const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
     if (nprobe <= 2 && T <= 32) {
@@ -275,7 +284,11 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             Timed t(s, KID_TOPN, st);
             if (NPs == 2) launch_topn<2>(s, w, st, B, Tpad);
             else if (NPs == 8) launch_topn<8>(s, w, st, B, Tpad);
-            else launch_topn<32>(s, w, st, B, Tpad);
+            else if (NPs == 32) launch_topn<32>(s, w, st, B, Tpad);
+            else   // nprobe > 32: stable sort of every token's K scores (one query at a time)
+                for (int b = 0; b < B; ++b)
+                    CLB_TRY(select_by_sort(s, w, st, w.cells.as<float>() + (size_t)b * s->K * Tpad, 1, (size_t)Tpad, T,
+                                           nprobe, NPs, w.sel.as<int>() + (size_t)b * Tpad * NPs));
         }
         s->prof.chain = nullptr;   // untimed conversion below
         if (want_half)
@@ -304,12 +317,112 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
 
 int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int64_t k) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
-    if (T < 1 || T > 128) return fail(CLB_EUNSUPPORTED, "query length T=%lld outside 1..128", (long long)T);
+    if (T < 1) return fail(CLB_EARGUMENT, "query length must be >= 1");
     if (B < 1) return fail(CLB_EARGUMENT, "batch size must be >= 1");
     if (nprobe < 1 || nprobe > s->K) return fail(CLB_EBOUNDS, "nprobe=%lld outside 1..K=%lld (partialsortperm)", (long long)nprobe, (long long)s->K);
-    if (nprobe > 32) return fail(CLB_EUNSUPPORTED, "nprobe > 32 not supported by the HIP path");
     if (k < 1) return fail(CLB_EBOUNDS, "k must be >= 1");
-    if (k > kMaxTopK) return fail(CLB_EUNSUPPORTED, "k=%lld > %d not supported by the HIP path", (long long)k, kMaxTopK);
+    if (T * nprobe > (int64_t)0x7fffffff / 4 || T * s->K > (int64_t)0x7fffffff) return fail(CLB_EUNSUPPORTED, "T * K too large");
+    return CLB_OK;
+}
+
+// ---- general-shape pieces (generic_kernels.hpp) --------------------------------------------------------------
+// top-nprobe of every token of ONE query by a stable sort of the T x K scores; sel_b: [T][NP] (0-based centroid ids)
+int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* cells, size_t stride_t, size_t stride_c,
+                   int T, int nprobe, int NP, int* sel_b) {
+    const size_t n = (size_t)T * s->K;
+    CLB_TRY(w.g_keys.ensure(sizeof(uint64_t) * n));
+    CLB_TRY(w.g_keys2.ensure(sizeof(uint64_t) * n));
+    CLB_TRY(w.g_vals.ensure(sizeof(uint32_t) * n));
+    CLB_TRY(w.g_vals2.ensure(sizeof(uint32_t) * n));
+    hipLaunchKernelGGL(generic_sel_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cells, stride_t,
+                       stride_c, (int)s->K, T, w.g_keys.as<unsigned long long>(), w.g_vals.as<uint32_t>());
+    CLB_TRY(sort_pairs_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), w.g_vals.as<uint32_t>(),
+                           w.g_vals2.as<uint32_t>(), n, st));
+    hipLaunchKernelGGL(generic_sel_extract_kernel, dim3((unsigned)((T * nprobe + 255) / 256)), dim3(256), 0, st,
+                       w.g_vals2.as<uint32_t>(), (int)s->K, T, nprobe, NP, sel_b);
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+// top-k of ONE query by a full stable sort (k above the single-work-group sort of topk_kernel); synchronises
+int topk_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, int b, const int* list, const int* nlist, int k,
+                 int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand) {
+    int n = 0, nc = 0;
+    CLB_HIP(hipMemcpyAsync(&nc, w.ncand.as<int>() + b, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (list) CLB_HIP(hipMemcpyAsync(&n, nlist + b, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (!list) n = nc;
+    const float* sc = w.scores.as<float>() + (size_t)b * w.cand_cap;
+    const int* lst = list ? list + (size_t)b * w.cand_cap : nullptr;
+    CLB_TRY(w.g_keys.ensure(sizeof(uint64_t) * std::max(n, 1)));
+    CLB_TRY(w.g_keys2.ensure(sizeof(uint64_t) * std::max(n, 1)));
+    if (n > 0) {
+        hipLaunchKernelGGL(generic_topk_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sc, lst, n,
+                           w.g_keys.as<unsigned long long>());
+        CLB_TRY(sort_keys_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), (size_t)n, st));
+    }
+    hipLaunchKernelGGL(generic_topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, st,
+                       w.g_keys2.as<unsigned long long>(), sc, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, lst, n, k,
+                       s->pid_offset, d_out_pids + (size_t)b * k, d_out_scores + (size_t)b * k);
+    const int flag = n < k ? 1 : 0;
+    CLB_HIP(hipMemcpyAsync(w.flags.as<int>() + b, &flag, sizeof(int), hipMemcpyHostToDevice, st));
+    if (d_n_cand) {
+        const int64_t nc64 = nc;
+        CLB_HIP(hipMemcpyAsync(d_n_cand + b, &nc64, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    CLB_HIP(hipStreamSynchronize(st));        // the two host words above must stay alive until copied
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+// S1-S3 of ONE query on the general-shape path: leaves cand / cand_hdr / ncand of slot b
+int run_retrieve_general(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int b, int T, int nprobe) {
+    const float* q = dQ + (size_t)b * T * s->dim;
+    CLB_TRY(w.g_cells.ensure(sizeof(float) * (size_t)T * s->K));
+    hipLaunchKernelGGL(generic_cells_kernel, dim3((unsigned)((s->K + 127) / 128), T), dim3(128), sizeof(float) * s->dim, st,
+                       s->centroids.as<float>(), q, (int)s->dim, (int)s->K, w.g_cells.as<float>());
+    int* sel_b = w.sel.as<int>();                 // one query at a time: slot 0 of the selection buffer
+    CLB_TRY(select_by_sort(s, w, st, w.g_cells.as<float>(), (size_t)s->K, 1, T, nprobe, nprobe, sel_b));
+    uint32_t* bm = w.bitmap.as<uint32_t>() + (size_t)b * w.W;
+    int* bs = w.blocksum.as<int>() + (size_t)b * w.nblk_bitmap;
+    hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, 1), dim3(256), 0, st, sel_b, s->ivf_off.as<uint32_t>(),
+                       s->ivf_pid.as<uint32_t>(), bm, T, T, nprobe, nprobe, w.W);
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, 1), dim3(kScanBlock), 0, st, bm, bs, w.W);
+    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(kScanBlock), 0, st, bs, w.ncand.as<int>() + b, w.nblk_bitmap);
+    hipLaunchKernelGGL(bitmap_emit_kernel, dim3(w.nblk_bitmap, 1), dim3(kScanBlock), 0, st, bm, bs,
+                       w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, s->doc_off.as<uint32_t>(),
+                       w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap, w.W, w.cand_cap);
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+// the whole search of B queries on the general-shape path (exact scoring only), one query after the other
+int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
+                       int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand) {
+    s->prof.chain = nullptr;
+    const int grid = 1024;
+    const size_t max_len = (size_t)std::max<int64_t>(s->max_doclen, 1);
+    CLB_TRY(w.g_scratch.ensure(sizeof(float) * grid * max_len * s->dim));
+    for (int b = 0; b < B; ++b) {
+        CLB_TRY(run_retrieve_general(s, w, st, dQ, b, T, nprobe));
+        hipLaunchKernelGGL(generic_score_kernel, dim3(grid), dim3(256), sizeof(float) * T, st, s->centroids.as<float>(),
+                           s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
+                           w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap, w.ncand.as<int>() + b,
+                           dQ + (size_t)b * T * s->dim, (int)s->dim, s->nbits, T, w.g_scratch.as<float>(), max_len,
+                           w.scores.as<float>() + (size_t)b * w.cand_cap);
+        CLB_HIP(hipGetLastError());
+        if (k <= kMaxTopK) {
+            const int kpow2 = next_pow2(k);
+            hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), sizeof(unsigned long long) * kpow2, st,
+                               w.scores.as<float>() + (size_t)b * w.cand_cap, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap,
+                               w.ncand.as<int>() + b, (const int*)nullptr, (const int*)nullptr, k, kpow2, w.cand_cap,
+                               s->pid_offset, d_out_pids + (size_t)b * k, d_out_scores + (size_t)b * k,
+                               w.flags.as<int>() + b, d_n_cand ? d_n_cand + b : nullptr);
+            CLB_HIP(hipGetLastError());
+        } else {
+            CLB_TRY(topk_by_sort(s, w, st, b, nullptr, nullptr, k, d_out_pids, d_out_scores, d_n_cand));
+        }
+    }
     return CLB_OK;
 }
 
@@ -321,7 +434,11 @@ int check_search_args(clb_searcher* s, int64_t T, int64_t B, int64_t nprobe, int
 int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
                int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr, int phase = 0,
                float* d_local_top = nullptr, const float* d_all_top = nullptr, int n_shards = 0) {
-    const int kpow2 = next_pow2(k);
+    if (s->generic || T > 128) {
+        if (phase != 0) return fail(CLB_EUNSUPPORTED, "the two-phase sharded search needs the two-pass mode");
+        return run_search_general(s, w, st, dQ, B, T, nprobe, k, d_out_pids, d_out_scores, d_n_cand);
+    }
+    const int kpow2 = next_pow2(std::min(k, (int)kMaxTopK));
     const int* list = nullptr;
     const int* nlist = nullptr;
     s->prof.chain = nullptr;           // the first timed kernel of a call records its own start
@@ -425,11 +542,14 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
             default: return fail(CLB_EUNSUPPORTED, "nbits=%d not supported by the HIP search path", s->nbits);
         }
     }
-    {
+    if (k <= kMaxTopK) {
         Timed t(s, KID_TOPK, st);
         hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
                            w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
                            kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
+    } else {      // k above the single-work-group sort: a full stable sort per query (synchronises)
+        s->prof.chain = nullptr;
+        for (int b = 0; b < B; ++b) CLB_TRY(topk_by_sort(s, w, st, b, list, nlist, k, d_out_pids, d_out_scores, d_n_cand));
     }
     if (s->prof.counters) {
         hipLaunchKernelGGL(batch_stats_kernel, dim3(32, B), dim3(256), 0, st, w.cand.as<uint32_t>(),
@@ -459,9 +579,9 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
                         const int64_t* ivf_lengths, int64_t pid_offset, clb_searcher** out) {
     if (!out) return fail(CLB_EARGUMENT, "out is null");
     *out = nullptr;
-    if (dim != kDim) return fail(CLB_EUNSUPPORTED, "the HIP search path is built for dim=128 (got %lld)", (long long)dim);
-    if (nbits != 1 && nbits != 2 && nbits != 4)
-        return fail(CLB_EUNSUPPORTED, "the HIP search path supports nbits in {1,2,4} (got %d)", nbits);
+    if (dim < 8 || dim % 8 != 0) return fail(CLB_EDOMAIN, "dim should be a multiple of 8!");          // residual.jl:763-768
+    if (nbits != 1 && nbits != 2 && nbits != 4 && nbits != 8)
+        return fail(CLB_EUNSUPPORTED, "the HIP codec supports nbits in {1,2,4,8} (got %d)", nbits);
     if (K < 1 || n_docs < 0 || n_emb < 0) return fail(CLB_EARGUMENT, "negative or empty sizes");
     if (n_emb >= (int64_t)0xffffffffll || n_docs >= (int64_t)0x7fffffffll)
         return fail(CLB_EUNSUPPORTED, "a shard holds at most 2^32-1 embeddings / 2^31-1 passages");
@@ -489,6 +609,8 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     clb_searcher* s = new clb_searcher();
     s->device = device; s->dim = dim; s->nbits = nbits; s->K = K; s->n_docs = n_docs; s->n_emb = n_emb;
     s->pid_offset = pid_offset;
+    s->generic = !(dim == kDim && nbits <= 4);     // the tuned kernels are built for dim 128, nbits 1/2/4
+    for (int64_t p = 0; p < n_docs; ++p) s->max_doclen = std::max(s->max_doclen, doclens[p]);
     auto bail = [&](int rc) { clb_searcher_destroy(s); return rc; };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(CLB_EHIP, "hipStreamCreate failed"));
@@ -530,6 +652,13 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     if (herr & 1) return bail(fail(CLB_EBOUNDS, "ivf holds embedding ids outside 1..n_emb"));
     if (herr & 2) return bail(fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!"));
 
+    if (s->generic) {
+        s->mode = 0;
+        s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
+                                   s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes);
+        *out = s;
+        return CLB_OK;
+    }
     {   // bf16 hi/lo split of the centroids for the bf16x3 centroid scoring
         if ((rc = s->cent_hi.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
         if ((rc = s->cent_lo.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
@@ -654,7 +783,7 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
     w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * B * T * kDim, hipMemcpyHostToDevice, st));
+    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * B * T * s->dim, hipMemcpyHostToDevice, st));
     CLB_TRY(run_search(s, w, st, w.Qdev.as<float>(), (int)B, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(),
                        w.outs.as<float>()));
     std::vector<int> nc((size_t)B), fl((size_t)B);
@@ -689,8 +818,9 @@ int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int
     w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, 1));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
-    CLB_TRY(run_retrieve(s, w, st, w.Qdev.as<float>(), 1, (int)T, (int)nprobe));
+    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * s->dim, hipMemcpyHostToDevice, st));
+    if (s->generic || T > 128) CLB_TRY(run_retrieve_general(s, w, st, w.Qdev.as<float>(), 0, (int)T, (int)nprobe));
+    else CLB_TRY(run_retrieve(s, w, st, w.Qdev.as<float>(), 1, (int)T, (int)nprobe));
     int nc = 0;
     CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));

@@ -32,6 +32,29 @@ int sort_keys_f32(const float* keys_in, float* keys_out, size_t n, hipStream_t s
     return CLB_OK;
 }
 
+int sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                   hipStream_t st) {
+    if (n == 0) return CLB_OK;
+    size_t tmp_bytes = 0;
+    CLB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
+    DevBuf tmp;
+    CLB_TRY(tmp.alloc(tmp_bytes));
+    CLB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+int sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, size_t n, hipStream_t st) {
+    if (n == 0) return CLB_OK;
+    size_t tmp_bytes = 0;
+    CLB_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, keys_out, n, 0, 64, st));
+    DevBuf tmp;
+    CLB_TRY(tmp.alloc(tmp_bytes));
+    CLB_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, keys_in, keys_out, n, 0, 64, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
     // scan n+1 inputs (the caller pads in[n] = 0) so that out[n] = total
     size_t tmp_bytes = 0;

@@ -14,6 +14,11 @@ int sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* 
                    size_t n, int end_bit, hipStream_t st);
 // ascending sort of float keys (quantiles of the pooled residuals, collection_indexer.jl:147-150)
 int sort_keys_f32(const float* keys_in, float* keys_out, size_t n, hipStream_t st);
+// stable ascending sorts on 64-bit keys (general-shape search path: top-nprobe per token for nprobe > 32, top-k for
+// k above the single-work-group sort)
+int sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                   hipStream_t st);
+int sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, size_t n, hipStream_t st);
 // exclusive prefix sum of n uint32 counts (out has n+1 entries, out[n] = total)
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 }  // namespace clb

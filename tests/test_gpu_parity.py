@@ -654,3 +654,35 @@ def test_sharded_kmeans_matches_oracle(oracle, dim, n0, n1, K, bsize):
     assert_same_f32(c1, ref, "one shard vs clb_kmeans")
     for h in hs + [one]:
         h.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# general shapes: everything the reference accepts (residual.jl:698-721, searching.jl:93-128, utils.jl:327-332)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,nbits", [(64, 2), (128, 8), (24, 8), (256, 4), (8, 1)])
+def test_search_general_dim_and_nbits(oracle, dim, nbits):
+    """dim != 128 and nbits = 8 take the general-shape path (generic_kernels.hpp): same pids, bit-identical scores."""
+    idx = synthetic.make_index(seed=41 + dim + nbits, n_docs=900, K=96, dim=dim, nbits=nbits, doclen_mean=30, doclen_std=12)
+    Qs = synthetic.make_queries(idx, 42, 3, T=20)
+    check_search(oracle, idx, Qs, k=40, modes=(0,))
+    check_search(oracle, idx, Qs, k=7, nprobe=5, modes=(0,))
+
+
+def test_search_long_queries_large_nprobe_large_k(oracle):
+    """On the tuned shape (dim 128, nbits 2): T > 128 goes to the general path; nprobe > 32 selects by a stable sort;
+    k > 4096 ranks by a full stable sort -- in both modes -- and nprobe = K makes every passage a candidate."""
+    idx = synthetic.make_index(seed=43, n_docs=6000, K=256, doclen_mean=24, doclen_std=6)
+    check_search(oracle, idx, synthetic.make_queries(idx, 44, 2, T=150), k=30, modes=(0,))
+    Qs = synthetic.make_queries(idx, 45, 3)
+    check_search(oracle, idx, Qs, k=50, nprobe=40)
+    check_search(oracle, idx, Qs, k=5000, nprobe=64)
+    s = clb.Searcher(index=idx)
+    try:
+        pids, scores = s.search_embeddings(Qs[:, :, 0], 6000, nprobe=256)           # every passage, fully ranked
+        rp, rs, rn = oracle.search(idx, Qs[:, :, 0], nprobe=256, k=6000)
+        assert rn == 6000 and np.array_equal(pids, rp)
+        assert_same_f32(scores, rs, "nprobe = K, k = n_docs")
+        with pytest.raises(clb.BoundsError):
+            s.search_embeddings(Qs[:, :, 0], 6001, nprobe=256)
+    finally:
+        s.close()
