@@ -20,7 +20,7 @@ struct clb_encoder {
     // per-layer relative offsets
     int64_t r_wqkv = 0, r_bqkv = 0, r_wo = 0, r_bo = 0, r_g1 = 0, r_b1n = 0, r_w1 = 0, r_b1 = 0, r_w2 = 0, r_b2 = 0, r_g2 = 0, r_b2n = 0;
     // workspace
-    DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err;
+    DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part;
 };
 
 namespace {
@@ -33,17 +33,51 @@ int64_t expected_weights(const clb_encoder* e) {
     return e->vocab * H + e->max_pos * H + e->type_vocab * H + 2 * H + e->layers * per_layer + e->dim * H + e->dim;
 }
 
+// `part`: scratch of at least 8 * M * N floats for the split-K path (may be null: no split)
 void gemm(hipStream_t st, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N, int K,
           int64_t lda, int64_t ldb_n, int64_t ldb_k, int64_t ldc, int epi, float scale = 1.0f, int zo = 1, int zi = 1,
-          int64_t a_so = 0, int64_t a_si = 0, int64_t b_so = 0, int64_t b_si = 0, int64_t c_so = 0, int64_t c_si = 0) {
-    GemmArgs g{A, B, C, bias, R, M, N, K, lda, ldb_n, ldb_k, ldc, zi, a_so, a_si, b_so, b_si, c_so, c_si, scale, epi};
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, zo * zi), dim3(256), 0, st, g);
+          int64_t a_so = 0, int64_t a_si = 0, int64_t b_so = 0, int64_t b_si = 0, int64_t c_so = 0, int64_t c_si = 0,
+          float* part = nullptr) {
+    GemmArgs g{A, B, C, bias, R, M, N, K, lda, ldb_n, ldb_k, ldc, zi, a_so, a_si, b_so, b_si, c_so, c_si, scale, epi, 1};
+    // the tiled kernel needs both operands contiguous in k with 16-byte aligned rows and whole 32-deep steps
+    const bool tiled = ldb_k == 1 && K % 32 == 0 && lda % 4 == 0 && ldb_n % 4 == 0 && a_so % 4 == 0 && a_si % 4 == 0 &&
+                       b_so % 4 == 0 && b_si % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && M >= 1 && N >= 1;
+    if (!tiled) {
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, zo * zi), dim3(256), 0, st, g);
+        return;
+    }
+    // the largest work-group tile that still gives the 256 CUs a few work-groups each; short activations (a batch of
+    // queries: M ~ 1000) get 64 x 64 tiles and, for the narrow outputs (N = hidden), a deterministic split over K
+    auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm) * zo * zi; };
+    if (wgs(128, 128) >= 384) {
+        hipLaunchKernelGGL((gemm_f32_tiled_kernel<2, 2>), dim3((N + 127) / 128, (M + 127) / 128, zo * zi), dim3(256),
+                           2 * 256 * kG2Ld * sizeof(float), st, g);
+    } else if (wgs(64, 128) >= 384 && N >= 128) {
+        hipLaunchKernelGGL((gemm_f32_tiled_kernel<1, 2>), dim3((N + 127) / 128, (M + 63) / 64, zo * zi), dim3(256),
+                           2 * 192 * kG2Ld * sizeof(float), st, g);
+    } else {
+        int ks = 1;
+        if (part && zo * zi == 1 && ldc == N) {
+            while (ks < 8 && wgs(64, 64) * ks < 512 && K % (ks * 2 * 32) == 0 && K / (ks * 2) >= 256) ks *= 2;
+        }
+        if (ks > 1) {
+            g.ksplit = ks; g.C = part;
+            hipLaunchKernelGGL((gemm_f32_tiled_kernel<1, 1>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256),
+                               2 * 128 * kG2Ld * sizeof(float), st, g);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, ks,
+                               (int64_t)M, N, C, bias, R, scale, epi);
+        } else {
+            hipLaunchKernelGGL((gemm_f32_tiled_kernel<1, 1>), dim3((N + 63) / 64, (M + 63) / 64, zo * zi), dim3(256),
+                               2 * 128 * kG2Ld * sizeof(float), st, g);
+        }
+    }
 }
 
-// forward for N sequences of length L already uploaded to e->ids / e->mask; result in e->out ((N*L) x dim)
-int forward(clb_encoder* e, int64_t L, int64_t N) {
+// forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
+// sync = false: everything is only enqueued on `st` (an out-of-vocabulary id is then clamped silently).
+int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t* d_ids, const uint8_t* d_mask,
+            bool sync = true) {
     const int64_t T = L * N, H = e->H, I = e->I, heads = e->heads, dh = H / heads;
-    hipStream_t st = e->stream;
     const float* W = e->weights.as<float>();
     CLB_TRY(e->x.ensure(sizeof(float) * T * H));
     CLB_TRY(e->qkv.ensure(sizeof(float) * T * 3 * H));
@@ -52,9 +86,12 @@ int forward(clb_encoder* e, int64_t L, int64_t N) {
     CLB_TRY(e->hbuf.ensure(sizeof(float) * T * I));
     CLB_TRY(e->tmp.ensure(sizeof(float) * T * H));
     CLB_TRY(e->out.ensure(sizeof(float) * T * e->dim));
+    const bool short_batch = T <= 4096;         // split-K scratch only where it can be used (query batches)
+    if (short_batch) CLB_TRY(e->part.ensure(sizeof(float) * 8 * T * H));
+    float* part = short_batch ? e->part.as<float>() : nullptr;
     CLB_TRY(e->err.ensure(sizeof(int)));
     CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, e->ids.as<int32_t>(), T, (int)L,
+    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, d_ids, T, (int)L,
                        (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
                        e->x.as<float>(), e->err.as<int>());
     float* x = e->x.as<float>();
@@ -72,21 +109,24 @@ int forward(clb_encoder* e, int64_t L, int64_t N) {
         gemm(st, qkv, qkv + H, sc, nullptr, nullptr, (int)L, (int)L, (int)dh, 3 * H, 3 * H, 1, L, 0, inv_sqrt, (int)N, (int)heads,
              L * 3 * H, dh, L * 3 * H, dh, heads * L * L, L * L);
         hipLaunchKernelGGL(masked_softmax_kernel, dim3(blocks_for(N * heads * L, 4)), dim3(256), 0, st, sc, N * heads * L, (int)L,
-                           (int)heads, e->mask.as<uint8_t>());
+                           (int)heads, d_mask);
         // context[n, head] = P V   (B(k = key, n = dim) = V[key][dim]: ldb_k = 3H, ldb_n = 1)
         gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
              heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
         // attention output + residual, LayerNorm
-        gemm(st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, H, H, 1, H, EPI_BIAS | EPI_RESID);
+        gemm(st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, H, H, 1, H, EPI_BIAS | EPI_RESID, 1.0f, 1, 1,
+             0, 0, 0, 0, 0, 0, part);
         hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, tmp, T, (int)H, P + e->r_g1, P + e->r_b1n, e->eps);
         // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
         gemm(st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, H, H, 1, I, EPI_BIAS | EPI_GELU);
-        gemm(st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, I, I, 1, H, EPI_BIAS | EPI_RESID);
+        gemm(st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, I, I, 1, H, EPI_BIAS | EPI_RESID, 1.0f, 1, 1,
+             0, 0, 0, 0, 0, 0, part);
         hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, x, T, (int)H, P + e->r_g2, P + e->r_b2n, e->eps);
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
     gemm(st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, H, H, 1, e->dim, EPI_BIAS);
     CLB_HIP(hipGetLastError());
+    if (!sync) return CLB_OK;
     int herr = 0;
     CLB_HIP(hipMemcpyAsync(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
@@ -172,7 +212,7 @@ int clb_encoder_destroy(clb_encoder* e) {
 
 int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out) {
     CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
-    CLB_TRY(forward(e, L, N));
+    CLB_TRY(forward(e, L, N, e->stream, e->ids.as<int32_t>(), e->mask.as<uint8_t>()));
     CLB_HIP(hipMemcpy(out, e->out.p, sizeof(float) * L * N * e->dim, hipMemcpyDeviceToHost));
     return CLB_OK;
 }
@@ -180,7 +220,7 @@ int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmas
 int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
                     const int64_t* skiplist, int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out) {
     CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
-    CLB_TRY(forward(e, L, N));
+    CLB_TRY(forward(e, L, N, e->stream, e->ids.as<int32_t>(), e->mask.as<uint8_t>()));
     hipStream_t st = e->stream;
     DevBuf dSkip, dMask, dLens, dStart, dOut;
     CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), st));
@@ -208,7 +248,7 @@ int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* b
 int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
                        const int64_t* skiplist, int64_t n_skip, float* out) {
     CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
-    CLB_TRY(forward(e, L, N));
+    CLB_TRY(forward(e, L, N, e->stream, e->ids.as<int32_t>(), e->mask.as<uint8_t>()));
     hipStream_t st = e->stream;
     DevBuf dSkip, dMask, dLens, dOut;
     CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), st));
@@ -222,6 +262,24 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
     CLB_HIP(hipGetLastError());
     CLB_HIP(hipMemcpyAsync(out, dOut.p, sizeof(float) * e->dim * L * N, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
+                              const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream) {
+    if (!e || !d_integer_ids || !d_bitmask || !d_out) return fail(CLB_EARGUMENT, "null argument");
+    if (L < 1 || N < 1) return fail(CLB_EARGUMENT, "empty batch");
+    if (L > e->max_pos) return fail(CLB_EBOUNDS, "sequence length %lld exceeds max_position_embeddings %lld", (long long)L, (long long)e->max_pos);
+    CLB_TRY(use_device(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    CLB_TRY(e->qmask.ensure((size_t)L * N));
+    CLB_TRY(e->qlens.ensure(sizeof(int64_t) * N));
+    CLB_TRY(forward(e, L, N, st, d_integer_ids, d_bitmask, /*sync=*/false));
+    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
+                       d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
+    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                       (int)L, (int)N, e->qmask.as<uint8_t>(), (const int64_t*)nullptr, d_out);
+    CLB_HIP(hipGetLastError());
     return CLB_OK;
 }
 

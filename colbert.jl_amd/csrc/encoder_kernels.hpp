@@ -30,6 +30,7 @@ struct GemmArgs {
     int64_t a_so, a_si, b_so, b_si, c_so, c_si;
     float scale;
     int epi;
+    int ksplit;        // > 1 (tiled kernel, unbatched only): blockIdx.z = K slice; raw partial sums go to C + z*M*N
 };
 
 constexpr int kGemmKT = 32;           // K per staged step
@@ -85,6 +86,143 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             C[(int64_t)m * g.ldc + n] = v;
         }
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// The same GEMM for the shapes that carry the encoder's flops (activations x torch Linear weights: both operands
+// contiguous in k, K % 32 == 0, 16-byte aligned rows).  On gfx950 a SIMD does not overlap an MFMA with other
+// instructions of its waves (tools/microbench/mfma_overlap.hip: MFMA time and VALU/LDS time add), so the loop is built
+// to issue as little as possible besides v_mfma_f32_32x32x2_f32: a wave owns WM x WN accumulator tiles of 32 x 32 and
+// feeds 4 MFMAs of a tile from ONE ds_read_b128 per operand (lane half h owns k in [16h, 16h+16) of the 32-deep
+// step, i.e. the k index of the MFMA is a permutation of the tile's k, applied to A and B alike); the next step's
+// global loads are issued before the MFMAs and written to the other LDS buffer after them (one barrier per step).
+// Per 32-deep step and wave: 4 (WM + WN) LDS reads for 16 WM WN MFMAs of 64 cycles.
+// Work-group = 2 x 2 waves = (64 WM) x (64 WN) output tile.  LDS rows are 36 floats: the 16 lanes of a ds_read_b128
+// group then touch 16 different 16-byte slots.
+// -------------------------------------------------------------------------------------------------------------
+constexpr int kG2Ld = 36;
+
+template <int WM, int WN>
+static __global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(GemmArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    extern __shared__ __attribute__((aligned(16))) float g2lds[];      // 2 buffers x (BM + BN) rows x 36 floats
+    const int z = blockIdx.z;
+    const bool split = g.ksplit > 1;
+    const int zo = split ? 0 : z / g.zi_count, zi = split ? 0 : z % g.zi_count;
+    const int kslice = split ? g.K / g.ksplit : g.K;           // a multiple of 32 (host)
+    const float* A = g.A + zo * g.a_so + zi * g.a_si + (split ? (int64_t)z * kslice : 0);
+    const float* B = g.B + zo * g.b_so + zi * g.b_si + (split ? (int64_t)z * kslice : 0);
+    float* C = g.C + zo * g.c_so + zi * g.c_si + (split ? (int64_t)z * g.M * g.ldc : 0);
+    const float* R = g.R ? g.R + zo * g.c_so + zi * g.c_si : nullptr;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    // loader: thread t moves float4 (t & 7) of rows (t >> 3) + 32 p  (p < BM / 32 for A, < BN / 32 for B)
+    const int lrow = tid >> 3, lq = tid & 7;
+    f32x4 pa[BM / 32], pb[BN / 32];
+    const int M_ = g.M, N_ = g.N, K_ = kslice;
+    const int64_t lda_ = g.lda, ldbn_ = g.ldb_n;
+    // (macros, not lambdas: a by-reference capture of the by-value argument struct forces it into scratch memory)
+#define CLB_G2_LOAD(K0)                                                                                      \
+    {                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < BM / 32; ++p) {                                                \
+            int m = m0 + lrow + 32 * p;                                                                      \
+            m = m < M_ ? m : M_ - 1;                                                                         \
+            pa[p] = *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda_ + (K0) + 4 * lq);                 \
+        }                                                                                                    \
+        _Pragma("unroll") for (int p = 0; p < BN / 32; ++p) {                                                \
+            int n = n0 + lrow + 32 * p;                                                                      \
+            n = n < N_ ? n : N_ - 1;                                                                         \
+            pb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldbn_ + (K0) + 4 * lq);                \
+        }                                                                                                    \
+    }
+#define CLB_G2_STORE(BUF)                                                                                    \
+    {                                                                                                        \
+        float* As_ = g2lds + (BUF) * (BM + BN) * kG2Ld;                                                      \
+        float* Bs_ = As_ + BM * kG2Ld;                                                                       \
+        _Pragma("unroll") for (int p = 0; p < BM / 32; ++p)                                                  \
+            *reinterpret_cast<f32x4*>(As_ + (lrow + 32 * p) * kG2Ld + 4 * lq) = pa[p];                      \
+        _Pragma("unroll") for (int p = 0; p < BN / 32; ++p)                                                  \
+            *reinterpret_cast<f32x4*>(Bs_ + (lrow + 32 * p) * kG2Ld + 4 * lq) = pb[p];                      \
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    CLB_G2_LOAD(0)
+    CLB_G2_STORE(0)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K_; k0 += 32) {
+        const bool more = k0 + 32 < K_;
+        if (more) CLB_G2_LOAD(k0 + 32)
+        const float* As = g2lds + buf * (BM + BN) * kG2Ld + (wr * 32 * WM + i) * kG2Ld + 16 * h;
+        const float* Bs = g2lds + buf * (BM + BN) * kG2Ld + BM * kG2Ld + (wc * 32 * WN + i) * kG2Ld + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 av[WM], bv[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) av[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * kG2Ld + 4 * j);
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bv[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * kG2Ld + 4 * j);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][0], bv[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][1], bv[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][2], bv[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][3], bv[b][3], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (more) CLB_G2_STORE(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef CLB_G2_LOAD
+#undef CLB_G2_STORE
+    // C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            const int n = n0 + (wc * WN + b) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wr * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M && n < g.N) {
+                    float v = acc[a][b][r];
+                    if (!split) {
+                        v = v * g.scale;
+                        if (g.epi & EPI_BIAS) v += g.bias[n];
+                        if (g.epi & EPI_GELU) v = gelu_erf(v);
+                        if (g.epi & EPI_RESID) v += R[(int64_t)m * g.ldc + n];
+                    }
+                    C[(int64_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
+// split-K second pass: C = epilogue(sum over the K slices, in slice order -- deterministic)
+static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ksplit,
+                                                                       int64_t M, int N, float* __restrict__ C,
+                                                                       const float* __restrict__ bias,
+                                                                       const float* __restrict__ R, float scale, int epi) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int n = (int)(idx % N);
+    float v = part[idx];
+    for (int z = 1; z < ksplit; ++z) v = v + part[(size_t)z * M * N + idx];
+    v = v * scale;
+    if (epi & EPI_BIAS) v += bias[n];
+    if (epi & EPI_GELU) v = gelu_erf(v);
+    if (epi & EPI_RESID) v += R[idx];
+    C[idx] = v;
 }
 
 // embeddings: word[id] + position[pos] + token_type[0], then LayerNorm.  One wave per token.  ids are the

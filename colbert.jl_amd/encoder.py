@@ -44,6 +44,27 @@ def pack_weights(state: dict, bert_cfg: dict, dim: int) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate(parts))
 
 
+BERT_BASE = {"vocab_size": 30522, "hidden_size": 768, "num_hidden_layers": 12, "num_attention_heads": 12,
+             "intermediate_size": 3072, "max_position_embeddings": 512, "type_vocab_size": 2, "layer_norm_eps": 1e-12}
+
+
+def random_weights(bert_cfg: dict, dim: int = 128, seed: int = 0) -> np.ndarray:
+    """A random-init blob of the architecture `bert_cfg` (benchmarks: no checkpoint exists in the build image):
+    N(0, 0.02) matrices, zero biases, unit LayerNorm gains -- the HuggingFace initialisation."""
+    rng = np.random.default_rng(seed)
+    H, I = bert_cfg["hidden_size"], bert_cfg["intermediate_size"]
+    mat = lambda *shape: (0.02 * rng.standard_normal(shape, dtype=np.float32)).ravel()     # noqa: E731
+    zeros = lambda n: np.zeros(n, np.float32)                                              # noqa: E731
+    ones = lambda n: np.ones(n, np.float32)                                                # noqa: E731
+    parts = [mat(bert_cfg["vocab_size"], H), mat(bert_cfg["max_position_embeddings"], H),
+             mat(bert_cfg.get("type_vocab_size", 2), H), ones(H), zeros(H)]
+    for _ in range(bert_cfg["num_hidden_layers"]):
+        parts += [mat(3 * H, H), zeros(3 * H), mat(H, H), zeros(H), ones(H), zeros(H), mat(I, H), zeros(I), mat(H, I),
+                  zeros(H), ones(H), zeros(H)]
+    parts += [mat(dim, H), zeros(dim)]
+    return np.concatenate(parts)
+
+
 class BertEncoder:
     def __init__(self, weights: np.ndarray, bert_cfg: dict, dim: int = 128, device: int = 0,
                  tokenizer=None, config: Optional[ColBERTConfig] = None):
@@ -106,6 +127,18 @@ class BertEncoder:
         out = np.zeros((self.dim, L, N), dtype=np.float32, order="F")
         check(lib().clb_encode_queries(self._h, fptr(ids), fptr(m), i64(L), i64(N), fptr(sk), i64(sk.size), fptr(out)))
         return out
+
+    def query_embeddings_device(self, d_ids, d_mask, d_skiplist, d_out):
+        """_query_embeddings with torch CUDA tensors: ids int32 (N, L) row-major (= Julia (L, N)), mask uint8 (N, L),
+        skiplist int64, out float32 (N, L, dim) -- enqueued on torch's current stream, not waited for.  `out` is the
+        (B, T, dim) query tensor DeviceSearch takes."""
+        import torch
+        N, L = d_ids.shape
+        st = torch.cuda.current_stream(d_ids.device).cuda_stream
+        check(lib().clb_encode_queries_device(self._h, C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_mask.data_ptr()), i64(L),
+                                              i64(N), C.c_void_p(d_skiplist.data_ptr()), i64(d_skiplist.numel()),
+                                              C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
+        return d_out
 
     # -- the reference's batching loops -----------------------------------------------------------------
     def encode_passages(self, passages: List[str], skiplist=None, doc_token: Optional[str] = None):

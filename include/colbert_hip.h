@@ -218,6 +218,13 @@ int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* b
 int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
                        const int64_t* skiplist, int64_t n_skip, float* out);
 
+/* _query_embeddings with every pointer on the encoder's device, enqueued on `hip_stream` and not waited for: the
+ * (dim, L, N) output is what clb_search_batch_device takes as d_Q, so encode_queries + search (src/searching.jl:93-127)
+ * run back to back without leaving HBM.  d_skiplist: n_skip Int64 ids on the device.  An id outside the vocabulary
+ * cannot be reported from an asynchronous call: it is clamped (use clb_encode_queries to validate inputs). */
+int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
+                              const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream);
+
 /* Encoder epilogue as stand-alone calls  (src/modelling/checkpoint.jl:27-71, embedding_utils.jl:172-205) */
 /* _doc_embeddings_and_doclens after doc(): clear skiplist tokens, normalise, doclens, compaction.
  * D (dim, L, N) is read only; out (dim, <= L*N); doclens Int64[N]; *n_out = kept columns. */
