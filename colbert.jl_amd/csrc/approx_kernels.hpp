@@ -27,7 +27,9 @@
 //   cells:   bf16x3 MFMA value vs canonical fp32 chain <= 1.25*7.4e-5*qn*cn       (centroid_top_bf16x3_kernel)
 //            fp16 storage                            <= 2^-11 * qn*cn + 2^-25  (|cells| <= qn*cn < 65504: guarded in
 //                                                       select_margin_kernel; 2^-25: values below the normal range)
-//   Q.r:     bf16(Q), bf16(w) relative 2^-9 each     <= (2^-8 + 2^-18) * qn*rn
+//   Q.r:     bf16(Q), bf16(w)                        <= dq * rb + qn * dw_rn  (dq = max_t ||Q_t - bf16(Q_t)|| per query,
+//                                                       rb = max ||bf16 residual vector||, dw_rn = sqrt(dim) * max |w - bf16(w)|
+//                                                       per index: measured, not the generic 2^-9 relative bounds)
 //            fp32 accumulation in the MFMA           <= 2*128*u*qn*rn
 //   scaling: add, multiply, inv_norm rounding        <= 8*u*qn
 //   oracle:  canonical fp32 value vs real arithmetic <= 320*u*qn               (x, sumsq, sqrt, divide, chain)
@@ -76,13 +78,18 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
                                                              const uint32_t* __restrict__ codes0,
                                                              const uint8_t* __restrict__ residuals, int64_t n,
                                                              float* __restrict__ inv_norm,
-                                                             unsigned int* __restrict__ inv_max_bits) {
+                                                             unsigned int* __restrict__ inv_max_bits,
+                                                             unsigned int* __restrict__ r2_max_bits) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    float w[4];
+    float w[4], wb2[4];      // wb2: squares of the bf16-rounded weights (the residual vector pass 1 multiplies)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = weights[j];
+    for (int j = 0; j < 4; ++j) {
+        w[j] = weights[j];
+        const float wb = __uint_as_float(f32_to_bf16_rne(weights[j]) << 16);
+        wb2[j] = wb * wb;
+    }
     const int64_t groups = (n + 15) / 16;
-    float vmax = 0.f;
+    float vmax = 0.f, r2max = 0.f;
     for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t el = grp * 16 + r;
         const int64_t e = el < n ? el : n - 1;
@@ -91,7 +98,7 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
         uint4 v0 = *reinterpret_cast<const uint4*>(rp), v1 = *reinterpret_cast<const uint4*>(rp + 4);
         R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w; R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w;
         const float* cent = C + (size_t)codes0[e] * kDim + g;
-        float p = 0.f;
+        float p = 0.f, rr = 0.f;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const int bitpos = 8 * s;
@@ -101,15 +108,25 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
             const float x = cent[4 * s] + ((idx & 2) ? hi : lo);
             const float sq = x * x;
             p = p + sq;
+            rr += (idx & 2) ? ((idx & 1) ? wb2[3] : wb2[2]) : ((idx & 1) ? wb2[1] : wb2[0]);
         }
         const float a = p + __shfl_xor(p, 16, 64);
         const float n2 = a + __shfl_xor(a, 32, 64);
         const float inv = 1.0f / (sqrtf(n2) + FLT_EPSILON);
         if (g == 0 && el < n) inv_norm[e] = inv;
         vmax = fmaxf(vmax, inv);
+        rr += __shfl_xor(rr, 16, 64);
+        rr += __shfl_xor(rr, 32, 64);
+        r2max = fmaxf(r2max, rr);
     }
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, o, 64));
-    if (lane == 0) atomicMax(inv_max_bits, __float_as_uint(vmax));
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax = fmaxf(vmax, __shfl_down(vmax, o, 64));
+        r2max = fmaxf(r2max, __shfl_down(r2max, o, 64));
+    }
+    if (lane == 0) {
+        atomicMax(inv_max_bits, __float_as_uint(vmax));
+        atomicMax(r2_max_bits, __float_as_uint(r2max));
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -922,8 +939,10 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
 // -------------------------------------------------------------------------------------------------------------
 struct ApproxConsts {
     float cn_max;   // max ||centroid||
-    float rn_max;   // sqrt(dim) * max |bucket weight|
+    float rn_max;   // sqrt(dim) * max |bucket weight|  (>= ||r|| of every embedding)
     float inv_max;  // max inv_norm
+    float rb_max;   // max over the shard's embeddings of ||r'||, r' = the bf16-rounded residual vector
+    float dw_rn;    // sqrt(dim) * max_b |bf16(w_b) - w_b|  (>= ||r - r'|| of every embedding)
 };
 
 static __global__ __launch_bounds__(1024) void select_margin_kernel(const float* __restrict__ scores,
@@ -938,24 +957,31 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     __shared__ int sh_scan[16];
     __shared__ uint32_t s_prefix, s_kmin, s_kmax;
     __shared__ int s_remaining, s_run;
-    __shared__ float s_qn;
+    __shared__ float s_qn, s_dq;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
     int* lst = list + (size_t)b * cand_cap;
     // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
-    if (tid == 0) s_qn = 0.f;
+    if (tid == 0) { s_qn = 0.f; s_dq = 0.f; }
     __syncthreads();
-    {   // 32 threads per token, one float4 each (T <= 32 in this mode)
+    {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - bf16(Q_t)||: what the
+        // bf16 query operand of pass 1 really loses (at most 2^-9 ||Q_t||, ~0.6 of that for typical values)
         const int t = tid >> 5, part = tid & 31;
-        float a = 0.f;
+        float a = 0.f, dd = 0.f;
         if (t < T) {
             const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
             a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+            const float dx = v.x - __uint_as_float(f32_to_bf16_rne(v.x) << 16), dy = v.y - __uint_as_float(f32_to_bf16_rne(v.y) << 16);
+            const float dz = v.z - __uint_as_float(f32_to_bf16_rne(v.z) << 16), dw = v.w - __uint_as_float(f32_to_bf16_rne(v.w) << 16);
+            dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        if (t < T && part == 0) atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); dd += __shfl_xor(dd, o, 64); }
+        if (t < T && part == 0) {
+            atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
+            atomicMax(reinterpret_cast<unsigned int*>(&s_dq), __float_as_uint(sqrtf(dd) * 1.001f));
+        }
     }
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
     __syncthreads();
@@ -965,7 +991,10 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const float qn = s_qn;
     // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
     const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
-    const float e_qr = (3.90625e-03f + 3.8146973e-06f) * qn * ac.rn_max + 2.f * 128.f * u * qn * ac.rn_max;
+    // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the bf16 operands (their products are exact
+    // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
+    // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
+    const float e_qr = 1.001f * (s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
     const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
     // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
     // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
@@ -1155,24 +1184,39 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
                                const uint8_t* dRes, int64_t n_emb, int K, float* d_inv_norm /*null: constants only*/,
                                int n_weights, ApproxConsts* out) {
     DevBuf tmp;
-    CLB_TRY(tmp.alloc(3 * sizeof(unsigned int)));
-    CLB_HIP(hipMemsetAsync(tmp.p, 0, 3 * sizeof(unsigned int), st));
+    CLB_TRY(tmp.alloc(4 * sizeof(unsigned int)));
+    CLB_HIP(hipMemsetAsync(tmp.p, 0, 4 * sizeof(unsigned int), st));
     unsigned int* bits = tmp.as<unsigned int>();
     if (n_emb > 0 && d_inv_norm) {
         const int grid = (int)std::min<int64_t>(4096, (n_emb + 63) / 64);
-        hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, d_inv_norm, bits);
+        hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, d_inv_norm, bits,
+                           bits + 3);
     }
     hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 1);
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
     CLB_HIP(hipGetLastError());
-    unsigned int h[3];
+    unsigned int h[4];
+    float hw[16];
     CLB_HIP(hipMemcpyAsync(h, bits, sizeof h, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(hw, dW, sizeof(float) * std::min(n_weights, 16), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
-    float f[3];
+    float f[4];
     memcpy(f, h, sizeof f);
     out->inv_max = f[0] * 1.0001f;
     out->rn_max = sqrtf((float)kDim) * f[1] * 1.0001f;
     out->cn_max = f[2];
+    float dw = 0.f;
+    for (int j = 0; j < std::min(n_weights, 16); ++j) {
+        uint32_t u32;
+        memcpy(&u32, &hw[j], 4);
+        const uint32_t b16 = (u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16 << 16;
+        float wb;
+        memcpy(&wb, &b16, 4);
+        dw = std::max(dw, std::fabs(wb - hw[j]));
+    }
+    out->dw_rn = sqrtf((float)kDim) * dw * 1.0001f;
+    // no inv_norm pass (constants only): fall back to the generic bound ||r'|| <= sqrt(dim) * max |w| * (1 + 2^-8)
+    out->rb_max = (n_emb > 0 && d_inv_norm) ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.004f;
     return CLB_OK;
 }
 

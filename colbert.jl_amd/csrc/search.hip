@@ -89,7 +89,7 @@ struct clb_searcher {
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
-    Workspace ws[1];     // per-batch scratch, grown on demand (ensure_workspace)
+    Workspace ws[2];     // per-batch scratch, grown on demand (ensure_workspace); slot 1: a second batch in flight
     Prof prof;
     int64_t last_cand_docs = 0, last_cand_embs = 0, last_resc_docs = 0, last_resc_embs = 0;
     int64_t index_bytes = 0;
@@ -137,7 +137,7 @@ int next_pow2(int x) {
 
 int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_t nprobe, int64_t k) {
     if (B <= w.Bcap && T <= w.Tcap && nprobe <= w.npcap && k <= w.kcap) return CLB_OK;
-    CLB_HIP(hipStreamSynchronize(s->stream));
+    CLB_HIP(hipDeviceSynchronize());       // buffers may be in use on any of the caller's streams
     B = std::max(B, w.Bcap); T = std::max(T, w.Tcap);
     nprobe = std::max(nprobe, w.npcap); k = std::max(k, w.kcap);
     const int64_t Tpad = token_tiles(T) * 32;
@@ -173,7 +173,10 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     CLB_TRY(w.outp.ensure(sizeof(int64_t) * B * k));
     CLB_TRY(w.outs.ensure(sizeof(float) * B * k));
     CLB_TRY(w.flags.ensure(sizeof(int) * B));
-    CLB_TRY(w.stats.ensure(sizeof(unsigned long long) * 8));
+    if (!w.stats.p) {
+        CLB_TRY(w.stats.ensure(sizeof(unsigned long long) * 8));
+        CLB_HIP(hipMemset(w.stats.p, 0, sizeof(unsigned long long) * 8));
+    }
     if (s->approx_ok) {
         CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
         CLB_TRY(w.rowmask.ensure(sizeof(unsigned long long) * 4 * B * w.cand_cap));
@@ -719,25 +722,35 @@ int clb_searcher_get_mode(const clb_searcher* s) { return s ? s->mode : -1; }
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {
     if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
     consts[0] = s->approx_consts.cn_max; consts[1] = s->approx_consts.rn_max; consts[2] = s->approx_consts.inv_max;
+    consts[3] = s->approx_consts.rb_max; consts[4] = s->approx_consts.dw_rn;
     return CLB_OK;
 }
 int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts) {
     if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 5; ++i)
         if (!(consts[i] >= 0.f)) return fail(CLB_EARGUMENT, "bound constants must be non-negative numbers");
     s->approx_consts.cn_max = std::max(s->approx_consts.cn_max, consts[0]);
     s->approx_consts.rn_max = std::max(s->approx_consts.rn_max, consts[1]);
     s->approx_consts.inv_max = std::max(s->approx_consts.inv_max, consts[2]);
+    s->approx_consts.rb_max = std::max(s->approx_consts.rb_max, consts[3]);
+    s->approx_consts.dw_rn = std::max(s->approx_consts.dw_rn, consts[4]);
     return CLB_OK;
 }
 
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                             void* hip_stream) {
+    return clb_search_batch_device_slot(s, 0, d_Q, T, B, nprobe, k, d_out_pids, d_out_scores, d_n_cand, hip_stream);
+}
+
+int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
+                                 void* hip_stream) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
+    if (slot < 0 || slot > 1) return fail(CLB_EARGUMENT, "workspace slot must be 0 or 1");
     CLB_TRY(use_device(s->device));
     hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
-    Workspace& w = s->ws[0];
+    Workspace& w = s->ws[slot];
     w.pending.valid = false;
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores, d_n_cand));

@@ -145,9 +145,9 @@ class DeviceSearch:
     """Device-resident batched search on one shard: queries and results stay in HBM (torch tensors),
     work is enqueued on torch's current stream."""
 
-    def __init__(self, searcher, T: int, B: int, k: int, nprobe: int):
+    def __init__(self, searcher, T: int, B: int, k: int, nprobe: int, slot: int = 0):
         import torch
-        self.s, self.T, self.B, self.k, self.nprobe = searcher, T, B, k, nprobe
+        self.s, self.T, self.B, self.k, self.nprobe, self.slot = searcher, T, B, k, nprobe, slot
         self.dev = torch.device("cuda", searcher.device)
         # pids and scores live in one packed block so that a single all-gather can move both (all_gather_packed)
         self.packed = torch.empty(packed_topk_bytes(k, B), dtype=torch.uint8, device=self.dev)
@@ -182,8 +182,8 @@ class DeviceSearch:
         """Qdev: torch float32 tensor holding B queries laid out (B, T, dim) contiguous == Julia (dim, T, B)."""
         import torch
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        check(lib().clb_search_batch_device(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
-                                            i64(self.nprobe), i64(self.k), C.c_void_p(self.out_p.data_ptr()),
-                                            C.c_void_p(self.out_s.data_ptr()), C.c_void_p(self.ncand.data_ptr()),
-                                            C.c_void_p(st)))
+        check(lib().clb_search_batch_device_slot(self.s._h, C.c_int(self.slot), C.c_void_p(Qdev.data_ptr()), i64(self.T),
+                                                 i64(self.B), i64(self.nprobe), i64(self.k),
+                                                 C.c_void_p(self.out_p.data_ptr()), C.c_void_p(self.out_s.data_ptr()),
+                                                 C.c_void_p(self.ncand.data_ptr()), C.c_void_p(st)))
         return self.out_p, self.out_s

@@ -77,6 +77,13 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                             void* hip_stream);
+/* The same with an explicit workspace slot (0 or 1): two batches can be in flight on two streams of the caller, each
+ * on its own per-batch scratch -- the latency-bound selection kernels of one batch then overlap the scoring kernels of
+ * the other (bench.py).  Calls that use the same slot must be stream-ordered by the caller.  Every other entry point
+ * uses slot 0. */
+int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
+                                 void* hip_stream);
 /* Sharded (multi-GPU) search in two calls, so that every shard cuts at the GLOBAL k-th approximate score instead
  * of its own (a shard must otherwise re-score ~k passages exactly however small it is).  Two-pass mode only
  * (CLB_EUNSUPPORTED otherwise: use clb_search_batch_device).
@@ -95,12 +102,13 @@ int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_
  *    index shape supports it (dim 128, nbits 2), else 0. */
 int clb_searcher_set_mode(clb_searcher* s, int mode);
 int clb_searcher_get_mode(const clb_searcher* s);
-/* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, consts[1] = sqrt(dim) * max
- * |bucket weight|, consts[2] = max over the shard's embeddings of 1/(||c + r|| + eps).  Sharded search with a global
- * threshold (clb_search_shard_phase1/2) needs ONE bound on every shard: take the element-wise maximum over the
- * shards (an all-reduce MAX of three floats at load time) and set it on each handle.  `set` never lowers a value. */
-int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts /* 3 */);
-int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts /* 3 */);
+/* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, [1] = sqrt(dim) * max |bucket
+ * weight|, [2] = max over the shard's embeddings of 1/(||c + r|| + eps), [3] = max ||bf16-rounded residual vector||,
+ * [4] = sqrt(dim) * max |w - bf16(w)|.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE
+ * bound on every shard: take the element-wise maximum over the shards (an all-reduce MAX of five floats at load time)
+ * and set it on each handle.  `set` never lowers a value. */
+int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts /* 5 */);
+int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts /* 5 */);
 
 /* retrieve()  (src/search/ranking.jl:23-44) on its own -- test hook.  out_pids needs n_docs entries. */
 int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
