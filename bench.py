@@ -362,9 +362,17 @@ def main():
             pmc_all = json.load(open(pmc_file))
             pmc = pmc_all.get("kernels", {}).get(dom, {})
             if pmc_all.get("csrc_sha256") == csrc_hash() and "hbm_read_bytes" in pmc:
-                roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
+                raw = pmc["hbm_read_bytes_uncorrected"]
+                if dom == "score_approx":
+                    # FETCH_SIZE counts this kernel's contiguous streams (residual 32 B + code 4 B + inv_norm 4 B per
+                    # embedding) at half their bytes and its 64-B score-row gathers in full (fetch_calib.hip)
+                    stream = 40.0 * stats["cand_embs"]
+                    roof["traffic"] = int(raw + 0.5 * stream + pmc.get("hbm_write_bytes", 0))
+                    roof["traffic_split"] = {"stream_bytes": int(stream), "gather_miss_bytes": int(raw - 0.5 * stream)}
+                else:
+                    roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
                 roof["traffic_source"] = ("profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                          "this command, " + pmc_all.get("correction", ""))
+                                          "this command; " + pmc_all.get("correction", ""))
             else:
                 roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on different kernel sources"
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(prof_steps, 1), 4) for kname, v in prof.items()}

@@ -18,10 +18,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# rocprofv3 kernel name (template arguments stripped) -> the kernel ids bench.py reports
-BENCH_IDS = {"score_approx32_kernel": "score_approx", "score_approx_kernel": "score_approx",
-             "score_exact_flat_kernel": "score_exact", "score_exact_kernel": "score_exact",
-             "centroid_top_bf16x3_mq_kernel": "centroid_scores", "rows_mark32_kernel": "rescore_rows"}
+# rocprofv3 kernel name -> the kernel ids bench.py reports
+def bench_id(name: str):
+    base = name.split("<")[0]
+    if base == "score_approx32_kernel":
+        return "rescore_rows" if name.startswith("score_approx32_kernel<true") else "score_approx"
+    return {"score_exact_flat_kernel": "score_exact", "score_exact_kernel": "score_exact",
+            "centroid_top_bf16x3_mq_kernel": "centroid_scores"}.get(base)
 
 
 def csrc_hash() -> str:
@@ -76,14 +79,17 @@ def main():
         res[k] = e
     kernels = {}
     for k, e in res.items():
-        base = k.split("<")[0]
-        if base in BENCH_IDS and ("FETCH_SIZE" in e or "WRITE_SIZE" in e):
-            dst = kernels.setdefault(BENCH_IDS[base], {})
+        bid = bench_id(k)
+        if bid and ("FETCH_SIZE" in e or "WRITE_SIZE" in e):
+            dst = kernels.setdefault(bid, {})
             if e.get("pmc_launches", 0) >= dst.get("pmc_launches", 0):     # the variant with the most launches
                 dst.update(e, rocprof_name=k)
     doc = {"csrc_sha256": csrc_hash(),
-           "correction": "FETCH_SIZE (KB) x 1024 x 2: gfx950 tallies 128-B requests of 16-B-per-lane loads at 64 B "
-                         "(MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024",
+           "correction": "calibrated with tools/microbench/fetch_calib.hip (profiles/r02_fetch_size_calibration.md): FETCH_SIZE "
+                         "tallies every L2 miss request at 64 B -- contiguous streams (4- or 16-B-per-lane loads) leave L2 as "
+                         "128-B requests and read 0.5x, 64-B row gathers read 1.0x.  hbm_read_bytes = FETCH_SIZE x 1024 x 2 is "
+                         "the all-streaming figure; bench.py computes a mixed kernel's traffic as FETCH_SIZE x 1024 + half of "
+                         "its known stream bytes; WRITE_SIZE x 1024",
            "kernels": kernels, "all": res}
     json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, len(res), "kernels")
