@@ -364,9 +364,9 @@ def main():
             if pmc_all.get("csrc_sha256") == csrc_hash() and "hbm_read_bytes" in pmc:
                 raw = pmc["hbm_read_bytes_uncorrected"]
                 if dom == "score_approx":
-                    # FETCH_SIZE counts this kernel's contiguous streams (residual 32 B + code 4 B + inv_norm 4 B per
+                    # FETCH_SIZE counts this kernel's contiguous streams (residual 32 B + one 4-B code|inv_norm word per
                     # embedding) at half their bytes and its 64-B score-row gathers in full (fetch_calib.hip)
-                    stream = 40.0 * stats["cand_embs"]
+                    stream = 36.0 * stats["cand_embs"]
                     roof["traffic"] = int(raw + 0.5 * stream + pmc.get("hbm_write_bytes", 0))
                     roof["traffic_split"] = {"stream_bytes": int(stream), "gather_miss_bytes": int(raw - 0.5 * stream)}
                 else:

@@ -19,7 +19,7 @@
 //                fed as the A operand of v_mfma_f32_16x16x32_bf16 against bf16(Q) -- no centroid row is read,
 //                nothing is normalised per element;
 //   * inv_norm[e] = 1/(sqrtf(sumsq(c+r)) + eps32), precomputed once per index (fp32, canonical sumsq).
-// Per embedding this pass reads 32 B residual + 4 B code + 4 B inv_norm from HBM (streaming) and gathers one
+// Per embedding this pass reads 32 B residual + ONE 4-B word (code | quantised inv_norm) from HBM (streaming) and gathers one
 // 64-B fp16 cells row from L2/MALL.  Algorithmic bytes (roofline accounting): 36 B per embedding.
 //
 // Error bound (u = 2^-24; qn = max_t ||Q_t||2; cn = max ||c||2; rn = sqrt(dim) * max|w| >= ||r||2;
@@ -79,7 +79,8 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
                                                              const uint8_t* __restrict__ residuals, int64_t n,
                                                              float* __restrict__ inv_norm,
                                                              unsigned int* __restrict__ inv_max_bits,
-                                                             unsigned int* __restrict__ r2_max_bits) {
+                                                             unsigned int* __restrict__ r2_max_bits,
+                                                             unsigned int* __restrict__ inv_min_bits) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     float w[4], wb2[4];      // wb2: squares of the bf16-rounded weights (the residual vector pass 1 multiplies)
 #pragma unroll
@@ -89,7 +90,7 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
         wb2[j] = wb * wb;
     }
     const int64_t groups = (n + 15) / 16;
-    float vmax = 0.f, r2max = 0.f;
+    float vmax = 0.f, r2max = 0.f, vmin = __builtin_inff();
     for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t el = grp * 16 + r;
         const int64_t e = el < n ? el : n - 1;
@@ -115,18 +116,34 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
         const float inv = 1.0f / (sqrtf(n2) + FLT_EPSILON);
         if (g == 0 && el < n) inv_norm[e] = inv;
         vmax = fmaxf(vmax, inv);
+        vmin = fminf(vmin, inv);
         rr += __shfl_xor(rr, 16, 64);
         rr += __shfl_xor(rr, 32, 64);
         r2max = fmaxf(r2max, rr);
     }
     for (int o = 32; o > 0; o >>= 1) {
         vmax = fmaxf(vmax, __shfl_down(vmax, o, 64));
+        vmin = fminf(vmin, __shfl_down(vmin, o, 64));
         r2max = fmaxf(r2max, __shfl_down(r2max, o, 64));
     }
     if (lane == 0) {
         atomicMax(inv_max_bits, __float_as_uint(vmax));
+        atomicMin(inv_min_bits, __float_as_uint(vmin));      // positive floats order like their bit patterns
         atomicMax(r2_max_bits, __float_as_uint(r2max));
     }
+}
+
+// Pass 1 streams ONE word per embedding: the 0-based centroid code in the low `cbits` bits and inv_norm quantised to
+// the remaining bits, inv' = inv_lo + q * step (|inv' - inv| <= step / 2, accounted for in the error bound).  36 B per
+// embedding are then streamed -- exactly the algorithmic bytes -- instead of 40, with one load less per step.
+static __global__ void pack_code_inv_kernel(const uint32_t* __restrict__ codes0, const float* __restrict__ inv_norm,
+                                            int64_t n, int cbits, float inv_lo, float inv_step_rcp, uint32_t qmax,
+                                            uint32_t* __restrict__ codeinv) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float qf = rintf((inv_norm[e] - inv_lo) * inv_step_rcp);
+    qf = fminf(fmaxf(qf, 0.f), (float)qmax);
+    codeinv[e] = codes0[e] | ((uint32_t)qf << cbits);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -690,11 +707,12 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // access in the loop at all.
 template <bool ROWS, int ABL = 0>
 static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
-    const float* __restrict__ weights, const uint32_t* __restrict__ codes0, const uint8_t* __restrict__ residuals,
-    const float* __restrict__ inv_norm, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
+    const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
+    int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
     int B, size_t cand_cap, uint16_t* __restrict__ tokmax, const int* __restrict__ list,
     const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask) {
+    const uint32_t cmask = (1u << cbits) - 1u;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const int x = blockIdx.x & 7;             // XCD group label
@@ -778,7 +796,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         int it_base = 0;
 
         // stage A: residual bytes (16 B / lane), code and inv_norm of the lane's row (dword each), ROWS: stored maximum
-#define CLB_STAGE_A(RB, CV, IV, PM, TAG)                                                                    \
+#define CLB_STAGE_A(RB, CV, PM, TAG)                                                                    \
     {                                                                                                       \
         const bool live = it_k < nd;                                                                        \
         const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
@@ -788,17 +806,16 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         const uint32_t rr = min((uint32_t)r, (uint32_t)(rows - 1));   /* tail lanes duplicate the last row */ \
         /* wave-uniform 64-bit bases + 32-bit lane offsets: the scalar-base form of global_load        */ \
         const uint8_t* rbase_ = residuals + (size_t)e0 * 32;                                                \
-        const uint32_t* cbase_ = codes0 + (size_t)e0;                                                       \
-        const float* ibase_ = inv_norm + (size_t)e0;                                                        \
+        const uint32_t* cbase_ = codeinv + (size_t)e0;                                                      \
         const uint32_t roff_ = rr * 32u + h16;                                                              \
         /* the three streams are read once per query: non-temporal loads keep them from evicting the score  */ \
         /* table, which the gathers want in L2 (measured: 0.779 -> 0.762 ms)                               */ \
         if (ABL == 3 || ABL == 7) RB = u32x4{e0 * 2654435761u + rr, e0 ^ h16, e0 + 77u * rr, e0 * 40503u};  \
         else if (ABL == 4) RB = *reinterpret_cast<const u32x4*>(rbase_ + roff_);                            \
         else RB = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rbase_ + roff_));               \
-        if (ABL == 7) { CV = (e0 * 97u + rr) & 131071u; IV = 1.f; }                                         \
-        else if (ABL == 4) { CV = cbase_[rr]; IV = ibase_[rr]; }                                            \
-        else { CV = __builtin_nontemporal_load(cbase_ + rr); IV = __builtin_nontemporal_load(ibase_ + rr); } \
+        if (ABL == 7) CV = (e0 * 97u + rr) & 131071u;                                                       \
+        else if (ABL == 4) CV = cbase_[rr];                                                                 \
+        else CV = __builtin_nontemporal_load(cbase_ + rr);      /* code | quantised inv_norm */              \
         TAG.j = live ? j0 + it_k * stride : -1;                                                             \
         TAG.rows = rows;                                                                                    \
         TAG.last = left <= kStepRows;                                                                       \
@@ -816,7 +833,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         // stage G: the score row of the lane's embedding: tokens 8h..8h+7 and 16+8h..16+8h+7 (fp16), 2 x 16 B
 #define CLB_STAGE_G(CV, X0, X1)                                                                             \
     {                                                                                                       \
-        const char* row_ = c16 + (((ABL == 2 ? (CV & 1023u) : CV) << 6) + h16);                             \
+        const char* row_ = c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);                   \
         if (ABL == 1 || ABL == 7) { X0 = u32x4{CV, CV, CV, CV}; X1 = X0; }                                  \
         else {                                                                                              \
         X0 = *reinterpret_cast<const u32x4*>(row_);                                                         \
@@ -824,11 +841,11 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         }                                                                                                   \
     }
 #define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + lut_offset<N>(W, lane8)))
-#define CLB_STAGE_C(RB, IV, X0, X1, PM, TAG)                                                                \
+#define CLB_STAGE_C(RB, CV, X0, X1, PM, TAG)                                                                \
     {                                                                                                       \
         /* inv_norm: lane layout (row = r) -> accumulator layout (register i = row (i&3) + 8(i>>2) + 4h)  */ \
         __builtin_amdgcn_wave_barrier();                                                                    \
-        myinv[r] = IV;                                                                                      \
+        myinv[r] = fmaf((float)(CV >> cbits), inv_step, inv_lo);                                            \
         __builtin_amdgcn_wave_barrier();                                                                    \
         /* residual byte -> 4 bf16 bucket weights through the LDS table; k-step s = bytes 2s, 2s+1.  All 16  */ \
         /* reads are issued before the first MFMA (an LDS read takes longer than an MFMA: interleaved one  */ \
@@ -907,23 +924,22 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
 
         float mx = kNegInf;
         u32x4 rb0, rb1, rb2, xa0, xa1, xa2, xb0, xb1, xb2;
-        uint32_t cv0, cv1, cv2;
-        float iv0, iv1, iv2;
+        uint32_t cv0, cv1, cv2, cw0, cw1, cw2;       // cv: as loaded (stage A); cw: the copy stage C dequantises
         uint16_t pm0 = 0, pm1 = 0, pm2 = 0;
         StepTag t0, t1, t2;
-        CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
-        CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
-        CLB_STAGE_G(cv0, xa0, xb0);
+        CLB_STAGE_A(rb0, cv0, pm0, t0);
+        CLB_STAGE_A(rb1, cv1, pm1, t1);
+        CLB_STAGE_G(cv0, xa0, xb0); cw0 = cv0;
         while (t0.j >= 0) {
-            CLB_STAGE_A(rb2, cv2, iv2, pm2, t2);
-            CLB_STAGE_G(cv1, xa1, xb1);
-            CLB_STAGE_C(rb0, iv0, xa0, xb0, pm0, t0);
-            CLB_STAGE_A(rb0, cv0, iv0, pm0, t0);
-            CLB_STAGE_G(cv2, xa2, xb2);
-            CLB_STAGE_C(rb1, iv1, xa1, xb1, pm1, t1);
-            CLB_STAGE_A(rb1, cv1, iv1, pm1, t1);
-            CLB_STAGE_G(cv0, xa0, xb0);
-            CLB_STAGE_C(rb2, iv2, xa2, xb2, pm2, t2);
+            CLB_STAGE_A(rb2, cv2, pm2, t2);
+            CLB_STAGE_G(cv1, xa1, xb1); cw1 = cv1;
+            CLB_STAGE_C(rb0, cw0, xa0, xb0, pm0, t0);
+            CLB_STAGE_A(rb0, cv0, pm0, t0);
+            CLB_STAGE_G(cv2, xa2, xb2); cw2 = cv2;
+            CLB_STAGE_C(rb1, cw1, xa1, xb1, pm1, t1);
+            CLB_STAGE_A(rb1, cv1, pm1, t1);
+            CLB_STAGE_G(cv0, xa0, xb0); cw0 = cv0;
+            CLB_STAGE_C(rb2, cw2, xa2, xb2, pm2, t2);
         }
         }   // chunk of 64 passages
 #undef CLB_STAGE_A
@@ -943,6 +959,7 @@ struct ApproxConsts {
     float inv_max;  // max inv_norm
     float rb_max;   // max over the shard's embeddings of ||r'||, r' = the bf16-rounded residual vector
     float dw_rn;    // sqrt(dim) * max_b |bf16(w_b) - w_b|  (>= ||r - r'|| of every embedding)
+    float inv_qerr; // max |dequantised inv_norm - inv_norm| = half a quantisation step of the packed code|inv word
 };
 
 static __global__ __launch_bounds__(1024) void select_margin_kernel(const float* __restrict__ scores,
@@ -995,7 +1012,8 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
     // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
     const float e_qr = 1.001f * (s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
-    const float eps_t = ac.inv_max * (e_cells + e_qr) + 328.f * u * qn;
+    // the packed inv_norm is off by at most inv_qerr: it scales P = X + Q.r, |P| <= qn (cn + rn), and the other terms
+    const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_cells + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 328.f * u * qn;
     // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
     // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
     // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
@@ -1179,28 +1197,33 @@ static __global__ void max_row_norm_kernel(const float* __restrict__ C, int K, u
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
 }
 
-// index-load: inv_norm array + the constants of the error bound
+// index-load: the packed code | inv_norm words of pass 1 + the constants of the error bound.
+// d_codeinv == nullptr: constants only (index build).  On return *inv_lo / *inv_step describe the quantisation.
 inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW, const uint32_t* dCodes0,
-                               const uint8_t* dRes, int64_t n_emb, int K, float* d_inv_norm /*null: constants only*/,
-                               int n_weights, ApproxConsts* out) {
-    DevBuf tmp;
-    CLB_TRY(tmp.alloc(4 * sizeof(unsigned int)));
+                               const uint8_t* dRes, int64_t n_emb, int K, uint32_t* d_codeinv /*null: constants only*/,
+                               int cbits, int n_weights, ApproxConsts* out, float* inv_lo = nullptr,
+                               float* inv_step = nullptr) {
+    DevBuf tmp, inv;
+    CLB_TRY(tmp.alloc(5 * sizeof(unsigned int)));
     CLB_HIP(hipMemsetAsync(tmp.p, 0, 4 * sizeof(unsigned int), st));
+    CLB_HIP(hipMemsetAsync(static_cast<char*>(tmp.p) + 4 * sizeof(unsigned int), 0x7f, sizeof(unsigned int), st));  // +huge
     unsigned int* bits = tmp.as<unsigned int>();
-    if (n_emb > 0 && d_inv_norm) {
+    const bool pack = n_emb > 0 && d_codeinv;
+    if (pack) {
+        CLB_TRY(inv.alloc(sizeof(float) * n_emb));
         const int grid = (int)std::min<int64_t>(4096, (n_emb + 63) / 64);
-        hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, d_inv_norm, bits,
-                           bits + 3);
+        hipLaunchKernelGGL(inv_norm_kernel, dim3(grid), dim3(256), 0, st, dC, dW, dCodes0, dRes, n_emb, inv.as<float>(), bits,
+                           bits + 3, bits + 4);
     }
     hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 1);
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
     CLB_HIP(hipGetLastError());
-    unsigned int h[4];
+    unsigned int h[5];
     float hw[16];
     CLB_HIP(hipMemcpyAsync(h, bits, sizeof h, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipMemcpyAsync(hw, dW, sizeof(float) * std::min(n_weights, 16), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
-    float f[4];
+    float f[5];
     memcpy(f, h, sizeof f);
     out->inv_max = f[0] * 1.0001f;
     out->rn_max = sqrtf((float)kDim) * f[1] * 1.0001f;
@@ -1216,7 +1239,23 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
     }
     out->dw_rn = sqrtf((float)kDim) * dw * 1.0001f;
     // no inv_norm pass (constants only): fall back to the generic bound ||r'|| <= sqrt(dim) * max |w| * (1 + 2^-8)
-    out->rb_max = (n_emb > 0 && d_inv_norm) ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.004f;
+    out->rb_max = pack ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.004f;
+    out->inv_qerr = 0.f;
+    if (pack) {
+        // at most 20 bits for inv_norm: every level is then an exact float (a 26-bit qmax rounds UP as a float and the
+        // top level would overflow the word) and the step is already far below the other error terms
+        const uint32_t qmax = (1u << std::min(32 - cbits, 20)) - 1u;
+        const float lo = f[4], hi = f[0];
+        const float step = hi > lo ? (hi - lo) / (float)qmax : 0.f;
+        // half a step plus the rounding of the (de)quantisation arithmetic itself
+        out->inv_qerr = 0.5f * step * 1.001f + 4.f * 5.9604645e-08f * hi;
+        hipLaunchKernelGGL(pack_code_inv_kernel, dim3((unsigned)((n_emb + 255) / 256)), dim3(256), 0, st, dCodes0,
+                           inv.as<float>(), n_emb, cbits, lo, step > 0.f ? 1.0f / step : 0.f, qmax, d_codeinv);
+        CLB_HIP(hipGetLastError());
+        CLB_HIP(hipStreamSynchronize(st));
+        if (inv_lo) *inv_lo = lo;
+        if (inv_step) *inv_step = step;
+    }
     return CLB_OK;
 }
 

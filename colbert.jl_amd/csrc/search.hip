@@ -84,7 +84,9 @@ struct clb_searcher {
     DevBuf doc_off;     // u32 [n_docs+1]
     DevBuf ivf_off;     // u32 [K+1]
     DevBuf ivf_pid;     // u32 [n_emb] local passage ids grouped by centroid
-    DevBuf inv_norm;    // fp32 [n_emb]  (two-pass mode)
+    DevBuf codeinv;     // u32 [n_emb]: code | quantised inv_norm, the one word pass 1 streams per embedding (two-pass mode)
+    int cbits = 0;      // bits of the code field
+    float inv_lo = 0.f, inv_step = 0.f;
     DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     ApproxConsts approx_consts{};
@@ -479,7 +481,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
             const dim3 approx_grid = gx2d > 0 && B > 1 ? dim3(std::max(1, gx2d / B), B) : dim3(8 * wgpg);
 #define CLB_LAUNCH_APPROX(ABL)                                                                                        \
     hipLaunchKernelGGL((score_approx32_kernel<false, ABL>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(), \
-                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,            \
+                       s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,  \
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(), \
                        (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,                    \
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
@@ -522,7 +524,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 256);
         const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 32);
         hipLaunchKernelGGL(score_approx32_kernel<true>, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
-                           s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
+                           s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                            (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
                            w.rowmask.as<unsigned long long>());
@@ -655,6 +657,35 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     if (herr & 1) return bail(fail(CLB_EBOUNDS, "ivf holds embedding ids outside 1..n_emb"));
     if (herr & 2) return bail(fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!"));
 
+    if (!s->generic && n_emb > 0 && !CLB_KNOB("CLB_DEBUG_NO_SORT", 0)) {
+        // Order every passage's embeddings by centroid code (results cannot change: MaxSim maximises over a passage's
+        // embeddings; row masks, headers and the IVF are positional or per passage).  Equal and neighbouring codes then
+        // sit in adjacent lanes of a pass-1 step: their 64-byte score rows coalesce into fewer, larger requests.
+        const size_t row_bytes = rows;                    // multiple of 16 for dim 128
+        DevBuf keys, keys2, vals, perm, codes_new, res_new;
+        if ((rc = keys.alloc(sizeof(uint64_t) * n_emb)) || (rc = keys2.alloc(sizeof(uint64_t) * n_emb)) ||
+            (rc = vals.alloc(sizeof(uint32_t) * n_emb)) || (rc = perm.alloc(sizeof(uint32_t) * n_emb)) ||
+            (rc = codes_new.alloc(sizeof(uint32_t) * (n_emb + kPad))) || (rc = res_new.alloc(row_bytes * (n_emb + kPad))))
+            return bail(rc);
+        const int blocks = (int)((n_emb + 255) / 256);
+        hipLaunchKernelGGL(passage_code_keys_kernel, dim3(blocks), dim3(256), 0, s->stream, s->codes0.as<uint32_t>(),
+                           s->doc_off.as<uint32_t>(), n_emb, (int)n_docs, keys.as<unsigned long long>(), vals.as<uint32_t>());
+        if ((rc = sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), perm.as<uint32_t>(),
+                                 (size_t)n_emb, s->stream)))
+            return bail(rc);
+        if (hipMemsetAsync(codes_new.p, 0, codes_new.bytes, s->stream) != hipSuccess ||
+            hipMemsetAsync(res_new.p, 0, res_new.bytes, s->stream) != hipSuccess)
+            return bail(fail(CLB_EHIP, "memset failed"));
+        hipLaunchKernelGGL(permute_codes_kernel, dim3(blocks), dim3(256), 0, s->stream, perm.as<uint32_t>(),
+                           s->codes0.as<uint32_t>(), codes_new.as<uint32_t>(), n_emb);
+        const int pieces = (int)(row_bytes / 16);
+        hipLaunchKernelGGL(permute_rows16_kernel, dim3((unsigned)(((int64_t)n_emb * pieces + 255) / 256)), dim3(256), 0,
+                           s->stream, perm.as<uint32_t>(), s->residuals.as<uint4>(), res_new.as<uint4>(), n_emb, pieces);
+        if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+            return bail(fail(CLB_EHIP, "reordering the index failed"));
+        std::swap(s->codes0.p, codes_new.p); std::swap(s->codes0.bytes, codes_new.bytes);
+        std::swap(s->residuals.p, res_new.p); std::swap(s->residuals.bytes, res_new.bytes);
+    }
     if (s->generic) {
         s->mode = 0;
         s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
@@ -669,18 +700,22 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
         hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s->stream,
                            s->centroids.as<float>(), s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), nel);
     }
-    s->approx_ok = approx_supported((int)dim, nbits);
+    s->cbits = 1;
+    while (((int64_t)1 << s->cbits) < K) ++s->cbits;
+    // the packed word leaves 32 - cbits bits for inv_norm: at least 12 (K <= 2^20), otherwise exact mode only
+    s->approx_ok = approx_supported((int)dim, nbits) && s->cbits <= 20;
     if (s->approx_ok) {
-        if ((rc = s->inv_norm.alloc(sizeof(float) * (n_emb + kStepRows)))) return bail(rc);
-        if (hipMemsetAsync(s->inv_norm.p, 0, s->inv_norm.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
+        if ((rc = s->codeinv.alloc(sizeof(uint32_t) * (n_emb + kStepRows)))) return bail(rc);
+        if (hipMemsetAsync(s->codeinv.p, 0, s->codeinv.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
     }
     if ((rc = build_approx_tables(s->stream, s->centroids.as<float>(), s->weights.as<float>(),
                                   s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), n_emb, (int)K,
-                                  s->approx_ok ? s->inv_norm.as<float>() : nullptr, 1 << nbits, &s->approx_consts)))
+                                  s->approx_ok ? s->codeinv.as<uint32_t>() : nullptr, s->cbits, 1 << nbits,
+                                  &s->approx_consts, &s->inv_lo, &s->inv_step)))
         return bail(rc);
     s->mode = s->approx_ok ? 1 : 0;
     s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
-                               s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes + s->inv_norm.bytes);
+                               s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes + s->codeinv.bytes);
     *out = s;
     return CLB_OK;
 }
@@ -722,18 +757,19 @@ int clb_searcher_get_mode(const clb_searcher* s) { return s ? s->mode : -1; }
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {
     if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
     consts[0] = s->approx_consts.cn_max; consts[1] = s->approx_consts.rn_max; consts[2] = s->approx_consts.inv_max;
-    consts[3] = s->approx_consts.rb_max; consts[4] = s->approx_consts.dw_rn;
+    consts[3] = s->approx_consts.rb_max; consts[4] = s->approx_consts.dw_rn; consts[5] = s->approx_consts.inv_qerr;
     return CLB_OK;
 }
 int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts) {
     if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
         if (!(consts[i] >= 0.f)) return fail(CLB_EARGUMENT, "bound constants must be non-negative numbers");
     s->approx_consts.cn_max = std::max(s->approx_consts.cn_max, consts[0]);
     s->approx_consts.rn_max = std::max(s->approx_consts.rn_max, consts[1]);
     s->approx_consts.inv_max = std::max(s->approx_consts.inv_max, consts[2]);
     s->approx_consts.rb_max = std::max(s->approx_consts.rb_max, consts[3]);
     s->approx_consts.dw_rn = std::max(s->approx_consts.dw_rn, consts[4]);
+    s->approx_consts.inv_qerr = std::max(s->approx_consts.inv_qerr, consts[5]);
     return CLB_OK;
 }
 
@@ -891,7 +927,7 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
     hipLaunchKernelGGL(score_approx32_kernel<false>, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
-                       s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), s->inv_norm.as<float>(), dQ,
+                       s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                        (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);

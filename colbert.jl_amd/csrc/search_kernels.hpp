@@ -1172,6 +1172,36 @@ static __global__ void ivf_to_pid_kernel(const int64_t* __restrict__ ivf, const 
     ivf_pid[i] = (uint32_t)lo;
 }
 
+// Load-time reordering of every passage's embeddings by centroid code (MaxSim takes a maximum over a passage's
+// embeddings, so their order inside the passage is free): key = local pid << 32 | code, value = embedding id.
+static __global__ void passage_code_keys_kernel(const uint32_t* __restrict__ codes0, const uint32_t* __restrict__ doc_off,
+                                                int64_t n_emb, int n_docs, unsigned long long* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_emb) return;
+    int lo = 0, hi = n_docs;  // largest p with doc_off[p] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)doc_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    keys[e] = ((unsigned long long)(uint32_t)lo << 32) | codes0[e];
+    vals[e] = (uint32_t)e;
+}
+// new[e] = old[perm[e]] for the codes (one thread per embedding) and the residual rows (16-byte pieces)
+static __global__ void permute_codes_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ src,
+                                            uint32_t* __restrict__ dst, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = src[perm[e]];
+}
+static __global__ void permute_rows16_kernel(const uint32_t* __restrict__ perm, const uint4* __restrict__ src,
+                                             uint4* __restrict__ dst, int64_t n, int pieces /* 16-byte pieces per row */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * pieces) return;
+    const int64_t e = i / pieces;
+    const int q = (int)(i % pieces);
+    dst[i] = src[(size_t)perm[e] * pieces + q];
+}
+
 // codes: 1-based -> 0-based, range check (decompress's DomainError, residual.jl:766-768)
 static __global__ void codes_to_zero_based_kernel(uint32_t* __restrict__ codes, int64_t n, uint32_t K,
                                            int* __restrict__ err) {

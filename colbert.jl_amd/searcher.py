@@ -75,15 +75,15 @@ class Searcher:
 
     @property
     def bound_consts(self) -> np.ndarray:
-        """The five constants of this handle's error bound (include/colbert_hip.h, clb_searcher_get_bound_consts)."""
-        out = np.zeros(5, dtype=np.float32)
+        """The six constants of this handle's error bound (include/colbert_hip.h, clb_searcher_get_bound_consts)."""
+        out = np.zeros(6, dtype=np.float32)
         check(lib().clb_searcher_get_bound_consts(self._h, fptr(out)))
         return out
 
     def raise_bound_consts(self, consts):
         """Element-wise maximum with `consts` (sharded search: one bound on every shard, distributed.sync_bound_consts)."""
         c = np.ascontiguousarray(consts, dtype=np.float32)
-        assert c.shape == (5,)
+        assert c.shape == (6,)
         check(lib().clb_searcher_set_bound_consts(self._h, fptr(c)))
 
     # -- search -----------------------------------------------------------------------------------

@@ -104,11 +104,11 @@ int clb_searcher_set_mode(clb_searcher* s, int mode);
 int clb_searcher_get_mode(const clb_searcher* s);
 /* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, [1] = sqrt(dim) * max |bucket
  * weight|, [2] = max over the shard's embeddings of 1/(||c + r|| + eps), [3] = max ||bf16-rounded residual vector||,
- * [4] = sqrt(dim) * max |w - bf16(w)|.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE
- * bound on every shard: take the element-wise maximum over the shards (an all-reduce MAX of five floats at load time)
+ * [4] = sqrt(dim) * max |w - bf16(w)|, [5] = the quantisation error of the packed inv_norm.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE
+ * bound on every shard: take the element-wise maximum over the shards (an all-reduce MAX of six floats at load time)
  * and set it on each handle.  `set` never lowers a value. */
-int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts /* 5 */);
-int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts /* 5 */);
+int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts /* 6 */);
+int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts /* 6 */);
 
 /* retrieve()  (src/search/ranking.jl:23-44) on its own -- test hook.  out_pids needs n_docs entries. */
 int clb_retrieve(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe, int64_t* out_pids,
