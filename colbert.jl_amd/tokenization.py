@@ -2,9 +2,11 @@
 (Julia): [PAD]=1, [unused0]=2, [unused1]=3, [UNK]=101, [CLS]=102, [SEP]=103, [MASK]=104 for bert-base-uncased.
 
 `WordPieceTokenizer` wraps the HuggingFace `tokenizers` WordPiece model over a vocab.txt and reproduces the
-reference's pipelines: documents are truncated AND padded to doc_maxlen-1 tokens (src/indexing.jl:37-46),
-queries truncated OR padded to query_maxlen-1 (src/searching.jl:32-40); the marker token is then inserted as
-the second row (_add_marker_row, tokenizer_utils.jl:140-143)."""
+reference's pipelines: documents go through TextEncodeBase.trunc_and_pad(doc_maxlen-1) (src/indexing.jl:37-46):
+cut to doc_maxlen-1 tokens, then padded to the LONGEST sequence of the batch; queries through
+trunc_or_pad(query_maxlen-1) (src/searching.jl:32-40): cut or padded to exactly query_maxlen-1.  The marker
+token is then inserted as the second row (_add_marker_row, tokenizer_utils.jl:140-143).  Both are pinned to the
+REPL outputs recorded in the reference's docstrings (tests/golden/tokenizer_kats.json)."""
 from __future__ import annotations
 
 from typing import List
@@ -36,8 +38,8 @@ class WordPieceTokenizer:
 
     def encode(self, batch_text: List[str], max_tokens: int, pad_to_max: bool):
         """TextEncoders.encode after the truncation/padding pipe: [CLS] w1 .. wn [SEP] truncated to
-        `max_tokens` (:tail), padded with [PAD] to max_tokens (documents: trunc_and_pad) or to the longest
-        sequence of the batch (queries: trunc_or_pad).  Returns (integer_ids Int32 (len, batch) 1-based,
+        `max_tokens` (:tail), padded with [PAD] to max_tokens (queries: trunc_or_pad) or to the longest
+        sequence of the batch (documents: trunc_and_pad).  Returns (integer_ids Int32 (len, batch) 1-based,
         bitmask Bool (len, batch))."""
         seqs = []
         for t in batch_text:
@@ -61,7 +63,7 @@ def _add_marker_row(data: np.ndarray, marker):
 
 def tensorize_docs(doc_token: str, tokenizer, batch_text: List[str], doc_maxlen: int = 300):
     """tensorize_docs (doc_tokenization.jl:143-156)."""
-    ids, mask = tokenizer.encode(batch_text, doc_maxlen - 1, pad_to_max=True)
+    ids, mask = tokenizer.encode(batch_text, doc_maxlen - 1, pad_to_max=False)
     ids = _add_marker_row(ids, np.int32(tokenizer.lookup(doc_token)))
     mask = _add_marker_row(mask, True)
     return ids, mask

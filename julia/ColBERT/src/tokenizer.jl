@@ -112,8 +112,8 @@ end
 
 """
 Token ids and mask of a batch: every sequence is cut to `max_tokens` (keeping its head) and padded with [PAD] to
-`max_tokens` (`pad_to_max`, documents: src/indexing.jl:37-46) or to the longest sequence of the batch (queries:
-src/searching.jl:32-40).  Returns (integer_ids::Matrix{Int32} (len, batch), bitmask::Matrix{Bool}).
+`max_tokens` (`pad_to_max`, queries: trunc_or_pad, src/searching.jl:32-40) or to the longest sequence of the batch
+(documents: trunc_and_pad, src/indexing.jl:37-46).  Returns (integer_ids::Matrix{Int32} (len, batch), bitmask::Matrix{Bool}).
 """
 function _integer_ids_and_mask(t::WordPieceTokenizer, batch_text::AbstractVector{<:AbstractString}, max_tokens::Int,
         pad_to_max::Bool)
@@ -135,7 +135,7 @@ _add_marker_row(data::AbstractMatrix{T}, marker::T) where {T} =
 "tensorize_docs (doc_tokenization.jl:143-156)"
 function tensorize_docs(doc_token::String, t::WordPieceTokenizer, batch_text::AbstractVector{<:AbstractString},
         doc_maxlen::Int)
-    ids, mask = _integer_ids_and_mask(t, batch_text, doc_maxlen - 1, true)
+    ids, mask = _integer_ids_and_mask(t, batch_text, doc_maxlen - 1, false)
     _add_marker_row(ids, lookup(t, doc_token)), _add_marker_row(mask, true)
 end
 

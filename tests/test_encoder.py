@@ -37,7 +37,7 @@ def test_add_marker_row():
 
 def test_tensorize_docs(tok):
     ids, mask = tokenization.tensorize_docs("[unused1]", tok, ["hello world!", "this is a longer passage with many words"], 12)
-    assert ids.shape == mask.shape == (12, 2) and ids.dtype == np.int32
+    assert ids.shape == mask.shape == (11, 2) and ids.dtype == np.int32           # padded to the longest of the batch
     one = lambda t: tok.lookup(t)
     assert ids[0, 0] == one("[CLS]") and ids[1, 0] == one("[unused1]") == 3          # marker is row 2, 1-based id 3
     assert list(ids[2:6, 0]) == [one("hello"), one("world"), one("!"), one("[SEP]")]
@@ -49,6 +49,39 @@ def test_tensorize_docs(tok):
     assert ids.shape == (6, 1) and mask.all()
     sk = tok.doc_skiplist(True)
     assert len(sk) == 33 and sk[-1] == 1 and len(tok.doc_skiplist(False)) == 1    # embedding_utils.jl:37-72
+
+
+def _docstring_tokenizer(tmp_path, kat, vocab_size):
+    """vocab.txt with the entries the recorded example touches at their bert-base-uncased line numbers."""
+    lines = ["[unused%d]" % i for i in range(vocab_size)]
+    for k, v in kat["vocab_1based"].items():
+        lines[int(k) - 1] = v
+    lines[100] = "[UNK]"
+    f = tmp_path / "vocab.txt"
+    f.write_text("\n".join(lines) + "\n")
+    return tokenization.WordPieceTokenizer(str(f))
+
+
+def test_tensorize_docs_reference_docstring(tmp_path):
+    """doc_tokenization.jl:61-141: the REPL session recorded against colbertv2.0's vocabulary."""
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_kats.json")))
+    kat = kats["docs"]
+    t = _docstring_tokenizer(tmp_path, kat, kats["vocab_size"])
+    ids, mask = tokenization.tensorize_docs(kat["marker"], t, kat["texts"], kat["maxlen"])
+    assert np.array_equal(ids, np.asarray(kat["integer_ids"], np.int32))
+    assert np.array_equal(mask, np.asarray(kat["bitmask"], bool))
+
+
+def test_tensorize_queries_reference_docstring(tmp_path):
+    """query_tokenization.jl:55-171 (wordpiece splits "ras ##p ##berries", truncation of the long query at 32)."""
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_kats.json")))
+    kat = kats["queries"]
+    # words of the examples whose ids the docstring does not show must not resolve by accident: every other line
+    # of the synthetic vocabulary is an [unusedN] filler
+    t = _docstring_tokenizer(tmp_path, kat, kats["vocab_size"])
+    ids, mask = tokenization.tensorize_queries(kat["marker"], False, t, kat["texts"], kat["maxlen"])
+    assert np.array_equal(ids, np.asarray(kat["integer_ids"], np.int32))
+    assert np.array_equal(mask, np.asarray(kat["bitmask"], bool))
 
 
 def test_tensorize_queries(tok):
