@@ -220,20 +220,25 @@ def main():
             dt = float(tmax.item())
         return dt
 
+    # (0) pre-conditioning + the sustained figure: the same loop repeated in whole multiples of --steps until the region
+    #     lasts --min-seconds (a 20-step region is ~25 ms: too short to trust on its own, and a GPU that has just
+    #     come out of index generation idles at a low clock); every rank uses the same count
     for i in range(args.warmup):
         step(i)
-    # (1) the contract's measurement: exactly --steps steps, per-kernel event timing OFF
-    elapsed = timed(args.steps, args.warmup)
-    qps = B * args.steps / elapsed
-    # (2) the same loop repeated in whole multiples of --steps until the region lasts --min-seconds (a 20-step region
-    #     is ~20 ms: too short to trust on its own); every rank uses the same count
-    reps = max(1, int(np.ceil(args.min_seconds / max(elapsed, 1e-6))))
+    probe = timed(args.steps, args.warmup)
+    reps = max(1, int(np.ceil(args.min_seconds / max(probe, 1e-6))))
     if world > 1:
         r_t = torch.tensor([reps], dtype=torch.int64, device=dev)
         dist.all_reduce(r_t, op=dist.ReduceOp.MAX)
         reps = int(r_t.item())
     sustained_steps = reps * args.steps
     sustained_s = timed(sustained_steps, args.warmup + args.steps)
+    # (1) the contract's measurement on the warm device: --warmup untimed steps, then exactly --steps steps between
+    #     barrier + synchronize pairs, per-kernel event timing OFF
+    for i in range(args.warmup):
+        step(i)
+    elapsed = timed(args.steps, args.warmup)
+    qps = B * args.steps / elapsed
     # (3) a separate pass with HIP events around every kernel (on the stream they are launched on) for the roofline
     #     -- on ONE stream, so that a kernel's time is its own (with two batches in flight kernels share the chip)
     was = overlap[0]

@@ -633,7 +633,7 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 //     kernel of round 1 issued 8 dword gathers (that kernel was bound by its request count, not its bytes);
 //   * inv_norm: one dword per lane (embedding r), moved to the accumulator layout (lane = token, register = row)
 //     through a 128-byte per-wave LDS patch: 1 ds_write_b32 + 4 ds_read_b128;
-//   * epilogue: 16 multiplies + 8 v_max3 per lane; at a passage's last step the two lane halves are combined and the
+//   * epilogue: 16 v_mul_f32 + 8 v_max3 per lane; at a passage's last step the two lane halves are combined and the
 //     32 per-token maxima summed.
 // Rows past the end of a passage (tail step) are DUPLICATES of the passage's last row -- the lane clamps its row
 // index before it forms any address, so residual, code, score row and inv_norm all belong to that row -- and a
@@ -687,7 +687,10 @@ __device__ __forceinline__ float sum_lanes_0_31(float s) {
 // (hipcc drops the second result of __builtin_amdgcn_permlane32_swap(m, m): one ds_bpermute per passage instead)
 __device__ __forceinline__ float max_lane_halves(float m) { return fmaxf(m, __shfl_xor(m, 32, 64)); }
 
-constexpr int kApproxThreads = 768;                 // 12 waves per work-group = 3 per SIMD, one work-group per CU
+#ifndef CLB_APPROX_WAVES
+#define CLB_APPROX_WAVES 12
+#endif
+constexpr int kApproxThreads = 64 * CLB_APPROX_WAVES;   // 12 waves per work-group = 3 per SIMD, one work-group per CU
 constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slots x 8 B
 
 // ROWS = false: pass 1 over every candidate; besides the score it leaves tokmax[b][slot][32] = the per-token maxima
@@ -703,7 +706,7 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 //        !(v < lo): a NaN or an infinite window (guarded query, select_margin_kernel) selects the row.
 // ABL != 0: ablation variants for the roofline analysis (instantiated only in -DCLB_ABLATIONS builds; results are
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
-// stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 plain v_mul instead of v_pk_mul; 7 no memory
+// stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
 // access in the loop at all.
 template <bool ROWS, int ABL = 0>
 static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
@@ -872,8 +875,11 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
                     __builtin_bit_cast(bf16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
                     __builtin_bit_cast(bf16x8, qb[s_]), acc, 0, 0, 0);                                      \
         }                                                                                                   \
+        /* plain v_mul_f32: packed f32 ops (v_pk_mul_f32) do not overlap the MFMAs of the co-resident waves  */ \
+        /* (tools/microbench/issue_overlap: 3 per MFMA gap cost 27 cycles, 6 plain multiplies cost 3); the  */ \
+        /* empty asm keeps the SLP vectoriser from re-packing them.  ABL 6: the packed form, for comparison */ \
         float v[16];                                                                                        \
-        if (ABL == 6) { _Pragma("unroll") for (int i = 0; i < 16; ++i) { v[i] = acc[i] * iq[i >> 2][i & 3]; asm volatile("" : "+v"(v[i])); } } \
+        if (ABL != 6) { _Pragma("unroll") for (int i = 0; i < 16; ++i) { v[i] = acc[i] * iq[i >> 2][i & 3]; asm volatile("" : "+v"(v[i])); } } \
         else                                                                                                \
         _Pragma("unroll") for (int i = 0; i < 16; i += 2) {    /* v_pk_mul_f32: two rows per instruction */ \
             const f32x2 p_ = f32x2{acc[i], acc[i + 1]} * f32x2{iq[i >> 2][i & 3], iq[i >> 2][(i & 3) + 1]}; \

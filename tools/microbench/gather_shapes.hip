@@ -80,6 +80,71 @@ static void run(const char* name, const unsigned char* tables, size_t table_byte
     fflush(stdout);
 }
 
+
+// Phased access: the rows of a step come from a 4-MB window of the XCD's table set; every wave switches window every
+// `period` steps on its own clock (no barrier: the waves of an XCD drift apart as in a real kernel), `leak`/256 of the
+// rows come from the sibling window (the other half of the same 8-MB table).  Models pass 1 walking a query's
+// candidates in two code-range phases.
+template <int SHAPE, int STREAM>
+__global__ __launch_bounds__(768) void kphase(const unsigned char* __restrict__ tables, size_t xcd_bytes, uint32_t period,
+                                              uint32_t leak, const unsigned char* __restrict__ stream,
+                                              uint32_t steps_per_wave, uint32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned char* base = tables + (size_t)(blockIdx.x & 7) * xcd_bytes;
+    const uint32_t wrows = (4u << 20) / 64u, nwin = (uint32_t)(xcd_bytes / (4u << 20));
+    uint32_t acc = 0;
+    const uint32_t s0 = wave * steps_per_wave;
+    // waves start a little out of step with each other (up to a quarter period)
+    const uint32_t skew = (wave * 2654435761u >> 24) * period / 1024u;
+#pragma unroll 4
+    for (uint32_t s = s0; s < s0 + steps_per_wave; ++s) {
+        const uint32_t g0 = s * 32u;
+        const uint32_t win = ((s - s0 + skew) / period) % nwin;
+        if (STREAM != NOSTREAM) {
+            const size_t off = (size_t)s * 1024 + (STREAM == SPLIT ? r * 32u + 16u * h : lane * 16u);
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(stream + off));
+            acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+        auto row_addr = [&](uint32_t g) -> const unsigned char* {
+            uint32_t x = g * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+            const uint32_t w = ((x >> 24) < leak) ? (win ^ 1u) : win;
+            const uint32_t row = (uint32_t)(((uint64_t)(x * 40503u + 77u) * wrows) >> 32);
+            return base + ((size_t)w * wrows + row) * 64;
+        };
+        if (SHAPE == PAIR32) {
+            const unsigned char* p = row_addr(g0 + r) + 16u * h;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 32);
+            acc ^= a[0] ^ a[3] ^ b[1] ^ b[2];
+        } else if (SHAPE == QUAD) {
+            const uint32_t q = lane & 3u, qd = lane >> 2;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(row_addr(g0 + 2u * qd) + 16u * q);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(row_addr(g0 + 2u * qd + 1u) + 16u * q);
+            acc ^= a[0] ^ a[3] ^ b[1] ^ b[2];
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int SHAPE, int STREAM>
+static void run_phase(const char* name, const unsigned char* tables, size_t xcd_bytes, uint32_t period, uint32_t leak,
+                      const unsigned char* stream, uint32_t* out) {
+    const int blocks = 256, threads = 768;                     // one work-group per CU, as pass 1
+    const uint32_t steps_per_wave = 512;                       // 256 x 12 x 512 x 32 = 50.3 M rows
+    const double rows = (double)blocks * 12 * steps_per_wave * 32;
+    hipLaunchKernelGGL((kphase<SHAPE, STREAM>), dim3(blocks), dim3(threads), 0, 0, tables, xcd_bytes, period, leak, stream, steps_per_wave, out);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((kphase<SHAPE, STREAM>), dim3(blocks), dim3(threads), 0, 0, tables, xcd_bytes, period, leak, stream, steps_per_wave, out);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    printf("%-40s period %4u steps, leak %3u/256: %.3f ms for %.1f M rows\n", name, period, leak, ms, rows * 1e-6);
+    fflush(stdout);
+}
+
 int main() {
     const size_t big = (size_t)4 << 30, small = (size_t)8 << 20;
     unsigned char *tb, *ts, *st; uint32_t* out;
@@ -111,6 +176,20 @@ int main() {
         snprintf(name, sizeof name, "PAIR32 alone, %zu MB table / XCD", mb);
         run<PAIR32, NOSTREAM>(name, ts, mb << 20, 1, st, out);
     }
+    {   // phased walk over 8 x 64 MB (16 windows of 4 MB per XCD)
+        unsigned char* tp; hipMalloc(&tp, (size_t)512 << 20); hipMemset(tp, 3, (size_t)512 << 20); hipDeviceSynchronize();
+        for (uint32_t period : {64u, 16u, 1u})
+            for (uint32_t leak : {0u, 33u, 128u}) {
+                run_phase<PAIR32, SPLIT>("phased PAIR32 + stream SPLIT", tp, (size_t)64 << 20, period, leak, st, out);
+                run_phase<QUAD, SPLIT>("phased QUAD + stream SPLIT", tp, (size_t)64 << 20, period, leak, st, out);
+                run_phase<QUAD, CONTIG>("phased QUAD + stream CONTIG", tp, (size_t)64 << 20, period, leak, st, out);
+            }
+        run_phase<QUAD, NOSTREAM>("phased QUAD alone", tp, (size_t)64 << 20, 64, 33, st, out);
+        run_phase<PAIR32, NOSTREAM>("phased PAIR32 alone", tp, (size_t)64 << 20, 64, 33, st, out);
+    }
+    run<QUAD, NOSTREAM>("QUAD alone 2 MB", ts, (size_t)2 << 20, 1, st, out);
+    run<QUAD, SPLIT>("QUAD + stream SPLIT 4 MB", ts, (size_t)4 << 20, 1, st, out);
+    run<PAIR32, CONTIG>("PAIR32 + stream CONTIG 4 MB", ts, (size_t)4 << 20, 1, st, out);
     run<NOGATHER, SPLIT>("residual stream SPLIT alone", ts, small, 1, st, out);
     run<NOGATHER, CONTIG>("residual stream CONTIG alone", ts, small, 1, st, out);
     return 0;
