@@ -300,7 +300,8 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt, dt_enc = float(tm[0].item()), float(tm[1].item())
         e2e = {"value": round(B * args.steps / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
-               "encoder_ms_per_step": round(dt_enc / args.steps * 1e3, 4), "dtype": "f32",
+               "encoder_ms_per_step": round(dt_enc / args.steps * 1e3, 4),
+               "dtype": "f32" if enc.gemm == "f32" else f"f32 ({enc.gemm}: every fp32 product of the Linear layers as exact bf16 MFMA products of split operands, fp32 accumulation)",
                "encoder": "bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072) + Dense 768->128, random weights, "
                           "synthetic token ids; every rank encodes the whole batch",
                "note": "encode_queries + search per step; the search consumes the synthetic queries of the headline line"}

@@ -15,6 +15,8 @@ struct clb_encoder {
     float eps = 1e-12f;
     hipStream_t stream = nullptr;
     DevBuf weights;
+    bool fused_attention = true;   // CLB_ENCODER_UNFUSED_ATTENTION=1: the three-kernel path (comparison / head sizes != 64)
+    int gemm_mode = 2;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6 (bf16 MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
     // per-layer relative offsets
@@ -73,6 +75,48 @@ void gemm(hipStream_t st, const float* A, const float* B, float* C, const float*
     }
 }
 
+// activations (T x K, fp32) x Linear weight (N x K, fp32) on the split-bf16 kernels (both operands are split into
+// bf16 planes while they are staged).  Falls back to the fp32 MFMA GEMM for shapes the kernel does not take.
+template <int NS>
+void linear_split(hipStream_t st, Gemm3Args g, float* part) {
+    const int M = g.M, N = g.N, K = g.K;
+    auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm); };
+    auto lds = [](int bm, int bn) { return (size_t)(NS * (bm + bn) * 64); };
+    // 128 x 128 per 4-wave work-group, two or three work-groups per CU (measured: 8-wave 128 x 256 / 256 x 128 tiles with
+    // one work-group per CU are 10 % slower -- nothing covers their barrier phases)
+    if (wgs(128, 128) >= 384) {
+        hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 2, 2, NS>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), lds(128, 128), st, g);
+    } else if (wgs(64, 128) >= 384 && N >= 128) {
+        hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 2, NS>), dim3((N + 127) / 128, (M + 63) / 64, 1), dim3(256), lds(64, 128), st, g);
+    } else {
+        int ks = 1;
+        if (part) {
+            while (ks < 8 && wgs(64, 64) * ks < 512 && K % (ks * 2 * 32) == 0 && K / (ks * 2) >= 256) ks *= 2;
+        }
+        if (ks > 1) {
+            float* C = g.C;
+            g.ksplit = ks; g.C = part;
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), lds(64, 64), st, g);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, ks,
+                               (int64_t)M, N, C, g.bias, g.R, 1.0f, g.epi);
+        } else {
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), lds(64, 64), st, g);
+        }
+    }
+}
+
+void linear(clb_encoder* e, hipStream_t st, const float* A, const float* Wt, float* C, const float* bias, const float* R,
+            int M, int N, int K, int epi, float* part) {
+    const bool ok = e->gemm_mode != 0 && K % 32 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)Wt % 16 == 0) && M >= 1 && N >= 1;
+    if (!ok) {
+        gemm(st, A, Wt, C, bias, R, M, N, K, K, K, 1, N, epi, 1.0f, 1, 1, 0, 0, 0, 0, 0, 0, part);
+        return;
+    }
+    Gemm3Args g{A, Wt, C, bias, R, M, N, K, K, K, N, 1.0f, epi, 1};
+    if (e->gemm_mode == 1) linear_split<2>(st, g, part);
+    else linear_split<3>(st, g, part);
+}
+
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
 // sync = false: everything is only enqueued on `st` (an out-of-vocabulary id is then clamped silently).
 int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t* d_ids, const uint8_t* d_mask,
@@ -81,7 +125,8 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     const float* W = e->weights.as<float>();
     CLB_TRY(e->x.ensure(sizeof(float) * T * H));
     CLB_TRY(e->qkv.ensure(sizeof(float) * T * 3 * H));
-    CLB_TRY(e->scores.ensure(sizeof(float) * N * heads * L * L));
+    const bool fused = dh == 64 && L <= 512 && e->fused_attention;
+    if (!fused) CLB_TRY(e->scores.ensure(sizeof(float) * N * heads * L * L));
     CLB_TRY(e->ctx.ensure(sizeof(float) * T * H));
     CLB_TRY(e->hbuf.ensure(sizeof(float) * T * I));
     CLB_TRY(e->tmp.ensure(sizeof(float) * T * H));
@@ -104,27 +149,34 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     for (int64_t l = 0; l < e->layers; ++l) {
         const float* P = W + e->o_layer0 + l * e->layer_stride;
         // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
-        gemm(st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, H, H, 1, 3 * H, EPI_BIAS);
-        // scores[n, head] = Q K^T / sqrt(dh)
-        gemm(st, qkv, qkv + H, sc, nullptr, nullptr, (int)L, (int)L, (int)dh, 3 * H, 3 * H, 1, L, 0, inv_sqrt, (int)N, (int)heads,
-             L * 3 * H, dh, L * 3 * H, dh, heads * L * L, L * L);
-        hipLaunchKernelGGL(masked_softmax_kernel, dim3(blocks_for(N * heads * L, 4)), dim3(256), 0, st, sc, N * heads * L, (int)L,
-                           (int)heads, d_mask);
-        // context[n, head] = P V   (B(k = key, n = dim) = V[key][dim]: ldb_k = 3H, ldb_n = 1)
-        gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
-             heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
+        linear(e, st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr);
+        if (dh == 64 && L <= 512 && e->fused_attention) {
+            // softmax(Q K^T / sqrt(dh) + mask) V, one wave per (sequence, head, 32 queries), scores never leave registers
+            const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
+#define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt)
+            if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
+            else if (L <= 256) CLB_ATT(8); else if (L <= 320) CLB_ATT(10); else if (L <= 384) CLB_ATT(12); else CLB_ATT(16);
+#undef CLB_ATT
+        } else {
+            // scores[n, head] = Q K^T / sqrt(dh)
+            gemm(st, qkv, qkv + H, sc, nullptr, nullptr, (int)L, (int)L, (int)dh, 3 * H, 3 * H, 1, L, 0, inv_sqrt, (int)N, (int)heads,
+                 L * 3 * H, dh, L * 3 * H, dh, heads * L * L, L * L);
+            hipLaunchKernelGGL(masked_softmax_kernel, dim3(blocks_for(N * heads * L, 4)), dim3(256), 0, st, sc, N * heads * L, (int)L,
+                               (int)heads, d_mask);
+            // context[n, head] = P V   (B(k = key, n = dim) = V[key][dim]: ldb_k = 3H, ldb_n = 1)
+            gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
+                 heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
+        }
         // attention output + residual, LayerNorm
-        gemm(st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, H, H, 1, H, EPI_BIAS | EPI_RESID, 1.0f, 1, 1,
-             0, 0, 0, 0, 0, 0, part);
+        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part);
         hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, tmp, T, (int)H, P + e->r_g1, P + e->r_b1n, e->eps);
         // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
-        gemm(st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, H, H, 1, I, EPI_BIAS | EPI_GELU);
-        gemm(st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, I, I, 1, H, EPI_BIAS | EPI_RESID, 1.0f, 1, 1,
-             0, 0, 0, 0, 0, 0, part);
+        linear(e, st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr);
+        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part);
         hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, x, T, (int)H, P + e->r_g2, P + e->r_b2n, e->eps);
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
-    gemm(st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, H, H, 1, e->dim, EPI_BIAS);
+    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, nullptr);
     CLB_HIP(hipGetLastError());
     if (!sync) return CLB_OK;
     int herr = 0;
@@ -161,6 +213,7 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
     clb_encoder* e = new clb_encoder();
     e->device = device; e->vocab = vocab; e->H = hidden; e->layers = layers; e->heads = heads; e->I = intermediate;
     e->max_pos = max_pos; e->type_vocab = type_vocab; e->dim = dim; e->eps = ln_eps;
+    e->fused_attention = !(getenv("CLB_ENCODER_UNFUSED_ATTENTION") && atoi(getenv("CLB_ENCODER_UNFUSED_ATTENTION")));
     if (expected_weights(e) != n_weights) {
         const long long want = (long long)expected_weights(e);
         delete e;
@@ -207,6 +260,13 @@ int clb_encoder_destroy(clb_encoder* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     delete e;
+    return CLB_OK;
+}
+
+int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (mode < 0 || mode > 2) return fail(CLB_EARGUMENT, "gemm mode %d: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6", mode);
+    e->gemm_mode = mode;
     return CLB_OK;
 }
 

@@ -90,12 +90,11 @@ static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
 // -------------------------------------------------------------------------------------------------------------
 // The same GEMM for the shapes that carry the encoder's flops (activations x torch Linear weights: both operands
-// contiguous in k, K % 32 == 0, 16-byte aligned rows).  On gfx950 a SIMD does not overlap an MFMA with other
-// instructions of its waves (tools/microbench/mfma_overlap.hip: MFMA time and VALU/LDS time add), so the loop is built
-// to issue as little as possible besides v_mfma_f32_32x32x2_f32: a wave owns WM x WN accumulator tiles of 32 x 32 and
-// feeds 4 MFMAs of a tile from ONE ds_read_b128 per operand (lane half h owns k in [16h, 16h+16) of the 32-deep
-// step, i.e. the k index of the MFMA is a permutation of the tile's k, applied to A and B alike); the next step's
-// global loads are issued before the MFMAs and written to the other LDS buffer after them (one barrier per step).
+// contiguous in k, K % 32 == 0, 16-byte aligned rows).  The loop issues little besides v_mfma_f32_32x32x2_f32: a wave
+// owns WM x WN accumulator tiles of 32 x 32 and feeds 4 MFMAs of a tile from ONE ds_read_b128 per operand (lane half
+// h owns k in [16h, 16h+16) of the 32-deep step, i.e. the k index of the MFMA is a permutation of the tile's k, applied
+// to A and B alike); the next step's global loads are issued before the MFMAs and written to the other LDS buffer
+// after them (one barrier per step).
 // Per 32-deep step and wave: 4 (WM + WN) LDS reads for 16 WM WN MFMAs of 64 cycles.
 // Work-group = 2 x 2 waves = (64 WM) x (64 WN) output tile.  LDS rows are 36 floats: the 16 lanes of a ds_read_b128
 // group then touch 16 different 16-byte slots.
@@ -208,6 +207,175 @@ static __global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(GemmArgs g) 
         }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate on gfx950: 512
+// matrix-pipe cycles per 32 x 32 x 16 block against 32 per bf16 MFMA).  Every fp32 operand is split into NS bf16
+// planes, x = p0 + p1 (+ p2) with p0 = RN_bf16(x), p1 = RN_bf16(x - p0), p2 = RN_bf16(x - p0 - p1) -- the
+// subtractions are exact in fp32 -- and the product is the sum of the plane products whose magnitude matters, every
+// one exact in the fp32 accumulator, smallest terms first:
+//   NS = 2 ("bf16x3"): a*b ~= a1*b0 + a0*b1 + a0*b0                            3 MFMAs, error < 2^-15 |a||b| per product
+//   NS = 3 ("bf16x6"): a*b ~= a2*b0 + a0*b2 + a1*b1 + a1*b0 + a0*b1 + a0*b0    6 MFMAs, error < 2^-22 |a||b|: three planes
+//                      hold all 24 significant bits of an fp32 number, the dropped terms are below 2^-24 |a||b| each
+// Both operands stay fp32 in HBM/L2 and are split by the loader threads while a tile is staged (v_cvt_pk_bf16_f32 +
+// exact subtractions: plain VALU work that hides under the MFMAs of the co-resident waves,
+// tools/microbench/issue_overlap): the kernel is bound by the bytes it pulls through L2 -- measured: pre-split
+// planes in memory (6 B per element instead of 4) made it slower, not faster -- so nothing but fp32 is ever read.
+// LDS: one buffer of NS planes per operand, rows of 32 bf16 = 64 B without padding; 16-byte chunk c of row r sits at
+// chunk position c ^ ((r >> 2) & 3), so the 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) touch
+// 16 different 16-byte bank groups.  Work-group = WGM x WGN waves, wave tile (32 WM) x (32 WN), K step 32 = two k16
+// MFMA groups; the next step's global loads are issued before the MFMAs and written after them (two barriers per step;
+// a second work-group or the second wave of every SIMD covers them).
+// -------------------------------------------------------------------------------------------------------------
+struct Gemm3Args {
+    const float* A; const float* B; float* C; const float* bias; const float* R;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    float scale;
+    int epi;
+    int ksplit;        // > 1: blockIdx.z = K slice; raw partial sums go to C + z*M*ldc
+};
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+// four consecutive k of one row -> 8 bytes in each of the NS planes (plane stride PL bytes)
+template <int NS>
+__device__ __forceinline__ void split_store4(const f32x4 v, unsigned char* d, int PL) {
+    const uint32_t h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
+    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+    const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[1] - __uint_as_float(h0 & 0xffff0000u);
+    const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
+    const uint32_t l0 = cvt_pk_bf16(r0, r1), l1 = cvt_pk_bf16(r2, r3);
+    *reinterpret_cast<uint2*>(d + PL) = make_uint2(l0, l1);
+    if (NS == 3) {
+        const uint32_t t0 = cvt_pk_bf16(r0 - __uint_as_float(l0 << 16), r1 - __uint_as_float(l0 & 0xffff0000u));
+        const uint32_t t1 = cvt_pk_bf16(r2 - __uint_as_float(l1 << 16), r3 - __uint_as_float(l1 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(t0, t1);
+    }
+}
+
+template <int WGM, int WGN, int WM, int WN, int NS>
+static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(Gemm3Args g) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+    constexpr int PA = BM * 64, PB = BN * 64;                              // bytes per plane
+    constexpr int RPP = NT / 8;                                            // rows covered by one loader pass
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the loader pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char g3lds[];  // [A planes | B planes]
+    const int z = blockIdx.z;
+    const bool split = g.ksplit > 1;
+    const int K_ = split ? g.K / g.ksplit : g.K;                // a multiple of 32 (host)
+    const float* A = g.A + (split ? (int64_t)z * K_ : 0);
+    const float* B = g.B + (split ? (int64_t)z * K_ : 0);
+    float* C = g.C + (split ? (int64_t)z * g.M * g.ldc : 0);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int i = lane & 31, h = lane >> 5;
+    const int M_ = g.M, N_ = g.N;
+    const int64_t lda_ = g.lda, ldb_ = g.ldb;
+    // loader: thread t moves float4 (t & 7) of rows (t >> 3) + RPP p of A and of B
+    const int lrow = tid >> 3, lq = tid & 7;
+    f32x4 pa[BM / RPP], pb[BN / RPP];
+#define CLB_G3_LOAD(K0)                                                                                      \
+    {                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
+            int m = m0 + lrow + RPP * p;                                                                     \
+            m = m < M_ ? m : M_ - 1;                                                                         \
+            pa[p] = *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda_ + (K0) + 4 * lq);                 \
+        }                                                                                                    \
+        _Pragma("unroll") for (int p = 0; p < BN / RPP; ++p) {                                               \
+            int n = n0 + lrow + RPP * p;                                                                     \
+            n = n < N_ ? n : N_ - 1;                                                                         \
+            pb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldb_ + (K0) + 4 * lq);                 \
+        }                                                                                                    \
+    }
+#define CLB_G3_STORE()                                                                                       \
+    {                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
+            const int row_ = lrow + RPP * p;                                                                 \
+            split_store4<NS>(pa[p], g3lds + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PA); \
+        }                                                                                                    \
+        _Pragma("unroll") for (int p = 0; p < BN / RPP; ++p) {                                               \
+            const int row_ = lrow + RPP * p;                                                                 \
+            split_store4<NS>(pb[p], g3lds + NS * PA + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PB); \
+        }                                                                                                    \
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    CLB_G3_LOAD(0)
+    CLB_G3_STORE()
+    __syncthreads();
+    const int sw = (i >> 2) & 3;                  // the swizzle of this lane's rows (tile bases are multiples of 32)
+    const unsigned char* As = g3lds + (wr * 32 * WM + i) * 64;
+    const unsigned char* Bs = g3lds + NS * PA + (wc * 32 * WN + i) * 64;
+    for (int k0 = 0; k0 < K_; k0 += 32) {
+        const bool more = k0 + 32 < K_;
+        if (more) CLB_G3_LOAD(k0 + 32)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((2 * s + h) ^ sw) << 4;
+            bf16x8 av[NS][WM], bv[NS][WN];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int a = 0; a < WM; ++a) av[q][a] = *reinterpret_cast<const bf16x8*>(As + q * PA + a * 32 * 64 + off);
+#pragma unroll
+                for (int b = 0; b < WN; ++b) bv[q][b] = *reinterpret_cast<const bf16x8*>(Bs + q * PB + b * 32 * 64 + off);
+            }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    f32x16 c = acc[a][b];
+                    if (NS == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][a], bv[0][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][a], bv[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][a], bv[1][b], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][a], bv[0][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][a], bv[1][b], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][a], bv[0][b], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+        }
+        __syncthreads();              // every wave has read the tile
+        if (more) CLB_G3_STORE()
+        __syncthreads();
+    }
+#undef CLB_G3_LOAD
+#undef CLB_G3_STORE
+    // C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            const int n = n0 + (wc * WN + b) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wr * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M && n < g.N) {
+                    float v = acc[a][b][r];
+                    if (!split) {
+                        v = v * g.scale;
+                        if (g.epi & EPI_BIAS) v += g.bias[n];
+                        if (g.epi & EPI_GELU) v = gelu_erf(v);
+                        if (g.epi & EPI_RESID) v += g.R[(int64_t)m * g.ldc + n];
+                    }
+                    C[(int64_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
 // split-K second pass: C = epilogue(sum over the K slices, in slice order -- deterministic)
 static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ksplit,
                                                                        int64_t M, int N, float* __restrict__ C,
@@ -301,6 +469,113 @@ static __global__ __launch_bounds__(256) void masked_softmax_kernel(float* __res
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     for (int k = lane; k < L; k += 64) s[k] *= inv;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Fused self-attention for head size 64: softmax(Q K^T / sqrt(dh) + key mask) V of one (sequence, head) pair and one
+// block of 32 query positions PER WAVE, entirely in registers -- no L x L score matrix in memory, no barrier, no LDS
+// (the unfused path writes and re-reads N heads L^2 floats three times per layer: 13 of the 32 ms of a 64 x 300 passage
+// batch).  fp32 MFMA (v_mfma_f32_32x32x2_f32) for both products:
+//   * S^T tile = K_tile (32 keys x 64) . Q_blk^T (64 x 32 queries): computing the TRANSPOSE puts query i in lane
+//     (i, h) with 16 of the tile's keys in its accumulator registers (key = 32 jt + (r & 3) + 8 (r >> 2) + 4 h), which
+//     is exactly the A-operand layout of the second product -- no transposition of P between the two MFMA chains.
+//     The summation index of an MFMA step is a dummy: lane half h carries features 32h + s at step s, so a lane's
+//     32 operand values are one contiguous 128-byte piece of its Q / K row (8 dwordx4 loads).
+//   * row maximum / sum: in-lane over the NT tiles' registers, then one exchange between the two lane halves;
+//     masked keys (bitmask == 0, GenericSequenceMask(bitmask), checkpoint.jl:24) and keys past L get probability 0.
+//   * O (32 x 64) = P V: A = the normalised probabilities straight from the accumulator registers, B = V[key][d]
+//     read as 128-byte row pieces (lane = d), two 32-column output tiles.
+// NT = key tiles of 32 (L <= 32 NT).  grid = (ceil(L / 32), heads, N), block = 64.
+// -------------------------------------------------------------------------------------------------------------
+template <int NT>
+static __global__ __launch_bounds__(64) void attention_fused_kernel(const float* __restrict__ qkv,
+                                                                    const uint8_t* __restrict__ mask,
+                                                                    float* __restrict__ ctx, int L, int H, float scale) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 32, head = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int64_t ld = 3 * (int64_t)H;
+    const float* base = qkv + n * L * ld + head * 64;
+    const uint8_t* mk = mask + n * L;
+    // B operand of the first product: Q[query q0 + i][32h + s]
+    float qreg[32];
+    {
+        const int qrow = q0 + i < L ? q0 + i : L - 1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(base + qrow * ld + 32 * h);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v = src[c];
+            qreg[4 * c] = v[0]; qreg[4 * c + 1] = v[1]; qreg[4 * c + 2] = v[2]; qreg[4 * c + 3] = v[3];
+        }
+    }
+    f32x16 st[NT];
+    uint32_t valid[NT];          // wave-uniform: bit j = key 32 jt + j takes part
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const int key = 32 * jt + i;
+        const int krow = key < L ? key : L - 1;
+        valid[jt] = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && mk[krow] != 0);
+        const f32x4* src = reinterpret_cast<const f32x4*>(base + H + krow * ld + 32 * h);
+        f32x4 kf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kf[c] = src[c];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s >> 2][s & 3], qreg[s], acc, 0, 0, 0);
+        st[jt] = acc;
+    }
+    // softmax over the keys of query i (this lane and its partner in the other half hold them all)
+    float mx = kNegInf;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = (valid[jt] >> kb) & 1u;
+            const float v = ok ? st[jt][r] * scale : kNegInf;
+            st[jt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = st[jt][r];
+            const float e = v > kNegInf ? expf(v - mx) : 0.f;
+            st[jt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    // O = P V
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    const float* vbase = base + 2 * H + i;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float* vrow = vbase + (int64_t)(key < L ? key : L - 1) * ld;
+            const float pr = st[jt][r] * inv;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr, vrow[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr, vrow[32], o1, 0, 0, 0);
+        }
+    // o[r] = O[query q0 + (r & 3) + 8 (r >> 2) + 4 h][d = i (+ 32)]
+    float* out = ctx + n * L * (int64_t)H + head * 64 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (q < L) {
+            out[(int64_t)q * H] = o0[r];
+            out[(int64_t)q * H + 32] = o1[r];
+        }
+    }
 }
 
 // (N*L, dim) row-major projection output -> the reference's (dim, L, N) column-major array is the same memory:

@@ -215,6 +215,12 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
                        int64_t intermediate, int64_t max_pos, int64_t type_vocab, int64_t dim, float ln_eps,
                        const float* weights, int64_t n_weights, clb_encoder** out);
 int clb_encoder_destroy(clb_encoder* e);
+/* Arithmetic of the Linear layers (the reference multiplies in Float32, checkpoint.jl:21-25 through Transformers.jl).
+ * Every fp32 operand is split into bf16 planes and the product is a sum of exact bf16 MFMA plane products in an
+ * fp32 accumulator: mode 2 (default) = "bf16x6": three planes (all 24 significant bits), six products, relative
+ * error per product < 2^-22; mode 1 = "bf16x3": two planes, three products, < 2^-15; mode 0 = fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate). */
+int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
 int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out);

@@ -118,12 +118,20 @@ def _state(bert, linear):
     return st
 
 
+# tolerance against the independent fp32 implementation: "f32" = fp32 MFMA GEMMs and "bf16x6" = six exact bf16 plane
+# products per fp32 product (differences are summation order / < 2^-22 per product); "bf16x3" = three plane products,
+# < 2^-15 relative error per product on top of that
+GEMM_TOL = {"f32": 2e-4, "bf16x6": 2e-4, "bf16x3": 6e-4}
+GEMM_TOL_BASE = {"f32": 1e-3, "bf16x6": 1e-3, "bf16x3": 6e-3}
+
+
 @pytest.mark.gpu
-def test_bert_forward_matches_fp32_reference():
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "bf16x3"])
+def test_bert_forward_matches_fp32_reference(gemm):
     torch, cfg, bert, linear = _random_bert()
     from colbert_jl_amd.encoder import pack_weights
     bcfg = cfg.to_dict()
-    enc = clb.BertEncoder(pack_weights(_state(bert, linear), bcfg, 32), bcfg, dim=32)
+    enc = clb.BertEncoder(pack_weights(_state(bert, linear), bcfg, 32), bcfg, dim=32, gemm=gemm)
     rng = np.random.default_rng(1)
     L, N = 37, 5
     ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
@@ -137,7 +145,8 @@ def test_bert_forward_matches_fp32_reference():
     got = enc.doc((ids0.T + 1).astype(np.int32), mask.T)                         # (dim, L, N), 1-based ids
     assert got.shape == (32, L, N)
     err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()                       # padded query rows are don't-care
-    assert err < 2e-4, err
+    assert err < GEMM_TOL[gemm], err
+    print(f"[encoder {gemm}] max |got - torch fp32| = {err:.3g}")
     # epilogues on top of the forward == the oracle's epilogue on the same forward output
     from oracle import oracle as orc
     skip = [5, 17, 33]
@@ -152,7 +161,42 @@ def test_bert_forward_matches_fp32_reference():
 
 
 @pytest.mark.gpu
-def test_bert_base_shape_and_export_roundtrip(tmp_path, tok):
+@pytest.mark.parametrize("L", [33, 100, 200, 300, 470])
+def test_fused_attention_long_sequences(L):
+    """Head size 64 takes the fused attention kernel (one wave per 32 queries, scores in registers); the key-tile count
+    is a template parameter, so every instantiation gets a ragged batch: against torch and against the unfused path."""
+    torch, cfg, bert, linear = _random_bert(hidden=128, layers=2, heads=2, inter=256, vocab=90, max_pos=512, dim=32, seed=L)
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    w = pack_weights(_state(bert, linear), bcfg, 32)
+    rng = np.random.default_rng(L)
+    N = 4
+    ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
+    lens = [L, max(1, L // 2), 1, L - 1]
+    mask = np.zeros((N, L), bool)
+    for n, l in enumerate(lens):
+        mask[n, :l] = True
+    with torch.no_grad():
+        ref = linear(bert(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state).numpy()
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f32")
+    got = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    enc.close()
+    err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()
+    print(f"[fused attention L={L}] max |got - torch fp32| = {err:.3g}")
+    assert err < 2e-4, err
+    os.environ["CLB_ENCODER_UNFUSED_ATTENTION"] = "1"
+    try:
+        enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f32")
+        unfused = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+        enc.close()
+    finally:
+        del os.environ["CLB_ENCODER_UNFUSED_ATTENTION"]
+    assert np.abs(got - unfused).transpose(2, 1, 0)[mask].max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "bf16x3"])
+def test_bert_base_shape_and_export_roundtrip(tmp_path, tok, gemm):
     """bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072), one short batch; weights through the export tool."""
     torch, cfg, bert, linear = _random_bert(hidden=768, layers=12, heads=12, inter=3072, vocab=len(VOCAB), max_pos=64, dim=128, seed=3)
     hf = tmp_path / "hf"; hf.mkdir()
@@ -164,7 +208,7 @@ def test_bert_base_shape_and_export_roundtrip(tmp_path, tok):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, os.path.join(root, "tools", "export_checkpoint.py"), str(hf), str(tmp_path / "exp")], check=True)
-    enc = clb.BertEncoder.from_export(str(tmp_path / "exp"), tokenizer=tok,
+    enc = clb.BertEncoder.from_export(str(tmp_path / "exp"), tokenizer=tok, gemm=gemm,
                                       config=clb.ColBERTConfig(doc_maxlen=24, query_maxlen=12, index_bsize=2))
     passages = ["hello world!", "this is a longer passage with many words.", "a test of the tokenizer"]
     embs, doclens = enc.encode_passages(passages)
@@ -177,7 +221,9 @@ def test_bert_base_shape_and_export_roundtrip(tmp_path, tok):
     assert np.array_equal(doclens, keep.sum(axis=0))
     flat = ref.transpose(0, 1, 2).reshape(-1, 128)[keep.T.ravel()]
     flat = flat / (np.linalg.norm(flat, axis=1, keepdims=True) + np.finfo(np.float32).eps)
-    assert np.abs(embs.T - flat).max() < 1e-3      # 12 layers of fp32 rounding in two different summation orders
+    err = np.abs(embs.T - flat).max()
+    print(f"[encoder {gemm}, bert-base geometry] max |got - torch fp32| = {err:.3g}")
+    assert err < GEMM_TOL_BASE[gemm], err     # 12 layers of fp32 rounding in two different summation orders (+ the split)
     Q = enc.encode_queries(["what is col bert", "hello"])
     assert Q.shape == (128, 12, 2) and np.allclose(np.linalg.norm(Q, axis=0), 1, atol=1e-5)
     enc.close()

@@ -23,14 +23,16 @@ def flops(cfg, L, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--gemm", default=None, help="bf16x6 (default), bf16x3 or f32")
     args = ap.parse_args()
     import torch
     import colbert_jl_amd as clb
     from colbert_jl_amd.encoder import BERT_BASE, random_weights
     cfg = dict(BERT_BASE)
-    enc = clb.BertEncoder(random_weights(cfg, 128, seed=1), cfg, dim=128)
+    enc = clb.BertEncoder(random_weights(cfg, 128, seed=1), cfg, dim=128, gemm=args.gemm)
+    out_gemm = enc.gemm
     rng = np.random.default_rng(2)
-    out = {}
+    out = {"gemm": out_gemm}
     for name, L, N in (("passages_64x300", 300, 64), ("queries_32x32", 32, 32), ("queries_64x32", 32, 64)):
         ids = rng.integers(1, cfg["vocab_size"] + 1, size=(L, N)).astype(np.int32)
         mask = np.ones((L, N), bool)
