@@ -55,7 +55,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=1_000_000)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="queries per step; 0 = 32 per GPU, at most 256 (the centroid stage is replicated on every shard and the "
+                         "selection kernels are one work-group per query: larger batches amortise both once the corpus is sharded)")
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--nprobe", type=int, default=2)
     ap.add_argument("--mode", type=int, default=-1, help="-1 library default, 0 exact, 1 two-pass")
@@ -116,7 +118,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- this rank's passage shard (generated directly, identical to the same passages of the full index)
-    T, B, k = 32, args.batch, args.k
+    T, B, k = 32, (args.batch if args.batch > 0 else min(32 * world, 256)), args.k
     n_blocks = 8
     assert n_blocks % world == 0, "shards are aligned to the 8 generation blocks: use 1, 2, 4 or 8 GPUs"
     per = n_blocks // world

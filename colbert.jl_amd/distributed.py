@@ -155,10 +155,23 @@ class DeviceSearch:
         self.out_s = self.packed[B * k * 8:B * k * 12].view(torch.float32).view(B, k)
         self.ncand = torch.zeros(B, dtype=torch.int64, device=self.dev)
 
+    def _check_queries(self, Qdev):
+        """The C ABI takes a bare pointer: a tensor with fewer than B x T x dim contiguous floats on this device would
+        be read past its end by the kernels, so it is refused here."""
+        import torch
+        from ._lib import ArgumentError
+        want = self.B * self.T * int(self.s.dim)
+        if (not isinstance(Qdev, torch.Tensor) or Qdev.dtype != torch.float32 or Qdev.device != self.dev
+                or not Qdev.is_contiguous() or Qdev.numel() != want):
+            raise ArgumentError(f"queries must be a contiguous float32 tensor of {self.B} x {self.T} x {int(self.s.dim)} "
+                                f"elements on {self.dev}, got {getattr(Qdev, 'dtype', type(Qdev))} "
+                                f"{tuple(getattr(Qdev, 'shape', ()))} on {getattr(Qdev, 'device', '?')}")
+
     def phase1(self, Qdev):
         """Two-phase sharded search, first half (clb_search_shard_phase1): everything up to pass 1 on this shard.
         Returns the (B, k) tensor of the shard's k largest approximate scores per query, to be all-gathered."""
         import torch
+        self._check_queries(Qdev)
         if not hasattr(self, "local_top"):
             self.local_top = torch.empty((self.B, self.k), dtype=torch.float32, device=self.dev)
         st = torch.cuda.current_stream(self.dev).cuda_stream
@@ -170,6 +183,11 @@ class DeviceSearch:
     def phase2(self, Qdev, all_top):
         """Second half (clb_search_shard_phase2).  all_top: (n_shards, B, k) gathered `local_top` blocks."""
         import torch
+        from ._lib import ArgumentError
+        self._check_queries(Qdev)
+        if (all_top.dtype != torch.float32 or all_top.dim() != 3 or tuple(all_top.shape[1:]) != (self.B, self.k)
+                or not all_top.is_contiguous() or all_top.device != self.dev):
+            raise ArgumentError(f"all_top must be a contiguous float32 (n_shards, {self.B}, {self.k}) tensor on {self.dev}")
         st = torch.cuda.current_stream(self.dev).cuda_stream
         check(lib().clb_search_shard_phase2(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
                                             i64(self.nprobe), i64(self.k), C.c_void_p(all_top.data_ptr()),
@@ -181,6 +199,7 @@ class DeviceSearch:
     def __call__(self, Qdev):
         """Qdev: torch float32 tensor holding B queries laid out (B, T, dim) contiguous == Julia (dim, T, B)."""
         import torch
+        self._check_queries(Qdev)
         st = torch.cuda.current_stream(self.dev).cuda_stream
         check(lib().clb_search_batch_device_slot(self.s._h, C.c_int(self.slot), C.c_void_p(Qdev.data_ptr()), i64(self.T),
                                                  i64(self.B), i64(self.nprobe), i64(self.k),

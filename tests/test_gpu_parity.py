@@ -341,6 +341,12 @@ def test_device_merge_kernel_matches_unsharded(oracle):
         sub, off = shard_index(idx, rnk, world)
         s = clb.Searcher(index=sub, pid_offset=off)
         run = DeviceSearch(s, 32, Qs.shape[2], k, 2)
+        if rnk == 0:        # the C ABI takes a bare pointer: a short, strided or mistyped tensor must never reach a kernel
+            for bad in (Qdev[:2], Qdev[:, :, ::2], Qdev.double(), Qdev.cpu()):
+                with pytest.raises(clb.ArgumentError):
+                    run(bad)
+                with pytest.raises(clb.ArgumentError):
+                    run.phase1(bad)
         p, sc = run(Qdev)
         torch.cuda.synchronize()
         gp.append(p.clone()); gs.append(sc.clone()); packed.append(run.packed.clone()); keep.append(s)

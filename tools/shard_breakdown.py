@@ -25,10 +25,10 @@ def main():
     K = synthetic.num_partitions_for(args.docs, 80.0)
     shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=8, blocks=range(0, per))
     s = clb.Searcher(index=shard, device=0, pid_offset=int(shard["pid_offset"]))
-    Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=256, T=T)
+    nb = 6                                                     # distinct batches
+    Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=max(256, nb * B), T=T)
     Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).cuda()
     run = DeviceSearch(s, T, B, k, 2)
-    nb = 6                                                     # distinct batches
     batches = [Qdev[i * B:(i + 1) * B] for i in range(nb)]
     tops = None
     if args.two_phase:
@@ -67,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     prof = s.profile_read()
     stats = s.last_batch_stats()
-    print(json.dumps({"world": args.world, "two_phase": bool(args.two_phase), "shard_passages": int(shard["doclens"].size), "ms_per_batch": round(dt * 1e3, 4),
+    print(json.dumps({"world": args.world, "batch": B, "two_phase": bool(args.two_phase), "shard_passages": int(shard["doclens"].size), "ms_per_batch": round(dt * 1e3, 4),
                       "queries_per_s_per_rank": round(B / dt, 1), "stats": stats,
                       "kernels_ms": {n: round(v["ms"] / max(v["launches"], 1), 4) for n, v in prof.items() if v["launches"]}}))
 
