@@ -365,7 +365,12 @@ def main():
         # sources they were measured on.  A summary taken on different sources is stale: traffic stays null.
         roof["traffic"] = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if world == 1 and os.path.exists(pmc_file):
+        # ... and on THIS workload (tools/gpu_profile.sh profiles the default one): bytes per launch do not transfer
+        default_workload = (args.docs == 1_000_000 and not args.uniform_codes and B == 32 and k == 1000
+                            and args.nprobe == 2 and args.mode < 0)
+        if world == 1 and not default_workload:
+            roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on the default workload, not this one"
+        elif world == 1 and os.path.exists(pmc_file):
             from tools.pmc_summary import csrc_hash
             pmc_all = json.load(open(pmc_file))
             pmc = pmc_all.get("kernels", {}).get(dom, {})
