@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--uniform-codes", action="store_true",
                     help="passages draw their centroid codes uniformly (worst case for the candidate count) instead of topically")
     ap.add_argument("--no-overlap", action="store_true", help="one compute stream: batches strictly one after the other")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight (compute streams / workspace slots), 1..4")
     ap.add_argument("--no-encoder", action="store_true",
                     help="skip the second measurement with the query encoder (bert-base geometry) in front of the search")
     ap.add_argument("--min-seconds", type=float, default=0.5,
@@ -141,23 +142,24 @@ def main():
     gather = world > 1 or args.force_gather
     # Two result buffers alternate so that the exchange of batch i (one RCCL all-gather of the packed per-shard
     # top-k + the merge kernel, on a side stream) overlaps the search of batch i+1 on the main stream.
-    # Two batches in flight: batch i runs on compute stream i & 1 with its own workspace slot and result buffers, so
+    # Two batches in flight: batch i runs on compute stream i % NF with its own workspace slot and result buffers, so
     # the latency-bound kernels of one batch (selection, top-k: one work-group per query) overlap the scoring kernels
     # of the other.  --no-overlap puts every batch on one stream.
-    runs = [DeviceSearch(s, T, B, k, args.nprobe, slot=i) for i in range(2)]
+    NF = max(1, min(4, args.in_flight))
+    runs = [DeviceSearch(s, T, B, k, args.nprobe, slot=i) for i in range(NF)]
     run = runs[0]
-    compute = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    compute = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     merged = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev))
-              for _ in range(2)]
+              for _ in range(NF)]
     comm = torch.cuda.Stream(device=dev) if gather else None
-    free_ev = [None, None]          # buffer set i may be overwritten once its exchange has finished
+    free_ev = [None] * NF          # buffer set i may be overwritten once its exchange has finished
     # With several shards the search runs in two phases around a second, small all-gather (every shard's k largest
     # approximate scores): all shards then cut at the GLOBAL k-th score and re-score ~k/N passages each instead of
     # ~k.  COLBERT_BENCH_TWO_PHASE=0/1 overrides.
     two_phase = gather and s.mode == 1 and (world >= 2 if "COLBERT_BENCH_TWO_PHASE" not in os.environ
                                             else os.environ["COLBERT_BENCH_TWO_PHASE"] == "1")
     import torch.distributed as _dist
-    gath = [torch.empty((max(world, 1) * B, k), dtype=torch.float32, device=dev) for _ in range(2)] if two_phase else None
+    gath = [torch.empty((max(world, 1) * B, k), dtype=torch.float32, device=dev) for _ in range(NF)] if two_phase else None
 
     def search_shard(r, Qb, i):
         """This rank's part of one batch on the main stream (results in r.packed)."""
@@ -170,36 +172,36 @@ def main():
         e1.record(main)
         with torch.cuda.stream(comm):
             comm.wait_event(e1)
-            _dist.all_gather_into_tensor(gath[i & 1], lt)
+            _dist.all_gather_into_tensor(gath[i % NF], lt)
             e2 = torch.cuda.Event()
             e2.record(comm)
         main.wait_event(e2)
-        r.phase2(Qb, gath[i & 1].view(world, B, k))
+        r.phase2(Qb, gath[i % NF].view(world, B, k))
 
     overlap = [not args.no_overlap]
 
     def step(i):
-        with torch.cuda.stream(compute[i & 1] if overlap[0] else compute[0]):
+        with torch.cuda.stream(compute[i % NF] if overlap[0] else compute[0]):
             return step_on_current_stream(i)
 
     def step_on_current_stream(i):
         off = (i * B) % (n_queries - B + 1)
-        r = runs[i & 1]
+        r = runs[i % NF]
         if not gather:
             return r(Qdev[off:off + B])
         main = torch.cuda.current_stream(dev)
-        if free_ev[i & 1] is not None:
-            main.wait_event(free_ev[i & 1])
+        if free_ev[i % NF] is not None:
+            main.wait_event(free_ev[i % NF])
         search_shard(r, Qdev[off:off + B], i)
         done = torch.cuda.Event()
         done.record(main)
         with torch.cuda.stream(comm):
             comm.wait_event(done)
             g = all_gather_packed(r.packed)
-            out = merge_packed(g, B, k, out_p=merged[i & 1][0], out_s=merged[i & 1][1])
+            out = merge_packed(g, B, k, out_p=merged[i % NF][0], out_s=merged[i % NF][1])
             ev = torch.cuda.Event()
             ev.record(comm)
-            free_ev[i & 1] = ev
+            free_ev[i % NF] = ev
         return out
 
     def barrier():
@@ -253,6 +255,32 @@ def main():
     s.profile_enable(False)
     overlap[0] = was
 
+    # ---- batches in flight do not disturb each other: one batch computed alone == the same batch computed in the middle
+    # of NF batches in flight on NF streams (every rank checks its own results)
+    def result_of(i):
+        out = step(i)
+        st = comm if gather else (compute[i % NF] if overlap[0] else compute[0])
+        with torch.cuda.stream(st):
+            return out[0].clone(), out[1].clone()
+    probe_i = args.warmup + 2 * NF + 1
+    was = overlap[0]
+    overlap[0] = False
+    barrier()
+    alone = result_of(probe_i)
+    barrier()
+    overlap[0] = was
+    for i in range(probe_i - NF, probe_i):
+        step(i)
+    busy = result_of(probe_i)
+    for i in range(probe_i + 1, probe_i + 1 + NF):
+        step(i)
+    barrier()
+    in_flight_ok = bool(torch.equal(alone[0], busy[0]) and torch.equal(alone[1], busy[1]))
+    if world > 1:
+        okt = torch.tensor([1 if in_flight_ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        in_flight_ok = bool(okt.item())
+
     # ---- the metric as the reference's search(::String) defines it (src/searching.jl:93-128): encode_queries first.
     # No checkpoint exists in the build image, so the encoder has bert-base-uncased GEOMETRY with random weights and
     # runs on synthetic token ids; random weights give meaningless embeddings that would change the candidate
@@ -268,16 +296,16 @@ def main():
         d_skip = torch.tensor([1], dtype=torch.int64, device=dev)
         q_enc = torch.empty((B, T, 128), dtype=torch.float32, device=dev)
 
-        q_encs = [q_enc, torch.empty_like(q_enc)]
+        q_encs = [q_enc] + [torch.empty_like(q_enc) for _ in range(NF - 1)]
         enc_done = [None]          # the encoder has ONE activation workspace: its calls are chained by an event
 
         def step_e2e(i):
             off = (i * B) % (n_queries - B + 1)
-            st = compute[i & 1] if overlap[0] else compute[0]
+            st = compute[i % NF] if overlap[0] else compute[0]
             with torch.cuda.stream(st):
                 if enc_done[0] is not None:
                     st.wait_event(enc_done[0])
-                enc.query_embeddings_device(d_ids[off:off + B], d_mask[off:off + B], d_skip, q_encs[i & 1])
+                enc.query_embeddings_device(d_ids[off:off + B], d_mask[off:off + B], d_skip, q_encs[i % NF])
                 ev = torch.cuda.Event()
                 ev.record(st)
                 enc_done[0] = ev
@@ -423,7 +451,7 @@ def main():
                                       f"passages sharded over {world} GPU(s)",
                           "search_mode": ("two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass")
                                          + (", global threshold exchange between the passes" if two_phase else "")},
-               "batches_in_flight": 2 if overlap[0] else 1,
+               "batches_in_flight": NF if overlap[0] else 1, "in_flight_matches_serial": in_flight_ok,
                "one_batch_at_a_time": {"value": round(B * args.steps / serial_s, 2), "ms_per_step": round(serial_s / args.steps * 1e3, 4)},
                "sustained": {"steps": sustained_steps, "seconds": round(sustained_s, 4),
                              "value": round(B * sustained_steps / sustained_s, 2),

@@ -67,6 +67,8 @@ struct Workspace {
     DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch;   // general-shape path (generic_kernels.hpp)
 };
 
+constexpr int kWorkspaceSlots = 4;
+
 struct clb_searcher {
     int device = 0;
     int64_t dim = 0, K = 0, n_docs = 0, n_emb = 0, pid_offset = 0;
@@ -91,7 +93,7 @@ struct clb_searcher {
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
-    Workspace ws[2];     // per-batch scratch, grown on demand (ensure_workspace); slot 1: a second batch in flight
+    Workspace ws[kWorkspaceSlots];   // per-batch scratch, grown on demand (ensure_workspace); slots 1..: further batches in flight
     Prof prof;
     int64_t last_cand_docs = 0, last_cand_embs = 0, last_resc_docs = 0, last_resc_embs = 0;
     int64_t index_bytes = 0;
@@ -783,7 +785,7 @@ int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, in
                                  int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                                  void* hip_stream) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
-    if (slot < 0 || slot > 1) return fail(CLB_EARGUMENT, "workspace slot must be 0 or 1");
+    if (slot < 0 || slot >= kWorkspaceSlots) return fail(CLB_EARGUMENT, "workspace slot must be 0..%d", kWorkspaceSlots - 1);
     CLB_TRY(use_device(s->device));
     hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
     Workspace& w = s->ws[slot];
@@ -795,10 +797,16 @@ int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, in
 
 int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
                             float* d_local_top, void* hip_stream) {
+    return clb_search_shard_phase1_slot(s, 0, d_Q, T, B, nprobe, k, d_local_top, hip_stream);
+}
+
+int clb_search_shard_phase1_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, float* d_local_top, void* hip_stream) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
     if (!d_local_top) return fail(CLB_EARGUMENT, "d_local_top is null");
+    if (slot < 0 || slot >= kWorkspaceSlots) return fail(CLB_EARGUMENT, "workspace slot must be 0..%d", kWorkspaceSlots - 1);
     CLB_TRY(use_device(s->device));
-    Workspace& w = s->ws[0];
+    Workspace& w = s->ws[slot];
     CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     w.pending.valid = false;
     CLB_TRY(run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, nullptr, nullptr, nullptr,
@@ -811,14 +819,22 @@ int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_
 int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
                             const float* d_all_top, int64_t n_shards, int64_t* d_out_pids, float* d_out_scores,
                             int64_t* d_n_cand, void* hip_stream) {
+    return clb_search_shard_phase2_slot(s, 0, d_Q, T, B, nprobe, k, d_all_top, n_shards, d_out_pids, d_out_scores, d_n_cand,
+                                        hip_stream);
+}
+
+int clb_search_shard_phase2_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, const float* d_all_top, int64_t n_shards, int64_t* d_out_pids,
+                                 float* d_out_scores, int64_t* d_n_cand, void* hip_stream) {
     CLB_TRY(check_search_args(s, T, B, nprobe, k));
     if (!d_all_top || n_shards < 1) return fail(CLB_EARGUMENT, "d_all_top is null or n_shards < 1");
+    if (slot < 0 || slot >= kWorkspaceSlots) return fail(CLB_EARGUMENT, "workspace slot must be 0..%d", kWorkspaceSlots - 1);
     CLB_TRY(use_device(s->device));
-    Workspace& w = s->ws[0];
+    Workspace& w = s->ws[slot];
     const auto& pd = w.pending;
     if (!pd.valid || pd.dQ != d_Q || pd.T != T || pd.B != B || pd.nprobe != nprobe || pd.k != k || pd.stream != hip_stream)
         return fail(CLB_EARGUMENT, "clb_search_shard_phase2 without a matching clb_search_shard_phase1 "
-                                   "(same queries, T, B, nprobe, k and stream, and no other search in between)");
+                                   "on this workspace slot (same queries, T, B, nprobe, k and stream, and no other search on the slot in between)");
     w.pending.valid = false;
     return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores,
                       d_n_cand, 2, nullptr, d_all_top, (int)n_shards);

@@ -175,7 +175,7 @@ class DeviceSearch:
         if not hasattr(self, "local_top"):
             self.local_top = torch.empty((self.B, self.k), dtype=torch.float32, device=self.dev)
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        check(lib().clb_search_shard_phase1(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
+        check(lib().clb_search_shard_phase1_slot(self.s._h, C.c_int(self.slot), C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
                                             i64(self.nprobe), i64(self.k), C.c_void_p(self.local_top.data_ptr()),
                                             C.c_void_p(st)))
         return self.local_top
@@ -189,7 +189,7 @@ class DeviceSearch:
                 or not all_top.is_contiguous() or all_top.device != self.dev):
             raise ArgumentError(f"all_top must be a contiguous float32 (n_shards, {self.B}, {self.k}) tensor on {self.dev}")
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        check(lib().clb_search_shard_phase2(self.s._h, C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
+        check(lib().clb_search_shard_phase2_slot(self.s._h, C.c_int(self.slot), C.c_void_p(Qdev.data_ptr()), i64(self.T), i64(self.B),
                                             i64(self.nprobe), i64(self.k), C.c_void_p(all_top.data_ptr()),
                                             i64(all_top.shape[0]), C.c_void_p(self.out_p.data_ptr()),
                                             C.c_void_p(self.out_s.data_ptr()), C.c_void_p(self.ncand.data_ptr()),

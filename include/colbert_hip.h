@@ -77,7 +77,7 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
 int clb_search_batch_device(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
                             int64_t k, int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand,
                             void* hip_stream);
-/* The same with an explicit workspace slot (0 or 1): two batches can be in flight on two streams of the caller, each
+/* The same with an explicit workspace slot (0..3): several batches can be in flight on streams of the caller, each
  * on its own per-batch scratch -- the latency-bound selection kernels of one batch then overlap the scoring kernels of
  * the other (bench.py).  Calls that use the same slot must be stream-ordered by the caller.  Every other entry point
  * uses slot 0. */
@@ -96,6 +96,13 @@ int clb_search_shard_phase1(clb_searcher* s, const float* d_Q, int64_t T, int64_
 int clb_search_shard_phase2(clb_searcher* s, const float* d_Q, int64_t T, int64_t B, int64_t nprobe, int64_t k,
                             const float* d_all_top, int64_t n_shards, int64_t* d_out_pids, float* d_out_scores,
                             int64_t* d_n_cand, void* hip_stream);
+/* The two phases on an explicit workspace slot (0..3), like clb_search_batch_device_slot: batches that are in flight on
+ * different streams of the caller MUST use different slots -- phase 2 continues on the scratch phase 1 left in its slot. */
+int clb_search_shard_phase1_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, float* d_local_top, void* hip_stream);
+int clb_search_shard_phase2_slot(clb_searcher* s, int slot, const float* d_Q, int64_t T, int64_t B, int64_t nprobe,
+                                 int64_t k, const float* d_all_top, int64_t n_shards, int64_t* d_out_pids,
+                                 float* d_out_scores, int64_t* d_n_cand, void* hip_stream);
 /* 0: exact single pass (every candidate scored with the canonical fp32 arithmetic);
  * 1: two-pass (bf16-MFMA approximate pass with a proven error bound selects a superset of the top-k,
  *    which is then re-scored exactly) -- results are identical by construction.  Default 1 when the

@@ -432,6 +432,40 @@ def test_two_phase_sharded_search(oracle, world, k):
         s.close()
 
 
+def test_two_phase_batches_in_flight_use_their_own_slot(oracle):
+    """Several batches of the two-phase search in flight on different streams (what bench.py does with more than one
+    rank): each continues on its own workspace slot -- phase 1 of the next batch must not disturb phase 2 of the
+    previous one -- and a phase 2 on the wrong slot is refused."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch
+    idx = synthetic.make_index(seed=2025, n_docs=6000, K=256)
+    Qs = synthetic.make_topic_queries(idx["centroids"], seed=79, n_queries=4 * 5)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    s = clb.Searcher(index=idx)
+    k, B, nslots = 100, 5, 4
+    runs = [DeviceSearch(s, 32, B, k, 2, slot=i) for i in range(nslots)]
+    streams = [torch.cuda.Stream() for _ in range(nslots)]
+    torch.cuda.synchronize()
+    tops = []
+    for i in range(nslots):                                   # all first halves, one per stream
+        with torch.cuda.stream(streams[i]):
+            tops.append(runs[i].phase1(Qdev[i * B:(i + 1) * B]).unsqueeze(0).contiguous())
+    with pytest.raises(clb.ArgumentError):                    # batch 1's second half on batch 0's slot
+        with torch.cuda.stream(streams[0]):
+            runs[0].phase2(Qdev[B:2 * B], tops[1])
+    for i in reversed(range(nslots)):                         # second halves in the opposite order
+        with torch.cuda.stream(streams[i]):
+            runs[i].phase2(Qdev[i * B:(i + 1) * B], tops[i])
+    torch.cuda.synchronize()
+    for i in range(nslots):
+        p = runs[i].out_p.cpu().numpy(); sc = runs[i].out_s.cpu().numpy()
+        for j in range(B):
+            rp, rs, _ = oracle.search(idx, Qs[:, :, i * B + j], 2, k)
+            assert np.array_equal(p[j], rp), (i, j)
+            assert_same_f32(sc[j], rs, "two-phase search on slot %d" % i)
+    s.close()
+
+
 def test_search_bounds_error_and_padding(oracle):
     idx = synthetic.make_index(seed=19, n_docs=300, K=64)
     Q = synthetic.make_queries(idx, 20, 1)
