@@ -888,13 +888,20 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         if (ROWS) {                                                                                         \
             const __half pmh = *reinterpret_cast<const __half*>(&PM);                                       \
             const float lo = r < T ? __half2float(pmh) - window : __builtin_inff();   /* tokens past T select nothing */ \
-            uint32_t bits = 0;                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                \
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(!(v[i] < lo));                   \
-                const int row0 = (i & 3) + 8 * (i >> 2);                                                    \
-                if ((uint32_t)bal) bits |= 1u << row0;                                                      \
-                if ((uint32_t)(bal >> 32)) bits |= 1u << (row0 + 4);                                        \
-            }                                                                                               \
+            /* per lane (token): bit i of lm = accumulator register i is inside the window; OR over the 32 tokens of */ \
+            /* each lane half with 4 DPP steps + 2 readlanes (16 wave-wide ballots cost ~130 scalar instructions per */ \
+            /* step, and a wave issues one instruction per ~5.7 cycles whatever its type)                            */ \
+            uint32_t lm = 0;                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) lm |= !(v[i] < lo) ? (1u << i) : 0u;             \
+            lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0xB1, 0xf, 0xf, true);    /* lane ^ 1 */     \
+            lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x4E, 0xf, 0xf, true);    /* lane ^ 2 */     \
+            lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x141, 0xf, 0xf, true);   /* row_half_mirror */ \
+            lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x140, 0xf, 0xf, true);   /* row_mirror */   \
+            const uint32_t m0_ = __builtin_amdgcn_readlane(lm, 0) | __builtin_amdgcn_readlane(lm, 16);      \
+            const uint32_t m1_ = __builtin_amdgcn_readlane(lm, 32) | __builtin_amdgcn_readlane(lm, 48);     \
+            /* register i of lane half h is row (i & 3) + 8 (i >> 2) + 4 h: spread the nibbles            */ \
+            uint32_t bits = ((m0_ & 0xFu) | ((m0_ & 0xF0u) << 4) | ((m0_ & 0xF00u) << 8) | ((m0_ & 0xF000u) << 12)) | \
+                            (((m1_ & 0xFu) | ((m1_ & 0xF0u) << 4) | ((m1_ & 0xF00u) << 8) | ((m1_ & 0xF000u) << 12)) << 4); \
             if (TAG.rows < kStepRows) bits &= (1u << TAG.rows) - 1u;   /* duplicates of the last row */     \
             const unsigned long long wbits = (unsigned long long)bits << (TAG.base & 32);                   \
             const int wi = TAG.base >> 6;                                                                   \
