@@ -302,16 +302,27 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
                                w.cells.as<float>(), w.cells_q.as<uint32_t>(), (int)s->K);
     }
+    static_assert(kScanBlock * kWordsPerThread == 1024, "mark_count_kernel writes 1024-word count blocks");
+    const int nslices = (w.nblk_bitmap + kMarkSliceBlocks - 1) / kMarkSliceBlocks;
+    // every slice re-reads the query's lists: beyond 16 slices (2 M passages per shard) the atomic path is cheaper; and
+    // for a few queries the 64 one-list work-groups of the atomic path finish sooner (one query: 8 us against 27)
+    const bool sliced = nslices <= 16 && B >= 8 && !CLB_KNOB("CLB_DEBUG_ATOMIC_MARK", 0);
     {
         Timed t(s, KID_MARK, st);
-        hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, w.sel.as<int>(),
-                           s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(), T,
-                           Tpad, NPs, nprobe, w.W);
+        if (sliced)     // mark + per-block counts, the bitmap slice of a work-group in LDS (no global atomics)
+            hipLaunchKernelGGL(mark_count_kernel, dim3(nslices, B), dim3(1024), 0, st, w.sel.as<int>(),
+                               s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(),
+                               w.blocksum.as<int>(), T, Tpad, NPs, nprobe, w.W, w.nblk_bitmap);
+        else
+            hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, w.sel.as<int>(),
+                               s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(), T,
+                               Tpad, NPs, nprobe, w.W);
     }
     {
         Timed t(s, KID_COMPACT, st);
-        hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
-                           w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.W);
+        if (!sliced)
+            hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
+                               w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.W);
         hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, w.blocksum.as<int>(),
                            w.ncand.as<int>(), w.nblk_bitmap);
         hipLaunchKernelGGL(bitmap_emit_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,

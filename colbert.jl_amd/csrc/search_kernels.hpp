@@ -305,9 +305,15 @@ static __global__ __launch_bounds__(256) void mark_candidates_kernel(const int* 
     const int t = blockIdx.x / nprobe, p = blockIdx.x % nprobe;
     const int* s = sel + (size_t)b * Tpad * NP;
     const int cid = s[t * NP + p];
-    // the same centroid selected by an earlier (token, rank): its list is already being marked
-    for (int e = 0; e < (int)blockIdx.x; ++e)
-        if (s[(e / nprobe) * NP + (e % nprobe)] == cid) return;
+    // the same centroid selected by an earlier (token, rank): its list is already being marked.  One entry per thread
+    // and a block-wide OR: the serial scan this replaces was a chain of up to T*nprobe dependent L2 round trips in
+    // every thread -- most of the kernel's time
+    bool dup = false;
+    for (int base = 0; base < (int)blockIdx.x; base += 256) {
+        const int e = base + (int)threadIdx.x;
+        if (e < (int)blockIdx.x && s[(e / nprobe) * NP + (e % nprobe)] == cid) dup = true;
+    }
+    if (__syncthreads_or(dup)) return;
     (void)T;
     uint32_t* bm = bitmap + (size_t)b * W;
     const uint32_t lo = ivf_off[cid], hi = ivf_off[cid + 1];
@@ -341,6 +347,73 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* sh /*>=8 int
     total = tot;
     __syncthreads();
     return base + x - v;
+}
+
+// mark + count in one kernel WITHOUT global atomics.  Device-scope atomics on the bitmap are served past the
+// (per-XCD, mutually incoherent) L2s: 1.25 M of them per 32-query batch cost 45 us -- the fabric request rate, not the
+// 4 us their bytes would suggest.  Here a work-group owns a SLICE of one query's bitmap (kMarkSliceBlocks count blocks
+// = 4096 words = 131 072 passages) in LDS, reads ALL selected IVF lists of the query (they stay in L2: 8 slices re-read
+// 156 KB each) and keeps the pids that fall into its slice, then stores the slice with plain stores and leaves the
+// per-block popcounts bitmap_scan_kernel wants.  Sixteen lists are in flight per round.
+// grid = (ceil(nblk / kMarkSliceBlocks), B), block = 1024.
+constexpr int kMarkSliceBlocks = 4;
+constexpr int kMarkSliceWords = kMarkSliceBlocks * kScanBlock * kWordsPerThread;   // 4096
+
+static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __restrict__ sel,
+                                                                 const uint32_t* __restrict__ ivf_off,
+                                                                 const uint32_t* __restrict__ ivf_pid,
+                                                                 uint32_t* __restrict__ bitmap,
+                                                                 int* __restrict__ blocksum, int T, int Tpad, int NP,
+                                                                 int nprobe, int W, int nblk) {
+    __shared__ uint32_t lbm[kMarkSliceWords];
+    __shared__ int cnt[kMarkSliceBlocks];
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < kMarkSliceWords; i += 1024) lbm[i] = 0u;
+    if (tid < kMarkSliceBlocks) cnt[tid] = 0;
+    __syncthreads();
+    const int* s = sel + (size_t)b * Tpad * NP;
+    const uint32_t p_lo = (uint32_t)slice * kMarkSliceWords * 32u, p_n = (uint32_t)kMarkSliceWords * 32u;
+    const int nl = T * nprobe;
+    for (int l0 = 0; l0 < nl; l0 += 16) {
+        uint32_t lo[16], hi[16], pid[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int l = l0 + u < nl ? l0 + u : nl - 1;            // past the end: the last list again (idempotent)
+            const int cid = s[(l / nprobe) * NP + (l % nprobe)];
+            lo[u] = ivf_off[cid];
+            hi[u] = ivf_off[cid + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t i = lo[u] + (uint32_t)tid;
+            pid[u] = i < hi[u] ? ivf_pid[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t q = pid[u] - p_lo;                       // 0xffffffff - p_lo >= p_n: never in range
+            if (q < p_n && pid[u] != 0xffffffffu) atomicOr(&lbm[q >> 5], 1u << (q & 31));
+            for (uint32_t i = lo[u] + (uint32_t)tid + 1024u; i < hi[u]; i += 1024u) {      // lists longer than 1024
+                const uint32_t q2 = ivf_pid[i] - p_lo;
+                if (q2 < p_n) atomicOr(&lbm[q2 >> 5], 1u << (q2 & 31));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* bm = bitmap + (size_t)b * W;
+    const int w0 = slice * kMarkSliceWords;
+#pragma unroll
+    for (int j = 0; j < kMarkSliceBlocks; ++j) {
+        const int wi = j * 1024 + tid;
+        const uint32_t word = lbm[wi];
+        if (w0 + wi < W) bm[w0 + wi] = word;
+        int c = __popc(word);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0 && c) atomicAdd(&cnt[j], c);
+    }
+    __syncthreads();
+    if (tid < kMarkSliceBlocks && slice * kMarkSliceBlocks + tid < nblk)
+        blocksum[(size_t)b * nblk + slice * kMarkSliceBlocks + tid] = cnt[tid];
 }
 
 // grid = (nblk, B)
