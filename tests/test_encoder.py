@@ -229,10 +229,16 @@ def test_bert_base_shape_and_export_roundtrip(tmp_path, tok, gemm):
     enc.close()
 
 
+# the four passages of the reference's examples/sample_collection.tsv (BASELINE config 1), as data
+SAMPLE_COLLECTION = ["hello world", "thank yo!", "a", "this is some longer text, so length should be longer"]
+
+
 @pytest.mark.gpu
-def test_text_to_search_end_to_end(tmp_path, tok):
-    """BASELINE config 1 in spirit (a handful of passages through Indexer + Searcher with a text query): the API
-    plumbing of examples/indexing.jl + examples/searching.jl with a randomly initialised encoder."""
+@pytest.mark.parametrize("which", ["synthetic", "sample_collection"])
+def test_text_to_search_end_to_end(tmp_path, tok, which):
+    """BASELINE config 1 (a handful of passages through Indexer + Searcher with a text query): the API plumbing of
+    examples/indexing.jl + examples/searching.jl with a randomly initialised encoder (no checkpoint is on disk) -- on
+    synthetic sentences and on the text of the reference's examples/sample_collection.tsv."""
     torch, cfg, bert, linear = _random_bert(hidden=64, layers=2, heads=4, inter=128, vocab=len(VOCAB), max_pos=64, dim=128, seed=5)
     from colbert_jl_amd.encoder import pack_weights
     from oracle import oracle as orc
@@ -243,12 +249,16 @@ def test_text_to_search_end_to_end(tmp_path, tok):
     words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with", "many", "words", "query", "colbert"]
     rng = np.random.default_rng(7)
     collection = [" ".join(rng.choice(words, size=rng.integers(4, 12))) + "." for _ in range(10)]
+    if which == "sample_collection":
+        collection = list(SAMPLE_COLLECTION)
+    n = len(collection)
     indexer = clb.Indexer(config, encoder=enc, collection=collection, seed=1)
     assert clb.index(indexer) == config.index_path
     searcher = clb.Searcher(config.index_path, encoder=enc)
     query = collection[3]
     pids, scores = clb.search(searcher, query, 3)
-    assert pids.shape == (3,) and np.all(np.diff(scores) <= 0) and np.all((pids >= 1) & (pids <= 10))
+    assert pids.shape == (3,) and np.all(np.diff(scores) <= 0) and np.all((pids >= 1) & (pids <= n))
+    assert pids[0] == 4            # the passage the query was copied from
     # same result as the oracle on the same query embeddings and index arrays
     from colbert_jl_amd import storage
     idx = storage.load_index(config.index_path)
@@ -256,5 +266,5 @@ def test_text_to_search_end_to_end(tmp_path, tok):
     rp, rs, _ = orc.search(idx, Q, config.nprobe, 3)
     assert np.array_equal(pids, rp) and np.array_equal(scores.view(np.uint32), rs.view(np.uint32))
     with pytest.raises(clb.BoundsError):
-        clb.search(searcher, query, 11)
+        clb.search(searcher, query, n + 1)
     searcher.close(); enc.close()
