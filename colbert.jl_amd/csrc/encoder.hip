@@ -154,7 +154,10 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             // softmax(Q K^T / sqrt(dh) + mask) V, one wave per (sequence, head, 32 queries), scores never leave registers
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt)
-            if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
+            static const int att = getenv("CLB_ENCODER_ATTENTION") ? atoi(getenv("CLB_ENCODER_ATTENTION")) : 0;   // 1: always register-resident
+            if (L > 64 && att != 1)
+                hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt);
+            else if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
             else if (L <= 256) CLB_ATT(8); else if (L <= 320) CLB_ATT(10); else if (L <= 384) CLB_ATT(12); else CLB_ATT(16);
 #undef CLB_ATT
         } else {

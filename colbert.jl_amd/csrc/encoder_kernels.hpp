@@ -578,6 +578,110 @@ static __global__ __launch_bounds__(64) void attention_fused_kernel(const float*
     }
 }
 
+// The same attention with a running (online) softmax for long sequences: the key tiles are visited one after the
+// other, only ONE 32 x 32 score tile lives in registers next to the 32 x 64 output accumulator, and whenever a query's
+// running maximum rises the output rows of that query are rescaled by exp(m_old - m_new).  ~130 registers instead of
+// 256+ (attention_fused_kernel keeps all NT tiles): three to four waves per SIMD cover each other's loads.  The
+// rescale factor of query q lives in lane q (transposed score layout) but scales accumulator REGISTERS (output rows):
+// it is fetched with v_readlane (two per register: the two lane halves hold different queries) and skipped for tiles
+// that raise no maximum (wave-uniform test).  Same arithmetic per product as the register-resident kernel; the softmax
+// differs from the two-pass form only by fp32 rounding (exp(a)exp(b) vs exp(a+b)).
+// grid = (ceil(L / 32), heads, N), block = 64.
+static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const float* __restrict__ qkv,
+                                                                        const uint8_t* __restrict__ mask,
+                                                                        float* __restrict__ ctx, int L, int H, float scale) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 32, head = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int64_t ld = 3 * (int64_t)H;
+    const float* base = qkv + n * L * ld + head * 64;
+    const uint8_t* mk = mask + n * L;
+    float qreg[32];
+    {
+        const int qrow = q0 + i < L ? q0 + i : L - 1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(base + qrow * ld + 32 * h);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v = src[c];
+            qreg[4 * c] = v[0]; qreg[4 * c + 1] = v[1]; qreg[4 * c + 2] = v[2]; qreg[4 * c + 3] = v[3];
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = kNegInf, l = 0.f;              // running maximum / sum of query i (l: this lane half's keys only)
+    const float* vbase = base + 2 * H + i;
+    const int nt = (L + 31) >> 5;
+    for (int jt = 0; jt < nt; ++jt) {
+        const int key = 32 * jt + i;
+        const int krow = key < L ? key : L - 1;
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && mk[krow] != 0);
+        if (valid == 0u) continue;                                   // a tile of masked keys (padding): nothing to add
+        const f32x4* src = reinterpret_cast<const f32x4*>(base + H + krow * ld + 32 * h);
+        f32x4 kf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kf[c] = src[c];
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s >> 2][s & 3], qreg[s], st, 0, 0, 0);
+        float tmax = kNegInf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = ((valid >> kb) & 1u) ? st[r] * scale : kNegInf;
+            st[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);                          // finite: the tile has a valid key
+        const float alpha = m > kNegInf ? expf(m - m_new) : 0.f;     // 1 when the maximum did not move
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = st[r] > kNegInf ? expf(st[r] - m_new) : 0.f;
+            st[r] = e;
+            psum += e;
+        }
+        l = l * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0ull) {       // some query's maximum rose: rescale its output row
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qa = (r & 3) + 8 * (r >> 2);               // the query of register r in lane half 0; +4 in half 1
+                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa));
+                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa + 4));
+                const float a = h ? a1 : a0;
+                o0[r] *= a;
+                o1[r] *= a;
+            }
+        }
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float* vrow = vbase + (int64_t)(kk < L ? kk : L - 1) * ld;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vrow[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vrow[32], o1, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float* out = ctx + n * L * (int64_t)H + head * 64 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qa = (r & 3) + 8 * (r >> 2);
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa));
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa + 4));
+        const float sc = h ? s1 : s0;
+        const int q = q0 + qa + 4 * h;
+        if (q < L) {
+            out[(int64_t)q * H] = o0[r] * sc;
+            out[(int64_t)q * H + 32] = o1[r] * sc;
+        }
+    }
+}
+
 // (N*L, dim) row-major projection output -> the reference's (dim, L, N) column-major array is the same memory:
 // element (d, l, n) at d + dim*(l + L*n) = row (l + L*n), column d.  So no transpose kernel is needed.
 
