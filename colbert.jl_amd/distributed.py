@@ -34,6 +34,67 @@ def packed_topk_bytes(k: int, B: int) -> int:
     return (B * k * 12 + 7) // 8 * 8
 
 
+class LibraryComm:
+    """The exchange step on the library's own RCCL communicator (clb_comm_*), for hosts without torch.distributed --
+    the same calls the Julia shim makes.  Rank 0 creates the unique id (`LibraryComm.unique_id()`) and hands its bytes to
+    the other ranks by any means; every rank then constructs `LibraryComm(device, rank, n_ranks, id_bytes)` (blocks until
+    all ranks have joined).  Tensors are torch CUDA tensors here only because the Python driver keeps its device memory
+    in torch; the entry points take bare device pointers."""
+
+    def __init__(self, device: int, rank: int, n_ranks: int, id_bytes: bytes):
+        self._h = C.c_void_p()
+        self.device, self.rank, self.n_ranks = device, rank, n_ranks
+        buf = C.create_string_buffer(bytes(id_bytes), len(id_bytes))
+        check(lib().clb_comm_create(C.c_int(device), C.c_int(rank), C.c_int(n_ranks), buf, i64(len(id_bytes)), C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        n = int(lib().clb_comm_unique_id_bytes())
+        buf = C.create_string_buffer(n)
+        check(lib().clb_comm_unique_id(buf, i64(n)))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().clb_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather(self, t):
+        """contiguous CUDA tensor -> (n_ranks, *t.shape) tensor of the same dtype, on torch's current stream"""
+        import torch
+        if not (t.is_cuda and t.is_contiguous() and t.device.index == self.device):
+            raise ValueError("all_gather needs a contiguous CUDA tensor on the communicator's device")
+        out = torch.empty((self.n_ranks,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        check(lib().clb_comm_all_gather(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()),
+                                        i64(t.numel() * t.element_size()), C.c_void_p(st)))
+        return out
+
+    def all_reduce_max_(self, t):
+        """in-place element-wise maximum of a contiguous float32 CUDA tensor over the ranks"""
+        import torch
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.device.index == self.device):
+            raise ValueError("all_reduce_max_ needs a contiguous float32 CUDA tensor on the communicator's device")
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        check(lib().clb_comm_all_reduce_max_f32(self._h, C.c_void_p(t.data_ptr()), i64(t.numel()), C.c_void_p(st)))
+        return t
+
+    def sync_bound_consts(self, searcher):
+        """one error bound on every shard (see sync_bound_consts below), over this communicator"""
+        import torch
+        t = torch.from_numpy(searcher.bound_consts.copy()).to(torch.device("cuda", self.device))
+        self.all_reduce_max_(t)
+        torch.cuda.current_stream(t.device).synchronize()
+        searcher.raise_bound_consts(t.cpu().numpy())
+        return searcher.bound_consts
+
+
 def all_gather_packed(packed, group=None):
     """ONE all-gather for a rank's whole result.  `packed`: the uint8 tensor of `packed_topk_bytes` bytes that
     DeviceSearch wrote its pids and scores into -> (world, nbytes) uint8 tensor on every rank."""

@@ -208,6 +208,28 @@ int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64
                   int64_t* ivf_lengths);
 
 /* ------------------------------------------------------------------------------------------------
+ * Exchange step of the sharded search / index build on RCCL  (the reference is single-GPU)
+ * One communicator per process and GPU.  Rank 0 calls clb_comm_unique_id and hands the bytes to the other ranks by
+ * whatever the host has (a file, MPI, a socket); every rank then calls clb_comm_create -- it blocks until all ranks
+ * have joined.  librccl is opened at run time; without it these calls return CLB_EHIP and nothing else is affected.
+ * The Python driver may use torch.distributed instead (the same RCCL underneath); hosts without torch -- the Julia
+ * shim -- use these.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct clb_comm clb_comm;
+int64_t clb_comm_unique_id_bytes(void);
+int clb_comm_unique_id(void* id, int64_t bytes);
+int clb_comm_create(int device, int rank, int n_ranks, const void* id, int64_t bytes, clb_comm** out);
+int clb_comm_destroy(clb_comm* c);
+int clb_comm_rank(const clb_comm* c);
+int clb_comm_size(const clb_comm* c);
+/* all-gather of `bytes_per_rank` bytes from every rank, in rank order, into d_recv (n_ranks * bytes_per_rank), enqueued
+ * on hip_stream: the packed per-shard top-k blocks (clb_packed_topk_bytes -> clb_merge_topk_packed_device), the (B, k)
+ * score blocks between clb_search_shard_phase1 and phase2, the cluster sums of clb_kmeans_shard_pass. */
+int clb_comm_all_gather(clb_comm* c, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* hip_stream);
+/* element-wise maximum over the ranks, in place (the six bound constants of clb_searcher_get/set_bound_consts) */
+int clb_comm_all_reduce_max_f32(clb_comm* c, float* d_buf, int64_t n, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Encoder  (src/modelling/checkpoint.jl)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct clb_encoder clb_encoder;

@@ -163,3 +163,40 @@ function _query_embeddings(ckpt::Checkpoint, skiplist::Vector{Int}, integer_ids:
     out
 end
 
+
+# ---- exchange step of a sharded search / index build on RCCL (clb_comm_*; SURVEY.md 8(e)) -------------------------
+# One `Communicator` per Julia process and GPU.  Rank 0 calls `comm_unique_id()` and hands the bytes to the other
+# ranks (a file, MPI.jl, a socket); every rank then constructs `Communicator(device, rank, n_ranks, id)`.
+# The device pointers these calls take are the ones the sharded search entry points produce (clb_search_shard_phase1,
+# clb_packed_topk_bytes / clb_merge_topk_packed_device): a host that keeps its device buffers in AMDGPU.jl arrays
+# passes their pointers.
+"the bytes rank 0 creates and every rank passes to `Communicator`"
+function comm_unique_id()
+    n = ccall((:clb_comm_unique_id_bytes, libcolbert), Int64, ())
+    id = Vector{UInt8}(undef, n)
+    GC.@preserve id _check(ccall((:clb_comm_unique_id, libcolbert), Cint, (Ptr{UInt8}, Int64), id, n))
+    id
+end
+
+mutable struct Communicator
+    handle::Ptr{Cvoid}
+    rank::Int
+    n_ranks::Int
+    function Communicator(device::Integer, rank::Integer, n_ranks::Integer, id::Vector{UInt8})
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve id _check(ccall((:clb_comm_create, libcolbert), Cint,
+            (Cint, Cint, Cint, Ptr{UInt8}, Int64, Ref{Ptr{Cvoid}}), device, rank, n_ranks, id, length(id), h))
+        c = new(h[], rank, n_ranks)
+        finalizer(c -> ccall((:clb_comm_destroy, libcolbert), Cint, (Ptr{Cvoid},), c.handle), c)
+    end
+end
+
+"all-gather of `bytes_per_rank` bytes per rank (device pointers), enqueued on `stream`"
+comm_all_gather(c::Communicator, d_send::Ptr{Cvoid}, d_recv::Ptr{Cvoid}, bytes_per_rank::Integer, stream::Ptr{Cvoid} = C_NULL) =
+    _check(ccall((:clb_comm_all_gather, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        c.handle, d_send, d_recv, bytes_per_rank, stream))
+
+"in-place element-wise maximum over the ranks of `n` Float32 at a device pointer (the bound constants of the two-phase search)"
+comm_all_reduce_max!(c::Communicator, d_buf::Ptr{Cvoid}, n::Integer, stream::Ptr{Cvoid} = C_NULL) =
+    _check(ccall((:clb_comm_all_reduce_max_f32, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        c.handle, d_buf, n, stream))

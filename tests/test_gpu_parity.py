@@ -466,6 +466,39 @@ def test_two_phase_batches_in_flight_use_their_own_slot(oracle):
     s.close()
 
 
+def test_library_rccl_communicator_single_rank(oracle):
+    """clb_comm_* (the exchange step on RCCL inside the library, for hosts without torch.distributed) with one rank: the
+    packed top-k all-gather + merge and the bound-constant all-reduce reproduce the unsharded result.  More ranks need
+    more GPUs than this box has; the entry points are the same."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch, LibraryComm, merge_packed
+    idx = synthetic.make_index(seed=41, n_docs=3000, K=256)
+    Qs = synthetic.make_queries(idx, 42, 4)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    uid = LibraryComm.unique_id()
+    assert len(uid) == 128
+    comm = LibraryComm(0, 0, 1, uid)
+    s = clb.Searcher(index=idx)
+    before = s.bound_consts.copy()
+    assert np.array_equal(comm.sync_bound_consts(s), before)
+    k = 64
+    run = DeviceSearch(s, 32, 4, k, 2)
+    tops = comm.all_gather(run.phase1(Qdev))                     # (1, B, k)
+    run.phase2(Qdev, tops)
+    gathered = comm.all_gather(run.packed)                       # (1, packed bytes)
+    mp, ms = merge_packed(gathered, 4, k)
+    torch.cuda.synchronize()
+    for j in range(4):
+        rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
+        assert np.array_equal(mp[j].cpu().numpy(), rp)
+        assert_same_f32(ms[j].cpu().numpy(), rs, "library communicator")
+    x = torch.arange(6, dtype=torch.float32, device="cuda")
+    assert torch.equal(comm.all_reduce_max_(x.clone()), x)
+    with pytest.raises(clb.ArgumentError):
+        LibraryComm(0, 1, 1, uid)                                # rank out of range
+    comm.close(); s.close()
+
+
 def test_search_bounds_error_and_padding(oracle):
     idx = synthetic.make_index(seed=19, n_docs=300, K=64)
     Q = synthetic.make_queries(idx, 20, 1)

@@ -28,12 +28,13 @@ def bench_id(name: str):
 
 
 def csrc_hash() -> str:
-    """sha256 over the kernel sources: a PMC summary is only valid for the sources it was measured on."""
+    """sha256 over the sources of the search kernels (search.hip and everything it includes): a PMC summary is only
+    valid for the sources it was measured on.  The encoder / codec / communicator files do not enter."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "colbert.jl_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("approx_kernels.hpp", "codec_kernels.hpp", "common.hpp", "generic_kernels.hpp", "search.hip", "search_kernels.hpp",
+              "sort.hpp"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
