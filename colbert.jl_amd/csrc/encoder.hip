@@ -15,7 +15,8 @@ struct clb_encoder {
     float eps = 1e-12f;
     hipStream_t stream = nullptr;
     DevBuf weights;
-    bool fused_attention = true;   // CLB_ENCODER_UNFUSED_ATTENTION=1: the three-kernel path (comparison / head sizes != 64)
+    int attention_mode = 0;     // 0 = fused (register-resident up to 64 keys, online softmax beyond), 1 = register-resident
+                                // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64)
     int gemm_mode = 2;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6 (bf16 MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
@@ -125,7 +126,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     const float* W = e->weights.as<float>();
     CLB_TRY(e->x.ensure(sizeof(float) * T * H));
     CLB_TRY(e->qkv.ensure(sizeof(float) * T * 3 * H));
-    const bool fused = dh == 64 && L <= 512 && e->fused_attention;
+    const bool fused = dh == 64 && L <= 512 && e->attention_mode != 2;
     if (!fused) CLB_TRY(e->scores.ensure(sizeof(float) * N * heads * L * L));
     CLB_TRY(e->ctx.ensure(sizeof(float) * T * H));
     CLB_TRY(e->hbuf.ensure(sizeof(float) * T * I));
@@ -150,12 +151,11 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         const float* P = W + e->o_layer0 + l * e->layer_stride;
         // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
         linear(e, st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr);
-        if (dh == 64 && L <= 512 && e->fused_attention) {
+        if (fused) {
             // softmax(Q K^T / sqrt(dh) + mask) V, one wave per (sequence, head, 32 queries), scores never leave registers
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt)
-            static const int att = getenv("CLB_ENCODER_ATTENTION") ? atoi(getenv("CLB_ENCODER_ATTENTION")) : 0;   // 1: always register-resident
-            if (L > 64 && att != 1)
+            if (L > 64 && e->attention_mode != 1)
                 hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt);
             else if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
             else if (L <= 256) CLB_ATT(8); else if (L <= 320) CLB_ATT(10); else if (L <= 384) CLB_ATT(12); else CLB_ATT(16);
@@ -216,7 +216,6 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
     clb_encoder* e = new clb_encoder();
     e->device = device; e->vocab = vocab; e->H = hidden; e->layers = layers; e->heads = heads; e->I = intermediate;
     e->max_pos = max_pos; e->type_vocab = type_vocab; e->dim = dim; e->eps = ln_eps;
-    e->fused_attention = !(getenv("CLB_ENCODER_UNFUSED_ATTENTION") && atoi(getenv("CLB_ENCODER_UNFUSED_ATTENTION")));
     if (expected_weights(e) != n_weights) {
         const long long want = (long long)expected_weights(e);
         delete e;
@@ -270,6 +269,13 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     if (mode < 0 || mode > 2) return fail(CLB_EARGUMENT, "gemm mode %d: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6", mode);
     e->gemm_mode = mode;
+    return CLB_OK;
+}
+
+int clb_encoder_set_attention_mode(clb_encoder* e, int mode) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (mode < 0 || mode > 2) return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels", mode);
+    e->attention_mode = mode;
     return CLB_OK;
 }
 

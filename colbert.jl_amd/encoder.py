@@ -67,7 +67,8 @@ def random_weights(bert_cfg: dict, dim: int = 128, seed: int = 0) -> np.ndarray:
 
 class BertEncoder:
     def __init__(self, weights: np.ndarray, bert_cfg: dict, dim: int = 128, device: int = 0,
-                 tokenizer=None, config: Optional[ColBERTConfig] = None, gemm: Optional[str] = None):
+                 tokenizer=None, config: Optional[ColBERTConfig] = None, gemm: Optional[str] = None,
+                 attention: str = "fused"):
         """`gemm`: arithmetic of the Linear layers -- "bf16x6" (default: fp32 operands split into three bf16 planes, six
         exact bf16 MFMA products per fp32 product, fp32 accumulation: fp32-faithful), "bf16x3" (two planes, three
         products, ~16 significant bits) or "f32" (fp32 MFMA); COLBERT_ENCODER_GEMM sets the default."""
@@ -87,6 +88,10 @@ class BertEncoder:
         if self.gemm not in modes:
             raise ValueError(f"gemm must be one of {sorted(modes)}, not {self.gemm!r}")
         check(lib().clb_encoder_set_gemm_mode(self._h, modes[self.gemm]))
+        amodes = {"fused": 0, "resident": 1, "unfused": 2}     # 1 and 2: comparison paths (clb_encoder_set_attention_mode)
+        if attention not in amodes:
+            raise ValueError(f"attention must be one of {sorted(amodes)}, not {attention!r}")
+        check(lib().clb_encoder_set_attention_mode(self._h, amodes[attention]))
 
     @classmethod
     def from_export(cls, path: str, **kw) -> "BertEncoder":

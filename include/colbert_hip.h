@@ -250,6 +250,10 @@ int clb_encoder_destroy(clb_encoder* e);
  * error per product < 2^-22; mode 1 = "bf16x3": two planes, three products, < 2^-15; mode 0 = fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate). */
 int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
+/* Self-attention for head size 64 and up to 512 positions: mode 0 (default) = fused in registers (all score tiles
+ * resident up to 64 keys, online softmax beyond), 1 = register-resident for every length, 2 = the three-kernel path
+ * (scores in memory; always taken for other head sizes) -- 1 and 2 exist for comparison. */
+int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
 int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out);

@@ -184,14 +184,11 @@ def test_fused_attention_long_sequences(L):
     err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()
     print(f"[fused attention L={L}] max |got - torch fp32| = {err:.3g}")
     assert err < 2e-4, err
-    os.environ["CLB_ENCODER_UNFUSED_ATTENTION"] = "1"
-    try:
-        enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f32")
-        unfused = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    for other in ("unfused", "resident"):
+        enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f32", attention=other)
+        alt = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
         enc.close()
-    finally:
-        del os.environ["CLB_ENCODER_UNFUSED_ATTENTION"]
-    assert np.abs(got - unfused).transpose(2, 1, 0)[mask].max() < 1e-4
+        assert np.abs(got - alt).transpose(2, 1, 0)[mask].max() < 1e-4, other
 
 
 @pytest.mark.gpu

@@ -24,12 +24,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--gemm", default=None, help="bf16x6 (default), bf16x3 or f32")
+    ap.add_argument("--attention", default="fused", help="fused (default), resident or unfused")
     args = ap.parse_args()
     import torch
     import colbert_jl_amd as clb
     from colbert_jl_amd.encoder import BERT_BASE, random_weights
     cfg = dict(BERT_BASE)
-    enc = clb.BertEncoder(random_weights(cfg, 128, seed=1), cfg, dim=128, gemm=args.gemm)
+    enc = clb.BertEncoder(random_weights(cfg, 128, seed=1), cfg, dim=128, gemm=args.gemm, attention=args.attention)
     out_gemm = enc.gemm
     rng = np.random.default_rng(2)
     out = {"gemm": out_gemm}
