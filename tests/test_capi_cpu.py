@@ -25,6 +25,15 @@ def test_no_cpu_fallback():
     idx = clb.synthetic.make_index(0, 20, K=8)
     with pytest.raises(clb.HipError):
         clb.Searcher(index=idx)
+    # the library's RCCL communicator: argument checks first, then the device (no GPU: HipError, nothing opened)
+    from colbert_jl_amd.distributed import LibraryComm
+    assert int(clb.lib().clb_comm_unique_id_bytes()) == 128
+    with pytest.raises(clb.ArgumentError):
+        LibraryComm(0, 3, 2, bytes(128))          # rank outside 0..n_ranks-1
+    with pytest.raises(clb.ArgumentError):
+        LibraryComm(0, 0, 1, bytes(16))           # not a unique id
+    with pytest.raises(clb.HipError):
+        LibraryComm(0, 0, 1, bytes(128))
 
 
 def test_product_package_never_imports_the_oracle():
