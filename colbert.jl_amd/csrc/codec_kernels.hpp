@@ -408,7 +408,7 @@ static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, in
 
 // -------------------------------------------------------------------------------------------------------------
 // Index build: exact nearest centroid of every point from the group lists centroid_top_bf16x3_mq_kernel<false, BIAS>
-// wrote with gx = 1 (partial: [ceil(n/32)][2 halves][32][kTopPartial]).  MODE 0: argmax of the canonical dot
+// wrote with gx = 1 (partial: [ceil(n/32)][32 points][2 halves][kTopPartial]).  MODE 0: argmax of the canonical dot
 // product, first index on ties (compress_into_codes!, residual.jl:67-81).  MODE 1: argmin of
 // fl(fl(-2 dot + ||c||^2) + ||x||^2), first index on ties (assign_clusters of kmeans_gpu_onehot!, utils.jl:38-79).
 // With w(c) = x.c - ||c||^2/2 the k-means distance is -2 w + ||x||^2 up to its own rounding (<= delta), and the
@@ -439,8 +439,8 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
     const float x2 = MODE == 1 ? sumsq_canonical(x, kDim) : 0.f;
     const int64_t b = pp >> 5;
     const int i = (int)(pp & 31);
-    const ValIdx* l0 = partial + ((size_t)(b * 2 + 0) * 32 + i) * kTopPartial;
-    const ValIdx* l1 = partial + ((size_t)(b * 2 + 1) * 32 + i) * kTopPartial;
+    const ValIdx* l0 = partial + (((size_t)b * 32 + i) * 2 + 0) * kTopPartial;     // [group of 32 points][point][slot][entry]
+    const ValIdx* l1 = partial + (((size_t)b * 32 + i) * 2 + 1) * kTopPartial;
     ValIdx ent[2 * kTopPartial];
 #pragma unroll
     for (int e = 0; e < kTopPartial; ++e) { ent[e] = l0[e]; ent[kTopPartial + e] = l1[e]; }
