@@ -25,7 +25,7 @@ FILL = {
 }
 
 
-def body(n_mfma, gap, tail=(), acc="acc"):
+def body(n_mfma, gap, tail=(), acc="acc", mfma="bf16"):
     """n_mfma MFMAs, each followed by the filler list `gap` ([(kind, count)]); then `tail` fillers."""
     out = []
     ctr = {}
@@ -35,7 +35,12 @@ def body(n_mfma, gap, tail=(), acc="acc"):
             ctr[kind] = i + 1
             out.append(FILL[kind](i))
     for _ in range(n_mfma):
-        out.append(f"v_mfma_f32_32x32x16_bf16 %[{acc}], %[a], %[b], %[{acc}]\\n")
+        if mfma == "bf16":
+            out.append(f"v_mfma_f32_32x32x16_bf16 %[{acc}], %[a], %[b], %[{acc}]\\n")
+        elif mfma == "f32_16":      # the exact scorer's MFMA: two alternating accumulators as in score_exact_flat_kernel
+            out.append(f"v_mfma_f32_16x16x4_f32 %[c{_ % 2}], %[kf], %[kf], %[c{_ % 2}]\\n")
+        else:                        # f32_32: the fp32 GEMM's MFMA
+            out.append(f"v_mfma_f32_32x32x2_f32 %[{acc}], %[kf], %[kf], %[{acc}]\\n")
         for kind, count in gap:
             emit(kind, count)
     for kind, count in tail:
@@ -73,6 +78,16 @@ VARIANTS = [
     ("mfma10 + 5 salu/gap", NM, [("salu", 5)], [], False),
     ("mfma10 + 4 add + 2 lds64 + 4 salu /gap", NM, [("add", 4), ("lds64", 2), ("salu", 4)], [], False),
     ("mfma10 + 6 add + 2 lds64 + 5 salu /gap", NM, [("add", 6), ("lds64", 2), ("salu", 5)], [], False),
+    # the fp32-input MFMAs (exact scorer: 16x16x4, two alternating accumulators; fp32 GEMM: 32x32x2)
+    ("f32 16x16x4 x20", 20, [], [], False, "f32_16"),
+    ("f32 16x16x4 x20 + 3 add/gap", 20, [("add", 3)], [], False, "f32_16"),
+    ("f32 16x16x4 x20 + 6 add/gap", 20, [("add", 6)], [], False, "f32_16"),
+    ("f32 16x16x4 x20 + 8 add/gap", 20, [("add", 8)], [], False, "f32_16"),
+    ("f32 16x16x4 x20 + 4 fma + 1 lds64 /gap", 20, [("fma", 4), ("lds64", 1)], [], False, "f32_16"),
+    ("add120 only", 0, [], [("add", 120)], False),
+    ("f32 32x32x2 x10", NM, [], [], False, "f32_32"),
+    ("f32 32x32x2 x10 + 6 add/gap", NM, [("add", 6)], [], False, "f32_32"),
+    ("f32 32x32x2 x10 + 12 add/gap", NM, [("add", 12)], [], False, "f32_32"),
 ]
 
 # two-role kernels: waves 0..3 of a work-group run role A, the others role B (one role-A wave per SIMD)
@@ -80,6 +95,7 @@ ROLES = [
     ("A: mfma10 | B: add60", (NM, [], []), (0, [], [("add", 60)])),
     ("A: mfma10 | B: perm40 + lds64x16 + salu30", (NM, [], []), (0, [], [("perm", 40), ("lds64", 16), ("salu", 30)])),
     ("A: mfma10 | B: mfma10", (NM, [], []), (NM, [], [])),
+    ("A: f32 16x16x4 x20 | B: add120", (20, [], [], "acc", "f32_16"), (0, [], [("add", 120)])),
 ]
 
 HEADER = r'''// GENERATED by gen_issue_overlap.py -- do not edit.  See that file for the purpose.
@@ -93,15 +109,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Regs {
-    bf16x8 a, b; f32x16 acc; uint32_t v[8]; f32x2 p[4]; u32x2 d[8]; u32x4 q[4]; uint32_t s[4];
+    bf16x8 a, b; f32x16 acc; f32x4 c[2]; uint32_t v[8]; f32x2 p[4]; u32x2 d[8]; u32x4 q[4]; uint32_t s[4];
     uint32_t k, sel, addr; float kf; f32x2 pk;
 };
 __device__ __forceinline__ void init(Regs& R, const void* lds) {
     const int lane = threadIdx.x & 63;
     for (int j = 0; j < 8; ++j) { R.a[j] = (__bf16)(0.01f * ((lane * 7 + j) % 13)); R.b[j] = (__bf16)(0.02f * ((lane * 5 - j) % 11)); }
     for (int j = 0; j < 16; ++j) R.acc[j] = 0.f;
+    for (int j = 0; j < 4; ++j) { R.c[0][j] = 0.f; R.c[1][j] = 0.f; }
     for (int j = 0; j < 8; ++j) { R.v[j] = lane * 3 + j; R.d[j] = u32x2{0u, 0u}; }
     for (int j = 0; j < 4; ++j) { R.p[j] = f32x2{1.f + lane, 2.f}; R.q[j] = u32x4{0u, 0u, 0u, 0u}; R.s[j] = j; }
     R.k = 0x01020304u + lane; R.sel = 0x07020500u; R.kf = 1.0001f; R.pk = f32x2{1.0001f, 0.9999f};
@@ -110,12 +128,13 @@ __device__ __forceinline__ void init(Regs& R, const void* lds) {
 __device__ __forceinline__ float fold(const Regs& R) {
     float s = 0.f;
     for (int j = 0; j < 16; ++j) s += R.acc[j];
+    for (int j = 0; j < 4; ++j) s += R.c[0][j] + R.c[1][j];
     for (int j = 0; j < 8; ++j) s += (float)R.v[j] + (float)R.d[j][0] + (float)R.d[j][1];
     for (int j = 0; j < 4; ++j) s += R.p[j][0] + R.p[j][1] + (float)R.q[j][0] + (float)R.q[j][3] + (float)R.s[j];
     return s;
 }
 #define OPERANDS(ACC)                                                                                          \
-    : [acc] ACC(R.acc), [v0] "+v"(R.v[0]), [v1] "+v"(R.v[1]), [v2] "+v"(R.v[2]), [v3] "+v"(R.v[3]),             \
+    : [acc] ACC(R.acc), [c0] "+v"(R.c[0]), [c1] "+v"(R.c[1]), [v0] "+v"(R.v[0]), [v1] "+v"(R.v[1]), [v2] "+v"(R.v[2]), [v3] "+v"(R.v[3]),             \
       [v4] "+v"(R.v[4]), [v5] "+v"(R.v[5]), [v6] "+v"(R.v[6]), [v7] "+v"(R.v[7]),                               \
       [p0] "+v"(R.p[0]), [p1] "+v"(R.p[1]), [p2] "+v"(R.p[2]), [p3] "+v"(R.p[3]),                               \
       [d0] "+v"(R.d[0]), [d1] "+v"(R.d[1]), [d2] "+v"(R.d[2]), [d3] "+v"(R.d[3]),                               \
@@ -137,7 +156,7 @@ __device__ __forceinline__ void finish(const Regs& R, float* out, long long* cyc
 '''
 
 
-def kernel(idx, n_mfma, gap, tail, agpr):
+def kernel(idx, n_mfma, gap, tail, agpr, mfma="bf16"):
     acc = '"+a"' if agpr else '"+v"'
     return f'''
 __global__ __launch_bounds__(768) void k{idx}(float* out, long long* cyc, int iters) {{
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(768) void k{idx}(float* out, long long* cyc, int it
     const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {{
         asm volatile(
-{body(n_mfma, gap, tail)}            OPERANDS({acc}));
+{body(n_mfma, gap, tail, mfma=mfma)}            OPERANDS({acc}));
     }}
     finish(R, out, cyc, t0, r0);
 }}
@@ -214,12 +233,13 @@ int main() {
 
 def main():
     print(HEADER)
-    for i, (name, n, gap, tail, agpr) in enumerate(VARIANTS):
-        print(kernel(i, n, gap, tail, agpr))
+    for i, v in enumerate(VARIANTS):
+        print(kernel(i, *v[1:]))
     for i, (name, ra, rb) in enumerate(ROLES):
         print(role_kernel(i, ra, rb))
     print(MAIN_HEAD)
-    for i, (name, n, gap, tail, agpr) in enumerate(VARIANTS):
+    for i, v in enumerate(VARIANTS):
+        name = v[0]
         for w in (1, 2, 3):
             print(f'    time_kernel("{name}", {w}, [](int b, int t, float* o, long long* c, int it) {{ hipLaunchKernelGGL(k{i}, dim3(b), dim3(t), 0, 0, o, c, it); }});')
     for i, (name, ra, rb) in enumerate(ROLES):
