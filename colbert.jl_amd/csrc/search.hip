@@ -323,11 +323,9 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         if (!sliced)
             hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
                                w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.W);
-        hipLaunchKernelGGL(bitmap_scan_kernel, dim3(B), dim3(kScanBlock), 0, st, w.blocksum.as<int>(),
-                           w.ncand.as<int>(), w.nblk_bitmap);
         hipLaunchKernelGGL(bitmap_emit_kernel, dim3(w.nblk_bitmap, B), dim3(kScanBlock), 0, st,
                            w.bitmap.as<uint32_t>(), w.blocksum.as<int>(), w.cand.as<uint32_t>(),
-                           s->doc_off.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.W, w.cand_cap);
+                           s->doc_off.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.W, w.cand_cap, w.ncand.as<int>());
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
@@ -406,10 +404,9 @@ int run_retrieve_general(clb_searcher* s, Workspace& w, hipStream_t st, const fl
     hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, 1), dim3(256), 0, st, sel_b, s->ivf_off.as<uint32_t>(),
                        s->ivf_pid.as<uint32_t>(), bm, T, T, nprobe, nprobe, w.W);
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(w.nblk_bitmap, 1), dim3(kScanBlock), 0, st, bm, bs, w.W);
-    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(kScanBlock), 0, st, bs, w.ncand.as<int>() + b, w.nblk_bitmap);
     hipLaunchKernelGGL(bitmap_emit_kernel, dim3(w.nblk_bitmap, 1), dim3(kScanBlock), 0, st, bm, bs,
                        w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, s->doc_off.as<uint32_t>(),
-                       w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap, w.W, w.cand_cap);
+                       w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap, w.W, w.cand_cap, w.ncand.as<int>() + b);
     CLB_HIP(hipGetLastError());
     return CLB_OK;
 }

@@ -354,9 +354,10 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* sh /*>=8 int
 // 4 us their bytes would suggest.  Here a work-group owns a SLICE of one query's bitmap (kMarkSliceBlocks count blocks
 // = 4096 words = 131 072 passages) in LDS, reads ALL selected IVF lists of the query (they stay in L2: 8 slices re-read
 // 156 KB each) and keeps the pids that fall into its slice, then stores the slice with plain stores and leaves the
-// per-block popcounts bitmap_scan_kernel wants.  Sixteen lists are in flight per round.
+// per-block popcounts the emit kernel wants.  kMarkLists lists are in flight per round.
 // grid = (ceil(nblk / kMarkSliceBlocks), B), block = 1024.
 constexpr int kMarkSliceBlocks = 4;
+constexpr int kMarkLists = 32;       // IVF lists in flight per round (one entry per thread and list)
 constexpr int kMarkSliceWords = kMarkSliceBlocks * kScanBlock * kWordsPerThread;   // 4096
 
 static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __restrict__ sel,
@@ -374,22 +375,22 @@ static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __re
     const int* s = sel + (size_t)b * Tpad * NP;
     const uint32_t p_lo = (uint32_t)slice * kMarkSliceWords * 32u, p_n = (uint32_t)kMarkSliceWords * 32u;
     const int nl = T * nprobe;
-    for (int l0 = 0; l0 < nl; l0 += 16) {
-        uint32_t lo[16], hi[16], pid[16];
+    for (int l0 = 0; l0 < nl; l0 += kMarkLists) {
+        uint32_t lo[kMarkLists], hi[kMarkLists], pid[kMarkLists];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kMarkLists; ++u) {
             const int l = l0 + u < nl ? l0 + u : nl - 1;            // past the end: the last list again (idempotent)
             const int cid = s[(l / nprobe) * NP + (l % nprobe)];
             lo[u] = ivf_off[cid];
             hi[u] = ivf_off[cid + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kMarkLists; ++u) {
             const uint32_t i = lo[u] + (uint32_t)tid;
             pid[u] = i < hi[u] ? ivf_pid[i] : 0xffffffffu;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kMarkLists; ++u) {
             const uint32_t q = pid[u] - p_lo;                       // 0xffffffff - p_lo >= p_n: never in range
             if (q < p_n && pid[u] != 0xffffffffu) atomicOr(&lbm[q >> 5], 1u << (q & 31));
             for (uint32_t i = lo[u] + (uint32_t)tid + 1024u; i < hi[u]; i += 1024u) {      // lists longer than 1024
@@ -432,33 +433,28 @@ static __global__ __launch_bounds__(kScanBlock) void bitmap_count_kernel(const u
     if (threadIdx.x == 0) blocksum[(size_t)b * gridDim.x + blockIdx.x] = total;
 }
 
-// grid = B, block = 256: exclusive scan of the block sums (in place), total -> ncand[b]
-static __global__ __launch_bounds__(kScanBlock) void bitmap_scan_kernel(int* __restrict__ blocksum,
-                                                                 int* __restrict__ ncand, int nblk) {
-    __shared__ int sh[8];
-    const int b = blockIdx.x;
-    int* bs = blocksum + (size_t)b * nblk;
-    int running = 0;
-    for (int base = 0; base < nblk; base += kScanBlock) {
-        const int idx = base + threadIdx.x;
-        const int v = idx < nblk ? bs[idx] : 0;
-        int total;
-        const int ex = block_exclusive_scan_256(v, sh, total);
-        if (idx < nblk) bs[idx] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) ncand[b] = running;
-}
-
 // grid = (nblk, B): emit ascending local pids (0-based) and clear the bitmap for the next query
+// The position of a block's first candidate is the sum of the counts of the blocks before it: every block adds them up
+// itself (at most a few hundred values) instead of waiting for a scan kernel; block 0 also leaves the total in ncand.
 static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t* __restrict__ bitmap,
-                                                                 const int* __restrict__ blockoff,
+                                                                 const int* __restrict__ blockcnt,
                                                                  uint32_t* __restrict__ cand,
                                                                  const uint32_t* __restrict__ doc_off,
                                                                  uint2* __restrict__ cand_hdr, int W,
-                                                                 size_t cand_cap) {
+                                                                 size_t cand_cap, int* __restrict__ ncand) {
     __shared__ int sh[8];
     const int b = blockIdx.y;
+    int before = 0;
+    {
+        const int* bc = blockcnt + (size_t)b * gridDim.x;
+        const int upto = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;      // block 0: everything, for the total
+        int part = 0;
+        for (int i = threadIdx.x; i < upto; i += kScanBlock) part += bc[i];
+        int total_;
+        (void)block_exclusive_scan_256(part, sh, total_);
+        if (blockIdx.x == 0) { if (threadIdx.x == 0) ncand[b] = total_; }
+        else before = total_;
+    }
     uint32_t* bm = bitmap + (size_t)b * W;
     const int w0 = (blockIdx.x * kScanBlock + threadIdx.x) * kWordsPerThread;
     uint32_t w[kWordsPerThread];
@@ -469,7 +465,7 @@ static __global__ __launch_bounds__(kScanBlock) void bitmap_emit_kernel(uint32_t
         cnt += __popc(w[j]);
     }
     int total;
-    int pos = block_exclusive_scan_256(cnt, sh, total) + blockoff[(size_t)b * gridDim.x + blockIdx.x];
+    int pos = block_exclusive_scan_256(cnt, sh, total) + before;
     uint32_t* out = cand + (size_t)b * cand_cap;
     uint2* hdr = cand_hdr + (size_t)b * cand_cap;   // {first embedding, length} of every candidate passage
 #pragma unroll
