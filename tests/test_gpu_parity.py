@@ -432,6 +432,34 @@ def test_two_phase_sharded_search(oracle, world, k):
         s.close()
 
 
+def test_batches_in_flight_equal_serial_results():
+    """Forty batches through two workspace slots on two streams (what bench.py times) give exactly the results the same
+    batches give one after the other on one stream."""
+    torch = pytest.importorskip("torch")
+    from colbert_jl_amd.distributed import DeviceSearch
+    idx = synthetic.make_index(seed=2026, n_docs=20000, K=1024)
+    nb, B, k = 40, 8, 200
+    Qs = synthetic.make_topic_queries(idx["centroids"], seed=80, n_queries=nb * B)
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+    s = clb.Searcher(index=idx)
+    runs = [DeviceSearch(s, 32, B, k, 2, slot=i) for i in range(2)]
+    serial = []
+    for i in range(nb):
+        p, sc = runs[0](Qdev[i * B:(i + 1) * B])
+        torch.cuda.synchronize()
+        serial.append((p.clone(), sc.clone()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [None] * nb
+    for i in range(nb):
+        with torch.cuda.stream(streams[i & 1]):
+            p, sc = runs[i & 1](Qdev[i * B:(i + 1) * B])
+            got[i] = (p.clone(), sc.clone())          # stream-ordered behind the search of batch i
+    torch.cuda.synchronize()
+    for i in range(nb):
+        assert torch.equal(got[i][0], serial[i][0]) and torch.equal(got[i][1], serial[i][1]), i
+    s.close()
+
+
 def test_two_phase_batches_in_flight_use_their_own_slot(oracle):
     """Several batches of the two-phase search in flight on different streams (what bench.py does with more than one
     rank): each continues on its own workspace slot -- phase 1 of the next batch must not disturb phase 2 of the
