@@ -432,6 +432,28 @@ def test_two_phase_sharded_search(oracle, world, k):
         s.close()
 
 
+@pytest.mark.parametrize("n_docs", [131071, 131073, 262145])
+def test_candidate_bitmap_slice_boundaries(oracle, n_docs):
+    """Batches mark their candidates in LDS slices of 131 072 passages (mark_count_kernel): corpora that end one passage
+    before / after a slice boundary, a batch of 9 (sliced path) and single queries (atomic path) against the oracle."""
+    idx = synthetic.make_index(seed=n_docs, n_docs=n_docs, K=2048, doclen_mean=12.0, doclen_std=3.0)
+    Qs = synthetic.make_topic_queries(idx["centroids"], seed=81, n_queries=9)
+    s = clb.Searcher(index=idx)
+    k = 50
+    bp, bs, _ = s.search_batch(Qs, k, nprobe=2)
+    for j in range(9):
+        rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
+        assert np.array_equal(bp[:, j], rp), j
+        assert_same_f32(bs[:, j], rs, "sliced candidate marking")
+        if j < 2:
+            p1, s1 = s.search_embeddings(Qs[:, :, j], k=k)
+            assert np.array_equal(p1, rp)
+            cand = s.retrieve(Qs[:, :, j])
+            assert np.array_equal(cand, oracle.retrieve(idx["ivf"], idx["ivf_lengths"], idx["centroids"],
+                                                        oracle.build_emb2pid(idx["doclens"]), 2, Qs[:, :, j]))
+    s.close()
+
+
 def test_batches_in_flight_equal_serial_results():
     """Forty batches through two workspace slots on two streams (what bench.py times) give exactly the results the same
     batches give one after the other on one stream."""
