@@ -133,6 +133,16 @@ struct Timed {
 // token tiles of 32 for the cells table: Tpad in {32, 64, 128} so that it divides the 256-thread scan
 inline int token_tiles(int64_t T) { return T <= 32 ? 1 : T <= 64 ? 2 : 4; }
 
+// the top-k kernel sorts up to kMaxTopK 8-byte keys in LDS: beyond 64 KB the attribute has to be raised
+void allow_large_topk_lds() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(unsigned long long) * kMaxTopK));
+    (void)hipGetLastError();
+    done = true;
+}
+
 int next_pow2(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -428,6 +438,7 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
         CLB_HIP(hipGetLastError());
         if (k <= kMaxTopK) {
             const int kpow2 = next_pow2(k);
+            allow_large_topk_lds();
             hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), sizeof(unsigned long long) * kpow2, st,
                                w.scores.as<float>() + (size_t)b * w.cand_cap, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap,
                                w.ncand.as<int>() + b, (const int*)nullptr, (const int*)nullptr, k, kpow2, w.cand_cap,
@@ -559,6 +570,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     }
     if (k <= kMaxTopK) {
         Timed t(s, KID_TOPK, st);
+        allow_large_topk_lds();
         hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
                            w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
                            kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);

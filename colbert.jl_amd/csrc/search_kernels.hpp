@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDim = 128;             // embedding dimension of the HIP search path
 constexpr int kCentTileStride = 132;  // dwords per staged centroid row: 16-B aligned, b128-conflict-free
-constexpr int kMaxTopK = 4096;        // k limit of the single-workgroup final sort
+constexpr int kMaxTopK = 16384;       // k limit of the single-workgroup final sort (8 B per slot in LDS: 128 KB)
 
 // -------------------------------------------------------------------------------------------------
 // S1  cells[b][c][t] = dot(Q[b][:,t], C[:,c])            (ranking.jl:27  `Q' * centroids`)

@@ -793,7 +793,8 @@ def test_search_general_dim_and_nbits(oracle, dim, nbits):
 
 def test_search_long_queries_large_nprobe_large_k(oracle):
     """On the tuned shape (dim 128, nbits 2): T > 128 goes to the general path; nprobe > 32 selects by a stable sort;
-    k > 4096 ranks by a full stable sort -- in both modes -- and nprobe = K makes every passage a candidate."""
+    k up to 16 384 is sorted by the one-work-group top-k kernel (128 KB of LDS), beyond that by a full stable sort -- in
+    both modes -- and nprobe = K makes every passage a candidate."""
     idx = synthetic.make_index(seed=43, n_docs=6000, K=256, doclen_mean=24, doclen_std=6)
     check_search(oracle, idx, synthetic.make_queries(idx, 44, 2, T=150), k=30, modes=(0,))
     Qs = synthetic.make_queries(idx, 45, 3)
@@ -809,3 +810,7 @@ def test_search_long_queries_large_nprobe_large_k(oracle):
             s.search_embeddings(Qs[:, :, 0], 6001, nprobe=256)
     finally:
         s.close()
+    big = synthetic.make_index(seed=46, n_docs=20000, K=256, doclen_mean=10, doclen_std=2)
+    Qb = synthetic.make_queries(big, 47, 2)
+    check_search(oracle, big, Qb, k=12000, nprobe=64)          # the largest power of two the top-k kernel sorts: 16 384
+    check_search(oracle, big, Qb, k=17000, nprobe=128)         # past it: the full stable sort
