@@ -78,8 +78,12 @@ void gemm(hipStream_t st, const float* A, const float* B, float* C, const float*
 
 // activations (T x K, fp32) x Linear weight (N x K, fp32) on the split-bf16 kernels (both operands are split into
 // bf16 planes while they are staged).  Falls back to the fp32 MFMA GEMM for shapes the kernel does not take.
+struct LnArgs { const float* gamma; const float* beta; float eps; };
+
+// ln != null: the caller applies a LayerNorm to the output next; returns true when it was applied here (split-K path:
+// fused into the reduction pass)
 template <int NS>
-void linear_split(hipStream_t st, Gemm3Args g, float* part) {
+bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
     const int M = g.M, N = g.N, K = g.K;
     auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm); };
     auto lds = [](int bm, int bn) { return (size_t)(NS * (bm + bn) * 64); };
@@ -92,30 +96,42 @@ void linear_split(hipStream_t st, Gemm3Args g, float* part) {
     } else {
         int ks = 1;
         if (part) {
-            while (ks < 8 && wgs(64, 64) * ks < 512 && K % (ks * 2 * 32) == 0 && K / (ks * 2) >= 256) ks *= 2;
+            // K slices of at least 256 (192 for the few-tile outputs such as the hidden -> dim projection of a query batch)
+            const int min_slice = wgs(64, 64) < 64 ? 192 : 256;
+            while (ks < 8 && wgs(64, 64) * ks < 512 && K % (ks * 2 * 32) == 0 && K / (ks * 2) >= min_slice) ks *= 2;
         }
+        float* C = g.C;
+        if (ks > 1) { g.ksplit = ks; g.C = part; }
+        hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), lds(64, 64), st, g);
         if (ks > 1) {
-            float* C = g.C;
-            g.ksplit = ks; g.C = part;
-            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), lds(64, 64), st, g);
+            if (ln && N <= 1024) {
+                if (N <= 768)
+                    hipLaunchKernelGGL(gemm_splitk_reduce_ln_kernel<3>, dim3(M), dim3(256), 0, st, part, ks, (int64_t)M, N,
+                                       C, g.bias, g.R, 1.0f, g.epi, ln->gamma, ln->beta, ln->eps);
+                else
+                    hipLaunchKernelGGL(gemm_splitk_reduce_ln_kernel<4>, dim3(M), dim3(256), 0, st, part, ks, (int64_t)M, N,
+                                       C, g.bias, g.R, 1.0f, g.epi, ln->gamma, ln->beta, ln->eps);
+                return true;
+            }
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, ks,
                                (int64_t)M, N, C, g.bias, g.R, 1.0f, g.epi);
-        } else {
-            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), lds(64, 64), st, g);
         }
     }
+    return false;
 }
 
+// Linear (+ optional LayerNorm of the output, in place)
 void linear(clb_encoder* e, hipStream_t st, const float* A, const float* Wt, float* C, const float* bias, const float* R,
-            int M, int N, int K, int epi, float* part) {
+            int M, int N, int K, int epi, float* part, const LnArgs* ln = nullptr) {
     const bool ok = e->gemm_mode != 0 && K % 32 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)Wt % 16 == 0) && M >= 1 && N >= 1;
     if (!ok) {
         gemm(st, A, Wt, C, bias, R, M, N, K, K, K, 1, N, epi, 1.0f, 1, 1, 0, 0, 0, 0, 0, 0, part);
-        return;
+    } else {
+        Gemm3Args g{A, Wt, C, bias, R, M, N, K, K, K, N, 1.0f, epi, 1};
+        const bool done = e->gemm_mode == 1 ? linear_split<2>(st, g, part, ln) : linear_split<3>(st, g, part, ln);
+        if (done) return;
     }
-    Gemm3Args g{A, Wt, C, bias, R, M, N, K, K, K, N, 1.0f, epi, 1};
-    if (e->gemm_mode == 1) linear_split<2>(st, g, part);
-    else linear_split<3>(st, g, part);
+    if (ln) hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, st, C, (int64_t)M, N, ln->gamma, ln->beta, ln->eps);
 }
 
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
@@ -171,15 +187,14 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
                  heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
         }
         // attention output + residual, LayerNorm
-        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part);
-        hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, tmp, T, (int)H, P + e->r_g1, P + e->r_b1n, e->eps);
+        const LnArgs ln1{P + e->r_g1, P + e->r_b1n, e->eps}, ln2{P + e->r_g2, P + e->r_b2n, e->eps};
+        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1);
         // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
         linear(e, st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr);
-        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part);
-        hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, x, T, (int)H, P + e->r_g2, P + e->r_b2n, e->eps);
+        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2);
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
-    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, nullptr);
+    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part);
     CLB_HIP(hipGetLastError());
     if (!sync) return CLB_OK;
     int herr = 0;

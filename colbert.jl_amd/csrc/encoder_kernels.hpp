@@ -280,7 +280,9 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
     // loader: thread t moves float4 (t & 7) of rows (t >> 3) + RPP p of A and of B
     const int lrow = tid >> 3, lq = tid & 7;
     f32x4 pa[BM / RPP], pb[BN / RPP];
-#define CLB_G3_LOAD(K0)                                                                                      \
+#define CLB_G3_LOAD(K0) CLB_G3_LOAD_(K0, pa, pb)
+#define CLB_G3_STORE() CLB_G3_STORE_(pa, pb)
+#define CLB_G3_LOAD_(K0, pa, pb)                                                                                      \
     {                                                                                                        \
         _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
             int m = m0 + lrow + RPP * p;                                                                     \
@@ -293,7 +295,7 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
             pb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldb_ + (K0) + 4 * lq);                 \
         }                                                                                                    \
     }
-#define CLB_G3_STORE()                                                                                       \
+#define CLB_G3_STORE_(pa, pb)                                                                                \
     {                                                                                                        \
         _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
             const int row_ = lrow + RPP * p;                                                                 \
@@ -317,9 +319,7 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
     const int sw = (i >> 2) & 3;                  // the swizzle of this lane's rows (tile bases are multiples of 32)
     const unsigned char* As = g3lds + (wr * 32 * WM + i) * 64;
     const unsigned char* Bs = g3lds + NS * PA + (wc * 32 * WN + i) * 64;
-    for (int k0 = 0; k0 < K_; k0 += 32) {
-        const bool more = k0 + 32 < K_;
-        if (more) CLB_G3_LOAD(k0 + 32)
+    auto compute_step = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = ((2 * s + h) ^ sw) << 4;
@@ -347,12 +347,19 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
                     acc[a][b] = c;
                 }
         }
+    };
+    for (int k0 = 0; k0 < K_; k0 += 32) {
+        const bool more = k0 + 32 < K_;
+        if (more) CLB_G3_LOAD(k0 + 32)
+        compute_step();
         __syncthreads();              // every wave has read the tile
         if (more) CLB_G3_STORE()
         __syncthreads();
     }
 #undef CLB_G3_LOAD
 #undef CLB_G3_STORE
+#undef CLB_G3_LOAD_
+#undef CLB_G3_STORE_
     // C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
 #pragma unroll
     for (int a = 0; a < WM; ++a)
@@ -391,6 +398,67 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
     if (epi & EPI_GELU) v = gelu_erf(v);
     if (epi & EPI_RESID) v += R[idx];
     C[idx] = v;
+}
+
+// split-K second pass fused with the LayerNorm that follows it (the attention-output and FFN-output Linears of a short
+// batch): one 256-thread work-group per output row (a wave per row leaves a query batch's 1 024 rows one wave per
+// SIMD, all latency: 19.7 us against 13.6 for the two separate launches), the row stays in registers between the
+// reduction and the normalisation.  The element arithmetic is that of gemm_splitk_reduce_kernel; mean and variance are
+// summed per wave, then over the four waves in order.  N <= 256 * NR.
+template <int NR>
+static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(const float* __restrict__ part, int ksplit,
+                                                                          int64_t M, int N, float* __restrict__ C,
+                                                                          const float* __restrict__ bias,
+                                                                          const float* __restrict__ R, float scale, int epi,
+                                                                          const float* __restrict__ gamma,
+                                                                          const float* __restrict__ beta, float eps) {
+    __shared__ float red[2][4];
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t slice = (size_t)M * N;
+    float v[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int n = tid + 256 * j;
+        v[j] = n < N ? part[t * N + n] : 0.f;
+    }
+    for (int z = 1; z < ksplit; ++z) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int n = tid + 256 * j;
+            if (n < N) v[j] = v[j] + part[z * slice + t * N + n];
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int n = tid + 256 * j;
+        if (n < N) {
+            float x = v[j] * scale;
+            if (epi & EPI_BIAS) x += bias[n];
+            if (epi & EPI_GELU) x = gelu_erf(x);
+            if (epi & EPI_RESID) x += R[t * N + n];
+            v[j] = x;
+            sum += x;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    const float mean = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)N;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+        if (tid + 256 * j < N) { const float c = v[j] - mean; var += c * c; }
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    if (lane == 0) red[1][wave] = var;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)N + eps);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int n = tid + 256 * j;
+        if (n < N) C[t * N + n] = (v[j] - mean) * rstd * gamma[n] + beta[n];
+    }
 }
 
 // embeddings: word[id] + position[pos] + token_type[0], then LayerNorm.  One wave per token.  ids are the

@@ -295,6 +295,43 @@ def test_search_many_candidates(oracle):
     check_search(oracle, idx, Qs, k=1000)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_search_random_configurations(oracle, seed):
+    """Randomly drawn shapes (corpus size, centroid count, nbits, passage lengths, query length, batch, k, nprobe,
+    topical or uniform codes, scaled queries): pids identical and scores bit-identical to the oracle, both modes."""
+    rng = np.random.default_rng(7000 + seed)
+    n_docs = int(rng.integers(40, 6000))
+    K = int(2 ** rng.integers(3, 11))
+    nbits = int(rng.choice([1, 2, 2, 2, 4]))
+    mean = float(rng.integers(4, 120))
+    idx = synthetic.make_index(seed=7100 + seed, n_docs=n_docs, K=K, nbits=nbits, doclen_mean=mean,
+                               doclen_std=float(rng.integers(0, 40)), topical=bool(rng.integers(0, 2)))
+    T = int(rng.choice([1, 3, 17, 32, 32, 32, 33, 48]))
+    Qs = synthetic.make_queries(idx, 7200 + seed, int(rng.integers(1, 10)), T=T)
+    if rng.integers(0, 3) == 0:
+        Qs = np.asfortranarray(Qs * np.float32(rng.choice([0.25, 3.0, 40.0])))   # the reference does not require unit queries
+    k = int(min(n_docs, rng.choice([1, 10, 100, 1000, n_docs])))
+    nprobe = int(min(K, rng.choice([1, 2, 2, 3, 8])))
+    # the reference raises BoundsError when k exceeds a query's candidate count (searching.jl:127): so must the product;
+    # the comparison itself then runs at the largest k every query of the batch can fill
+    fewest = min(oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=1)[2] for j in range(Qs.shape[2]))
+    if k > fewest:
+        j = int(np.argmin([oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=1)[2] for j in range(Qs.shape[2])]))
+        srch = clb.Searcher(index=idx)
+        try:
+            for mode in (0, 1):
+                try:
+                    srch.set_mode(mode)
+                except clb.Unsupported:
+                    continue
+                with pytest.raises(clb.BoundsError):
+                    srch.search_embeddings(Qs[:, :, j], k, nprobe=nprobe)
+        finally:
+            srch.close()
+        k = fewest
+    check_search(oracle, idx, Qs, k=k, nprobe=nprobe)
+
+
 def test_search_ties_keep_ascending_pid(oracle):
     """Duplicate passages score identically; the stable sortperm keeps the lower pid first."""
     idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
