@@ -26,12 +26,12 @@ _is_cjk(c::Char) = (0x4E00 <= UInt32(c) <= 0x9FFF) || (0x3400 <= UInt32(c) <= 0x
 function _is_punct(c::Char)
     u = UInt32(c)
     ((33 <= u <= 47) || (58 <= u <= 64) || (91 <= u <= 96) || (123 <= u <= 126)) && return true
-    Unicode.category_code(c) in (Unicode.UTF8PROC_CATEGORY_PC, Unicode.UTF8PROC_CATEGORY_PD, Unicode.UTF8PROC_CATEGORY_PS,
-        Unicode.UTF8PROC_CATEGORY_PE, Unicode.UTF8PROC_CATEGORY_PI, Unicode.UTF8PROC_CATEGORY_PF,
-        Unicode.UTF8PROC_CATEGORY_PO)
+    Base.Unicode.category_code(c) in (Base.Unicode.UTF8PROC_CATEGORY_PC, Base.Unicode.UTF8PROC_CATEGORY_PD, Base.Unicode.UTF8PROC_CATEGORY_PS,
+        Base.Unicode.UTF8PROC_CATEGORY_PE, Base.Unicode.UTF8PROC_CATEGORY_PI, Base.Unicode.UTF8PROC_CATEGORY_PF,
+        Base.Unicode.UTF8PROC_CATEGORY_PO)
 end
 _is_control(c::Char) = !(c in ('\t', '\n', '\r')) &&
-                       Unicode.category_code(c) in (Unicode.UTF8PROC_CATEGORY_CC, Unicode.UTF8PROC_CATEGORY_CF)
+                       Base.Unicode.category_code(c) in (Base.Unicode.UTF8PROC_CATEGORY_CC, Base.Unicode.UTF8PROC_CATEGORY_CF)
 
 "BERT's BasicTokenizer: clean, isolate CJK, split on whitespace, lowercase + strip accents, split punctuation"
 function _basic_tokens(t::WordPieceTokenizer, text::AbstractString)
@@ -51,18 +51,18 @@ function _basic_tokens(t::WordPieceTokenizer, text::AbstractString)
         w = String(word)
         if t.lowercase
             w = lowercase(w)
-            w = filter(c -> Unicode.category_code(c) != Unicode.UTF8PROC_CATEGORY_MN, Unicode.normalize(w, :NFD))
+            w = filter(c -> Base.Unicode.category_code(c) != Base.Unicode.UTF8PROC_CATEGORY_MN, Unicode.normalize(w, :NFD))
         end
         cur = IOBuffer()
         for c in w
             if _is_punct(c)
-                cur.size > 0 && push!(out, String(take!(cur)))
+                position(cur) > 0 && push!(out, String(take!(cur)))
                 push!(out, string(c))
             else
                 print(cur, c)
             end
         end
-        cur.size > 0 && push!(out, String(take!(cur)))
+        position(cur) > 0 && push!(out, String(take!(cur)))
     end
     out
 end
