@@ -158,6 +158,41 @@ def test_codec_stats_match_oracle(oracle):
         assert np.isclose(avg, ravg, rtol=1e-6)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_index_build_stages_random_configurations(oracle, seed):
+    """The index-build stages chained at randomly drawn shapes (dim a multiple of 8, nbits, K, sample and chunk sizes,
+    k-means batch size): every stage's output is bit-identical to the oracle's, and each stage is fed the PRODUCT's
+    output of the previous one, so a difference cannot hide behind a later stage."""
+    rng = np.random.default_rng(8800 + seed)
+    dim = int(rng.choice([8, 16, 24, 64, 128, 128, 128, 256]))
+    nbits = int(rng.choice([1, 2, 2, 4, 8]))
+    K = int(rng.integers(1, 400))
+    n = int(rng.integers(K, K + 5000))
+    centres = rng.normal(size=(dim, max(2, K // 3))).astype(np.float32)
+    data = oracle.normalize_array((centres[:, rng.integers(0, centres.shape[1], size=n)]
+                                   + 0.4 * rng.normal(size=(dim, n))).astype(np.float32))
+    init = data[:, rng.permutation(n)[:K]]
+    bsize = int(rng.choice([64, 1000, 4096]))
+    c, a, it = codec.kmeans(data, init, max_iters=4, point_bsize=bsize)
+    rc, ra, rit = oracle.kmeans(data, init, max_iters=4, point_bsize=bsize)
+    assert it == rit and np.array_equal(a, ra)
+    assert_same_f32(c, rc, "kmeans centroids")
+    held = oracle.normalize_array(rng.normal(size=(dim, int(rng.integers(50, 900)))).astype(np.float32))
+    cut, w, avg, hcodes = codec.compute_avg_residuals(nbits, c, held)
+    rcut, rw, ravg, rhcodes = oracle.compute_avg_residuals(nbits, c, held)
+    assert np.array_equal(hcodes, rhcodes)
+    assert_same_f32(cut, rcut, "cutoffs"); assert_same_f32(w, rw, "weights")
+    assert np.isclose(avg, ravg, rtol=1e-6)
+    embs = oracle.normalize_array(rng.normal(size=(dim, int(rng.integers(1, 3000)))).astype(np.float32))
+    codes, res = codec.compress(c, cut, dim, nbits, embs)
+    rcodes, rres = oracle.compress(c, cut, dim, nbits, embs)
+    assert np.array_equal(codes, rcodes) and np.array_equal(res, rres)
+    assert_same_f32(codec.decompress(dim, nbits, c, w, codes, res), oracle.decompress(dim, nbits, c, w, codes, res), "decompress")
+    ivf, lens = codec.build_ivf(codes, K)
+    rivf, rlens = oracle.build_ivf(codes, K)
+    assert np.array_equal(ivf, rivf) and np.array_equal(lens, rlens)
+
+
 def test_build_ivf_matches_oracle(oracle):
     rng = np.random.default_rng(107)
     codes = rng.integers(1, 5001, size=200_000).astype(np.uint32)
@@ -186,6 +221,7 @@ def test_encoder_epilogue_bit_exact(oracle):
 # ---------------------------------------------------------------------------------------------------
 def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0):
     s = clb.Searcher(index=idx, pid_offset=pid_offset)
+    refs = [oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k) for j in range(Qs.shape[2])]   # the oracle, once per query
     try:
         for mode in modes:
             if mode == 1 and s.mode != 1:
@@ -195,7 +231,7 @@ def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0):
                     continue
             s.set_mode(mode)
             for j in range(Qs.shape[2]):
-                rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k)
+                rp, rs, rn = refs[j]
                 pids, scores = s.search_embeddings(Qs[:, :, j], k, nprobe=nprobe)
                 assert s.last_num_candidates == rn
                 assert np.array_equal(pids, rp + pid_offset), (mode, j, np.nonzero(pids != rp + pid_offset)[0][:5])
@@ -203,7 +239,7 @@ def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0):
             # the batch entry point returns the same thing
             bp, bs, bn = s.search_batch(Qs, k, nprobe=nprobe)
             for j in range(Qs.shape[2]):
-                rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k)
+                rp, rs, rn = refs[j]
                 assert np.array_equal(bp[:, j], rp + pid_offset) and bn[j] == rn
                 assert_same_f32(bs[:, j], rs, f"batch scores mode={mode} q={j}")
     finally:
@@ -314,9 +350,10 @@ def test_search_random_configurations(oracle, seed):
     nprobe = int(min(K, rng.choice([1, 2, 2, 3, 8])))
     # the reference raises BoundsError when k exceeds a query's candidate count (searching.jl:127): so must the product;
     # the comparison itself then runs at the largest k every query of the batch can fill
-    fewest = min(oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=1)[2] for j in range(Qs.shape[2]))
+    counts = [oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=1)[2] for j in range(Qs.shape[2])]
+    fewest = min(counts)
     if k > fewest:
-        j = int(np.argmin([oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=1)[2] for j in range(Qs.shape[2])]))
+        j = int(np.argmin(counts))
         srch = clb.Searcher(index=idx)
         try:
             for mode in (0, 1):
