@@ -977,6 +977,56 @@ struct ApproxConsts {
     float inv_qerr; // max |dequantised inv_norm - inv_norm| = half a quantisation step of the packed code|inv word
 };
 
+// The error bound of one query (see the header of this file): eps_t bounds |approx - canonical| of ONE (token, embedding)
+// score, eps_sum the same for a passage score (T tokens); `unsafe` = the fp16 score table cannot be trusted for this
+// query.  Called by all 1 024 threads of a work-group (two barriers); s_qn / s_dq are two shared floats.
+struct QueryBound { float eps_t, eps_sum; bool unsafe; };
+__device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, int b, int T, const ApproxConsts& ac,
+                                                  float* s_qn, float* s_dq) {
+    const int tid = threadIdx.x;
+    // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
+    if (tid == 0) { *s_qn = 0.f; *s_dq = 0.f; }
+    __syncthreads();
+    {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - bf16(Q_t)||: what the
+        // bf16 query operand of pass 1 really loses (at most 2^-9 ||Q_t||, ~0.6 of that for typical values)
+        const int t = tid >> 5, part = tid & 31;
+        float a = 0.f, dd = 0.f;
+        if (t < T) {
+            const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
+            a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+            const float dx = v.x - __uint_as_float(f32_to_bf16_rne(v.x) << 16), dy = v.y - __uint_as_float(f32_to_bf16_rne(v.y) << 16);
+            const float dz = v.z - __uint_as_float(f32_to_bf16_rne(v.z) << 16), dw = v.w - __uint_as_float(f32_to_bf16_rne(v.w) << 16);
+            dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); dd += __shfl_xor(dd, o, 64); }
+        if (t < T && part == 0) {
+            atomicMax(reinterpret_cast<unsigned int*>(s_qn), __float_as_uint(sqrtf(a) * 1.001f));
+            atomicMax(reinterpret_cast<unsigned int*>(s_dq), __float_as_uint(sqrtf(dd) * 1.001f));
+        }
+    }
+    __syncthreads();
+    const float u = 5.9604645e-08f;  // 2^-24
+    const float qn = *s_qn;
+    // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
+    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
+    // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the bf16 operands (their products are exact
+    // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
+    // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
+    const float e_qr = 1.001f * (*s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
+    // the packed inv_norm is off by at most inv_qerr: it scales P = X + Q.r, |P| <= qn (cn + rn), and the other terms
+    const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_cells + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 328.f * u * qn;
+    QueryBound r;
+    r.eps_t = eps_t;
+    // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
+    // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
+    // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
+    // scored by the exact kernel alone, exactly as in mode 0.  (NaN-safe: written with negated comparisons.)
+    r.unsafe = !(qn * ac.cn_max < 3.0e4f) || !(eps_t < 1.0e30f);
+    r.eps_sum = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
+    return r;
+}
+
 static __global__ __launch_bounds__(1024) void select_margin_kernel(const float* __restrict__ scores,
                                                                    const int* __restrict__ ncand,
                                                                    const float* __restrict__ Q, int T, int k,
@@ -995,47 +1045,11 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const int n = ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
     int* lst = list + (size_t)b * cand_cap;
-    // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
-    if (tid == 0) { s_qn = 0.f; s_dq = 0.f; }
-    __syncthreads();
-    {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - bf16(Q_t)||: what the
-        // bf16 query operand of pass 1 really loses (at most 2^-9 ||Q_t||, ~0.6 of that for typical values)
-        const int t = tid >> 5, part = tid & 31;
-        float a = 0.f, dd = 0.f;
-        if (t < T) {
-            const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
-            a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
-            const float dx = v.x - __uint_as_float(f32_to_bf16_rne(v.x) << 16), dy = v.y - __uint_as_float(f32_to_bf16_rne(v.y) << 16);
-            const float dz = v.z - __uint_as_float(f32_to_bf16_rne(v.z) << 16), dw = v.w - __uint_as_float(f32_to_bf16_rne(v.w) << 16);
-            dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); dd += __shfl_xor(dd, o, 64); }
-        if (t < T && part == 0) {
-            atomicMax(reinterpret_cast<unsigned int*>(&s_qn), __float_as_uint(sqrtf(a) * 1.001f));
-            atomicMax(reinterpret_cast<unsigned int*>(&s_dq), __float_as_uint(sqrtf(dd) * 1.001f));
-        }
-    }
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
-    __syncthreads();
+    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq);
     float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
-    // bound on |approx - canonical| of ONE (token, embedding) score; see the header of this file
-    const float u = 5.9604645e-08f;  // 2^-24
-    const float qn = s_qn;
-    // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
-    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
-    // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the bf16 operands (their products are exact
-    // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
-    // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
-    const float e_qr = 1.001f * (s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
-    // the packed inv_norm is off by at most inv_qerr: it scales P = X + Q.r, |P| <= qn (cn + rn), and the other terms
-    const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_cells + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 328.f * u * qn;
-    // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
-    // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
-    // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
-    // scored by the exact kernel alone, exactly as in mode 0.  (NaN-safe: written with negated comparisons.)
-    const bool unsafe = !(qn * ac.cn_max < 3.0e4f) || !(eps_t < 1.0e30f);
-    if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * eps_t;
+    const bool unsafe = qb.unsafe;
+    if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
     // thread t owns the contiguous slots [t*chunk, (t+1)*chunk); up to kSelCache order keys stay in registers for the
     // radix passes and the compaction (the approximate scores are read once)
     const int chunk = (n + 1023) >> 10;
@@ -1068,12 +1082,12 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     } else if (tau_in) {
         // sharded search, phase 2: tau is the GLOBAL k-th approximate score over all shards (global_tau_kernel); -inf
         // means fewer than k candidates exist anywhere, i.e. everything is listed
-        eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
+        eps = qb.eps_sum;
         tau_f = tau_in[b];
         thr = tau_f == kNegInf ? kNegInf : tau_f - 2.f * eps;
     } else if (n > k) {
         CLB_RADIX_SELECT()
-        eps = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
+        eps = qb.eps_sum;
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;
     }
@@ -1150,6 +1164,266 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         nlist[b] = s_run;
         thresh[2 * b] = tau_f;
         thresh[2 * b + 1] = eps;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Wide selection: the same tau / list as select_margin_kernel, by kWideBlocks work-groups per query.  One CU needs
+// 0.26 ms for the five radix passes over the ~96 k candidates a query has on a 10 M-passage shard (issue-bound);
+// here every pass is its own launch of grid (kWideBlocks, B): the work-groups add the histogram of their segment to
+// the query's global one.  No work-group waits for another and nothing is fenced: the launch boundary orders the
+// passes, and every work-group of a launch re-derives the selection state (prefix, rank, digit position) from the
+// finished histograms of the earlier passes (wide_replay: at most four 256-bin picks).  A first version let the last
+// work-group to arrive pick the digit behind a device-scope fence: 8 192 waves x 7 launches of L2 write-backs made it
+// 1.1 ms per batch.  Launch order: wide_minmax, wide_hist x 4 (a pass a query does not need returns at once),
+// wide_count, wide_emit.  `WideSel` (one per query) must be zero before wide_minmax.
+// -------------------------------------------------------------------------------------------------------------
+constexpr int kWideBlocks = 16;
+struct WideSel {
+    uint32_t kmax, kmin_inv;      // max key, max of ~key
+    int unsafe;
+    float eps_sum;
+    int cnt[kWideBlocks];
+    int hist[4][256];
+};
+struct WideState {
+    uint32_t prefix;
+    int remaining, shift, width;
+    bool done;
+    float thr, tau, eps;
+};
+
+// slots [lo, hi) of work-group g: segments of whole 1 024-slot blocks
+__device__ __forceinline__ void wide_segment(int n, int g, int& lo, int& hi) {
+    const int seg = ((n + kWideBlocks * 1024 - 1) / (kWideBlocks * 1024)) * 1024;
+    lo = g * seg;
+    hi = lo + seg < n ? lo + seg : n;
+    if (lo > n) lo = n;
+}
+
+// The selection state after the first `upto` radix passes, from what the earlier launches left in `w`.  Called by all
+// threads of the work-group; hist = 256 ints of LDS (16-byte aligned), s_prefix / s_remaining shared words.
+__device__ __forceinline__ WideState wide_replay(const WideSel& w, int n, int k, const float* __restrict__ tau_in, int b,
+                                                 int upto, int* hist, uint32_t* s_prefix, int* s_remaining) {
+    const int tid = threadIdx.x;
+    WideState st;
+    st.prefix = 0u; st.remaining = 0; st.shift = 0; st.width = 0; st.done = true;
+    st.thr = kNegInf; st.tau = kNegInf; st.eps = 0.f;
+    if (w.unsafe) {
+        st.eps = __builtin_inff();                        // everything is listed
+    } else if (tau_in) {                                  // sharded search, phase 2: the global threshold
+        st.eps = w.eps_sum;
+        st.tau = tau_in[b];
+        st.thr = st.tau == kNegInf ? kNegInf : st.tau - 2.f * st.eps;
+    } else if (n > k) {
+        st.eps = w.eps_sum;
+        const uint32_t gmax = w.kmax, gmin = ~w.kmin_inv;
+        const uint32_t diff = gmin ^ gmax;
+        if (diff == 0u) {
+            st.prefix = gmax;
+            st.tau = f32_from_order_key(gmax);
+            st.thr = st.tau - 2.f * st.eps;
+        } else {
+            const int top = 31 - __clz((int)diff);
+            st.shift = top > 7 ? top - 7 : 0;
+            st.width = top - st.shift + 1;
+            st.prefix = top == 31 ? 0u : (gmax & (0xffffffffu << (top + 1)));
+            st.remaining = k;
+            st.done = false;
+            for (int p = 0; p < upto && !st.done; ++p) {  // uniform over the work-group
+                __syncthreads();
+                if (tid < 256) hist[tid] = w.hist[p][tid];
+                __syncthreads();
+                if (tid < 64) radix_pick(hist, st.remaining, st.prefix, st.shift, s_prefix, s_remaining);
+                __syncthreads();
+                st.prefix = *s_prefix;
+                st.remaining = *s_remaining;
+                if (st.shift == 0) {
+                    st.tau = f32_from_order_key(st.prefix);
+                    st.thr = st.tau - 2.f * st.eps;
+                    st.done = true;
+                } else {
+                    const int ns = st.shift > 8 ? st.shift - 8 : 0;
+                    st.width = st.shift - ns;
+                    st.shift = ns;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    return st;
+}
+
+// grid = (kWideBlocks, B), block = 1024
+static __global__ __launch_bounds__(1024) void wide_minmax_kernel(const float* __restrict__ scores,
+                                                                 const int* __restrict__ ncand,
+                                                                 const float* __restrict__ Q, int T, size_t cand_cap,
+                                                                 ApproxConsts ac, WideSel* __restrict__ wsel,
+                                                                 float* __restrict__ eps_pair) {
+    __shared__ uint32_t s_kmin, s_kmax;
+    __shared__ float s_qn, s_dq;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int n = ncand[b];
+    const float* sc = scores + (size_t)b * cand_cap;
+    WideSel& w = wsel[b];
+    if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0u; }
+    __syncthreads();
+    if (g == 0) {                                         // uniform over the work-group
+        const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq);
+        if (tid == 0) {
+            eps_pair[b] = qb.unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
+            w.unsafe = qb.unsafe ? 1 : 0;
+            w.eps_sum = qb.eps_sum;
+        }
+    }
+    int lo, hi;
+    wide_segment(n, g, lo, hi);
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll 4
+    for (int i = lo + tid; i < hi; i += 1024) {
+        const uint32_t key = f32_order_key(sc[i]);
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    if ((tid & 63) == 0) { atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); }
+    __syncthreads();
+    if (tid == 0 && lo < hi) { atomicMax(&w.kmax, s_kmax); atomicMax(&w.kmin_inv, ~s_kmin); }
+}
+
+// one radix pass; grid = (kWideBlocks, B), block = 1024
+static __global__ __launch_bounds__(1024) void wide_hist_kernel(const float* __restrict__ scores,
+                                                               const int* __restrict__ ncand, int k, size_t cand_cap,
+                                                               WideSel* __restrict__ wsel, int pass) {
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    WideSel& w = wsel[b];
+    const int n = ncand[b];
+    const WideState st = wide_replay(w, n, k, nullptr, b, pass, hist, &s_prefix, &s_remaining);
+    if (st.done) return;                                  // uniform over the work-group
+    const float* sc = scores + (size_t)b * cand_cap;
+    const uint32_t prefix = st.prefix;
+    const int shift = st.shift, width = st.width;
+    const uint32_t himask = shift + width >= 32 ? 0u : (0xffffffffu << (shift + width));
+    const uint32_t bmask = (1u << width) - 1u;
+    __syncthreads();
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    int lo, hi;
+    wide_segment(n, g, lo, hi);
+#pragma unroll 4
+    for (int i0 = lo; i0 < hi; i0 += 1024) {              // whole waves take part in the aggregated add
+        const int i = i0 + tid;
+        const bool valid = i < hi;
+        const uint32_t key = valid ? f32_order_key(sc[i]) : 0u;
+        hist_add_aggregated(hist, (key >> shift) & bmask, valid && (key & himask) == prefix);
+    }
+    __syncthreads();
+    if (tid < 256 && hist[tid]) atomicAdd(&w.hist[pass][tid], hist[tid]);
+}
+
+// how many slots of the segment are listed; grid = (kWideBlocks, B), block = 1024
+static __global__ __launch_bounds__(1024) void wide_count_kernel(const float* __restrict__ scores,
+                                                                const int* __restrict__ ncand, int k, size_t cand_cap,
+                                                                WideSel* __restrict__ wsel,
+                                                                const float* __restrict__ tau_in) {
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining, s_cnt;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    WideSel& w = wsel[b];
+    const int n = ncand[b];
+    const float* sc = scores + (size_t)b * cand_cap;
+    const float thr = wide_replay(w, n, k, tau_in, b, 4, hist, &s_prefix, &s_remaining).thr;
+    __syncthreads();
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int lo, hi;
+    wide_segment(n, g, lo, hi);
+    int c = 0;
+#pragma unroll 4
+    for (int i = lo + tid; i < hi; i += 1024) c += !(sc[i] < thr) ? 1 : 0;      // NaN (unsafe query) is listed
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (tid == 0) w.cnt[g] = s_cnt;
+}
+
+// ordered compaction: the segment's listed slots follow those of the segments before it; grid = (kWideBlocks, B)
+static __global__ __launch_bounds__(1024) void wide_emit_kernel(const float* __restrict__ scores,
+                                                               const int* __restrict__ ncand, int k, size_t cand_cap,
+                                                               const WideSel* __restrict__ wsel,
+                                                               const float* __restrict__ tau_in, int* __restrict__ list,
+                                                               int* __restrict__ nlist, float* __restrict__ thresh) {
+    __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining;
+    __shared__ int sh_big[2][8][16];
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const WideSel& w = wsel[b];
+    const int n = ncand[b];
+    const float* sc = scores + (size_t)b * cand_cap;
+    int* lst = list + (size_t)b * cand_cap;
+    const WideState st = wide_replay(w, n, k, tau_in, b, 4, hist, &s_prefix, &s_remaining);
+    const float thr = st.thr;
+    int run = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < kWideBlocks; ++j) {
+        const int c = w.cnt[j];
+        run += j < g ? c : 0;
+        total += c;
+    }
+    if (g == 0 && tid == 0) {
+        nlist[b] = total;
+        thresh[2 * b] = st.tau;
+        thresh[2 * b + 1] = st.eps;
+    }
+    int lo, hi;
+    wide_segment(n, g, lo, hi);
+    const int lane = tid & 63, wave = tid >> 6;
+    int it = 0;
+    for (int base = lo; base < hi; base += 8192, ++it) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * 1024 + tid;
+            v[j] = i < hi ? sc[i] : 0.f;
+        }
+        int pre[8];
+        bool take[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * 1024 + tid;
+            take[j] = i < hi && !(v[j] < thr);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take[j]);
+            pre[j] = (int)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) sh_big[it & 1][j][wave] = (int)__popcll(m);
+        }
+        __syncthreads();
+        int offs = run;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane < 16 ? sh_big[it & 1][j][lane] : 0;
+            int x = c;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            const int wbase = __shfl(x - c, wave, 64);
+            const int tot = __shfl(x, 15, 64);
+            if (take[j]) lst[offs + wbase + pre[j]] = base + j * 1024 + tid;
+            offs += tot;
+        }
+        run = offs;
     }
 }
 

@@ -63,7 +63,7 @@ struct Workspace {
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel;
     DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch;   // general-shape path (generic_kernels.hpp)
 };
 
@@ -74,6 +74,7 @@ struct clb_searcher {
     int64_t dim = 0, K = 0, n_docs = 0, n_emb = 0, pid_offset = 0;
     int nbits = 0;
     int mode = 0;
+    int wide_select = -1;      // selection by kWideBlocks work-groups per query: -1 by candidate capacity, 0 never, 1 always
     bool approx_ok = false;
     bool generic = false;      // dim != 128 or nbits == 8: every query takes the general-shape path
     int64_t max_doclen = 0;
@@ -457,6 +458,34 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
 // phase 1 = candidate generation, pass 1, local selection, and the shard's k largest approximate scores per query
 // to `d_local_top`; phase 2 = global tau from the gathered scores `d_all_top` ([n_shards][B][k]), selection at that
 // tau, pass 2, top-k.  Phase 2 continues on the workspace phase 1 left behind.
+// tau and the list {approx >= tau - 2 eps} of every query of the batch (two-pass mode).  One work-group per query keeps
+// up to 32 768 candidates in registers; shards whose queries can have several times that (candidate capacity >= 131 072:
+// roughly 3 M passages and up) take the wide selection -- kWideBlocks work-groups per query, one launch per radix pass.
+constexpr size_t kWideSelectCap = 131072;
+int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int k, const float* tau_in) {
+    const bool wide = s->wide_select == 1 || (s->wide_select < 0 && w.cand_cap >= kWideSelectCap);
+    if (!wide) {
+        hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
+                           w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
+                           w.eps_pair.as<float>(), tau_in);
+        return CLB_OK;
+    }
+    CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
+    CLB_HIP(hipMemsetAsync(w.wsel.p, 0, sizeof(WideSel) * B, st));
+    const dim3 grid(kWideBlocks, B);
+    hipLaunchKernelGGL(wide_minmax_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, w.cand_cap,
+                       s->approx_consts, w.wsel.as<WideSel>(), w.eps_pair.as<float>());
+    if (!tau_in)
+        for (int pass = 0; pass < 4; ++pass)
+            hipLaunchKernelGGL(wide_hist_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
+                               w.wsel.as<WideSel>(), pass);
+    hipLaunchKernelGGL(wide_count_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
+                       w.wsel.as<WideSel>(), tau_in);
+    hipLaunchKernelGGL(wide_emit_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
+                       (const WideSel*)w.wsel.as<WideSel>(), tau_in, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>());
+    return CLB_OK;
+}
+
 int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
                int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand = nullptr, int phase = 0,
                float* d_local_top = nullptr, const float* d_all_top = nullptr, int n_shards = 0) {
@@ -475,10 +504,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         hipLaunchKernelGGL(global_tau_kernel, dim3(B), dim3(1024), 0, st, d_all_top, n_shards, B, k,
                            w.tau_glob.as<float>());
         Timed t(s, KID_SELECT, st);
-        hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(),
-                           w.ncand.as<int>(), dQ, T, k, w.cand_cap, s->approx_consts, w.list.as<int>(),
-                           w.nlist.as<int>(), w.thresh.as<float>(), w.eps_pair.as<float>(),
-                           (const float*)w.tau_glob.as<float>());
+        CLB_TRY(launch_select(s, w, st, dQ, B, T, k, (const float*)w.tau_glob.as<float>()));
         list = w.list.as<int>();
         nlist = w.nlist.as<int>();
     }
@@ -524,9 +550,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         }
         {
             Timed t(s, KID_SELECT, st);
-            hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(),
-                               w.ncand.as<int>(), dQ, T, k, w.cand_cap, s->approx_consts, w.list.as<int>(),
-                               w.nlist.as<int>(), w.thresh.as<float>(), w.eps_pair.as<float>());
+            CLB_TRY(launch_select(s, w, st, dQ, B, T, k, nullptr));
         }
         list = w.list.as<int>();
         nlist = w.nlist.as<int>();
@@ -775,6 +799,13 @@ int clb_searcher_set_mode(clb_searcher* s, int mode) {
     return CLB_OK;
 }
 int clb_searcher_get_mode(const clb_searcher* s) { return s ? s->mode : -1; }
+
+int clb_searcher_set_wide_select(clb_searcher* s, int on) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (on < -1 || on > 1) return fail(CLB_EARGUMENT, "wide select must be -1 (by candidate capacity), 0 (never) or 1 (always)");
+    s->wide_select = on;
+    return CLB_OK;
+}
 
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {
     if (!s || !consts) return fail(CLB_EARGUMENT, "null argument");

@@ -69,6 +69,10 @@ class Searcher:
     def set_mode(self, mode: int):
         check(lib().clb_searcher_set_mode(self._h, C.c_int(mode)))
 
+    def set_wide_select(self, on: int):
+        """-1: the selection step picks one or sixteen work-groups per query by the candidate capacity; 0 / 1 force it."""
+        check(lib().clb_searcher_set_wide_select(self._h, C.c_int(on)))
+
     @property
     def mode(self) -> int:
         return int(lib().clb_searcher_get_mode(self._h))

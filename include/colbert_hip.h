@@ -109,6 +109,12 @@ int clb_search_shard_phase2_slot(clb_searcher* s, int slot, const float* d_Q, in
  *    index shape supports it (dim 128, nbits 2), else 0. */
 int clb_searcher_set_mode(clb_searcher* s, int mode);
 int clb_searcher_get_mode(const clb_searcher* s);
+/* Selection step of the two-pass mode (the k-th approximate score and the list it cuts; part of search(), no call site of
+ * its own in the reference): one work-group per query, or -- "wide" -- 16 work-groups per query with one launch per radix
+ * pass, for shards whose queries have far more candidates than one work-group holds in registers (10 M passages on one
+ * GPU: ~96 k per query).  on = -1: chosen by the handle's candidate capacity (default), 0: never, 1: always.  The
+ * results are identical either way. */
+int clb_searcher_set_wide_select(clb_searcher* s, int on);
 /* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, [1] = sqrt(dim) * max |bucket
  * weight|, [2] = max over the shard's embeddings of 1/(||c + r|| + eps), [3] = max ||bf16-rounded residual vector||,
  * [4] = sqrt(dim) * max |w - bf16(w)|, [5] = the quantisation error of the packed inv_norm.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE

@@ -219,8 +219,10 @@ def test_encoder_epilogue_bit_exact(oracle):
 # ---------------------------------------------------------------------------------------------------
 # search vs the oracle
 # ---------------------------------------------------------------------------------------------------
-def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0):
+def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0, wide=None):
     s = clb.Searcher(index=idx, pid_offset=pid_offset)
+    if wide is not None:
+        s.set_wide_select(wide)
     refs = [oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k) for j in range(Qs.shape[2])]   # the oracle, once per query
     try:
         for mode in modes:
@@ -369,6 +371,36 @@ def test_search_random_configurations(oracle, seed):
     check_search(oracle, idx, Qs, k=k, nprobe=nprobe)
 
 
+@pytest.mark.parametrize("case", ["many", "few", "ties", "scaled", "uniform"])
+def test_wide_selection_matches_oracle(oracle, case):
+    """The selection step with sixteen work-groups per query and one launch per radix pass (what a 10 M-passage shard
+    takes by default) forced on small indexes: more candidates than one work-group keeps in registers, fewer candidates
+    than k, tied scores, un-normalised queries (the unsafe path lists everything), uniform codes."""
+    if case == "many":
+        idx = synthetic.make_index(seed=27, n_docs=45_000, K=32, doclen_mean=40, doclen_std=8)
+        Qs, k = synthetic.make_queries(idx, 28, 2), 1000
+    elif case == "few":
+        idx = synthetic.make_index(seed=1, n_docs=300, K=64)
+        Qs = synthetic.make_queries(idx, 2, 5)
+        k = min(oracle.search(idx, Qs[:, :, j], nprobe=2, k=1)[2] for j in range(5))      # k = the fewest candidates: n <= k
+    elif case == "ties":
+        idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
+        for p in range(0, 400, 2):
+            idx["codes"][(p + 1) * 16:(p + 2) * 16] = idx["codes"][p * 16:(p + 1) * 16]
+            idx["residuals"][:, (p + 1) * 16:(p + 2) * 16] = idx["residuals"][:, p * 16:(p + 1) * 16]
+        idx["ivf"], idx["ivf_lengths"] = synthetic.build_ivf(idx["codes"], 32)
+        Qs, k = synthetic.make_queries(idx, 18, 9), 60
+    elif case == "scaled":
+        idx = synthetic.make_index(seed=3, n_docs=6000, K=512)
+        Qs = synthetic.make_queries(idx, 4, 8)
+        Qs = np.asfortranarray(Qs * np.float32(1.0e5))                                   # fp16 table overflows: unsafe query
+        k = 200
+    else:
+        idx = synthetic.make_index(seed=5, n_docs=5000, K=512, topical=False)
+        Qs, k = synthetic.make_queries(idx, 6, 11), 100
+    check_search(oracle, idx, Qs, k=k, modes=(1,), wide=1)
+
+
 def test_search_ties_keep_ascending_pid(oracle):
     """Duplicate passages score identically; the stable sortperm keeps the lower pid first."""
     idx = synthetic.make_index(seed=17, n_docs=400, K=32, constant_doclen=True, doclen_mean=16)
@@ -466,8 +498,8 @@ def test_bench_sharding_path_matches_unsharded(oracle):
         s.close()
 
 
-@pytest.mark.parametrize("world,k", [(4, 200), (8, 1000), (2, 5000)])
-def test_two_phase_sharded_search(oracle, world, k):
+@pytest.mark.parametrize("world,k,wide", [(4, 200, -1), (8, 1000, -1), (2, 5000, -1), (4, 200, 1), (2, 5000, 1)])
+def test_two_phase_sharded_search(oracle, world, k, wide):
     """clb_search_shard_phase1/2 on `world` shards of one index (the all-gather is simulated by stacking the shards'
     score blocks): every shard cuts at the global k-th approximate score, the merged result equals the oracle's on
     the full index, and the shards together list far fewer passages than with shard-local thresholds.  k = 5000
@@ -483,6 +515,7 @@ def test_two_phase_sharded_search(oracle, world, k):
     for rank in range(world):
         sh = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8, blocks=range(per * rank, per * rank + per))
         s = clb.Searcher(index=sh, pid_offset=int(sh["pid_offset"]))
+        s.set_wide_select(wide)                                          # 1: the sixteen-work-group selection in both phases
         runs.append(DeviceSearch(s, 32, 9, kk, 2)); keep.append(s)
     tops = torch.stack([r.phase1(Qdev).clone() for r in runs])           # (world, B, k) as an all-gather delivers
     torch.cuda.synchronize()

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--reps", type=int, default=60)
     ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--wide-select", type=int, default=-1, help="-1 by candidate capacity (default), 0 never, 1 always")
     args = ap.parse_args()
     import torch
     import colbert_jl_amd as clb
@@ -22,6 +23,7 @@ def main():
     T, B = 32, args.batch
     idx = synthetic.make_index(seed=2024, n_docs=args.docs, n_blocks=8)
     s = clb.Searcher(index=idx, device=0)
+    s.set_wide_select(args.wide_select)
     Q = synthetic.make_topic_queries(idx["centroids"], seed=77, n_queries=256, T=T)
     Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).cuda()
     run = DeviceSearch(s, T, B, args.k, 2)
@@ -42,7 +44,7 @@ def main():
         torch.cuda.synchronize()
     prof = s.profile_read()
     s.profile_enable(False)
-    out = {"batch": B, "p50_ms": round(float(np.median(lat)) * 1e3, 4), "min_ms": round(float(np.min(lat)) * 1e3, 4),
+    out = {"batch": B, "wide_select": args.wide_select, "p50_ms": round(float(np.median(lat)) * 1e3, 4), "min_ms": round(float(np.min(lat)) * 1e3, 4),
            "kernels_ms": {k: round(v["ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}}
     out["kernels_sum_ms"] = round(sum(out["kernels_ms"].values()), 4)
     print(json.dumps(out))
