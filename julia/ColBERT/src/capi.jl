@@ -30,6 +30,9 @@ function _searcher_create(nbits::Int, centroids::Matrix{Float32}, bucket_weights
     h[]
 end
 _searcher_destroy(h::Ptr{Cvoid}) = ccall((:clb_searcher_destroy, libcolbert), Cint, (Ptr{Cvoid},), h)
+"selection step by one (0) or sixteen (1) work-groups per query; -1 (default): chosen by the candidate capacity"
+_searcher_set_wide_select(h::Ptr{Cvoid}, on::Integer) =
+    _check(ccall((:clb_searcher_set_wide_select, libcolbert), Cint, (Ptr{Cvoid}, Cint), h, on))
 
 "search() after encode_queries (src/searching.jl:102-127): one library call."
 function _search(handle::Ptr{Cvoid}, Q::Matrix{Float32}, nprobe::Int, k::Int)
