@@ -63,7 +63,7 @@ struct Workspace {
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds;
     DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch;   // general-shape path (generic_kernels.hpp)
 };
 
@@ -76,6 +76,7 @@ struct clb_searcher {
     int mode = 0;
     int wide_select = -1;      // selection by kWideBlocks work-groups per query: -1 by candidate capacity, 0 never, 1 always
     bool approx_ok = false;
+    bool ivf_sorted = false;   // every IVF list holds non-decreasing passage ids (mark_count_kernel<true> needs it)
     bool generic = false;      // dim != 128 or nbits == 8: every query takes the general-shape path
     int64_t max_doclen = 0;
     hipStream_t stream = nullptr;
@@ -180,6 +181,11 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     CLB_TRY(w.blocksum.ensure(sizeof(int) * B * w.nblk_bitmap));
     CLB_TRY(w.ncand.ensure(sizeof(int) * B));
     CLB_TRY(w.cand.ensure(sizeof(uint32_t) * B * w.cand_cap));
+    {   // slice boundaries of every selected list (mark_count_kernel<true>, shards of more than 16 slices)
+        const size_t nsl = ((size_t)w.nblk_bitmap + kMarkSliceBlocks - 1) / kMarkSliceBlocks;
+        const size_t nbig = ((size_t)w.nblk_bitmap + kMarkSliceBlocksBig - 1) / kMarkSliceBlocksBig;
+        if (nsl > 16) CLB_TRY(w.bounds.ensure(sizeof(uint32_t) * B * T * nprobe * (nbig + 1)));
+    }
     CLB_TRY(w.cand_hdr.ensure(sizeof(uint2) * B * w.cand_cap));
     CLB_TRY(w.scores.ensure(sizeof(float) * B * w.cand_cap));
     CLB_TRY(w.list.ensure(sizeof(int) * B * w.cand_cap));
@@ -315,16 +321,28 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
     }
     static_assert(kScanBlock * kWordsPerThread == 1024, "mark_count_kernel writes 1024-word count blocks");
     const int nslices = (w.nblk_bitmap + kMarkSliceBlocks - 1) / kMarkSliceBlocks;
-    // every slice re-reads the query's lists: beyond 16 slices (2 M passages per shard) the atomic path is cheaper; and
-    // for a few queries the 64 one-list work-groups of the atomic path finish sooner (one query: 8 us against 27)
-    const bool sliced = nslices <= 16 && B >= 8 && !CLB_KNOB("CLB_DEBUG_ATOMIC_MARK", 0);
+    const int nslices_big = (w.nblk_bitmap + kMarkSliceBlocksBig - 1) / kMarkSliceBlocksBig;
+    // every slice re-reads the query's lists: beyond 16 slices (2 M passages per shard) that costs more than the atomics
+    // it saves -- unless the lists are sorted by passage id: then slice_bounds_kernel cuts every list at the slice
+    // boundaries first (binary searches) and larger slices keep the number of work-groups down.  For a few queries the
+    // 64 one-list work-groups of the atomic path finish sooner (one query: 8 us against 27)
+    const bool sliced = (nslices <= 16 || s->ivf_sorted) && B >= 8 && !CLB_KNOB("CLB_DEBUG_ATOMIC_MARK", 0);
     {
         Timed t(s, KID_MARK, st);
-        if (sliced)     // mark + per-block counts, the bitmap slice of a work-group in LDS (no global atomics)
-            hipLaunchKernelGGL(mark_count_kernel, dim3(nslices, B), dim3(1024), 0, st, w.sel.as<int>(),
+        if (sliced && nslices <= 16)     // mark + per-block counts, the bitmap slice of a work-group in LDS (no global atomics)
+            hipLaunchKernelGGL((mark_count_kernel<false, kMarkSliceBlocks>), dim3(nslices, B), dim3(1024), 0, st, w.sel.as<int>(),
                                s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(),
                                w.blocksum.as<int>(), T, Tpad, NPs, nprobe, w.W, w.nblk_bitmap);
-        else
+        else if (sliced) {
+            const int nb = T * nprobe * (nslices_big + 1);
+            hipLaunchKernelGGL(slice_bounds_kernel, dim3((nb + 255) / 256, B), dim3(256), 0, st, w.sel.as<int>(),
+                               s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), T, Tpad, NPs, nprobe, nslices_big,
+                               (uint32_t)(kMarkSliceBlocksBig * 1024 * 32), w.bounds.as<uint32_t>());
+            hipLaunchKernelGGL((mark_count_kernel<true, kMarkSliceBlocksBig>), dim3(nslices_big, B), dim3(1024), 0, st,
+                               w.sel.as<int>(), s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(),
+                               w.blocksum.as<int>(), T, Tpad, NPs, nprobe, w.W, w.nblk_bitmap,
+                               (const uint32_t*)w.bounds.as<uint32_t>());
+        } else
             hipLaunchKernelGGL(mark_candidates_kernel, dim3(T * nprobe, B), dim3(256), 0, st, w.sel.as<int>(),
                                s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), w.bitmap.as<uint32_t>(), T,
                                Tpad, NPs, nprobe, w.W);
@@ -695,6 +713,8 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
                            s->doc_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), n_emb, (int)n_docs, err.as<int>());
         hipLaunchKernelGGL(codes_to_zero_based_kernel, dim3(blocks), dim3(256), 0, s->stream,
                            s->codes0.as<uint32_t>(), n_emb, (uint32_t)K, err.as<int>());
+        hipLaunchKernelGGL(ivf_lists_sorted_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, s->stream,
+                           s->ivf_off.as<uint32_t>(), s->ivf_pid.as<uint32_t>(), (int)K, err.as<int>());
     }
     int herr = 0;
     if (hipMemcpyAsync(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -702,6 +722,7 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
         return bail(fail(CLB_EHIP, "index upload failed: %s", hipGetErrorString(hipGetLastError())));
     if (herr & 1) return bail(fail(CLB_EBOUNDS, "ivf holds embedding ids outside 1..n_emb"));
     if (herr & 2) return bail(fail(CLB_EDOMAIN, "All the codes must be in the valid range of centroid IDs!"));
+    s->ivf_sorted = !(herr & 4);
 
     if (!s->generic && n_emb > 0 && !CLB_KNOB("CLB_DEBUG_NO_SORT", 0)) {
         // Order every passage's embeddings by centroid code (results cannot change: MaxSim maximises over a passage's

@@ -357,32 +357,78 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* sh /*>=8 int
 // per-block popcounts the emit kernel wants.  kMarkLists lists are in flight per round.
 // grid = (ceil(nblk / kMarkSliceBlocks), B), block = 1024.
 constexpr int kMarkSliceBlocks = 4;
+constexpr int kMarkSliceBlocksBig = 16;   // with slice_bounds_kernel (shards of more than 16 small slices)
 constexpr int kMarkLists = 32;       // IVF lists in flight per round (one entry per thread and list)
 constexpr int kMarkSliceWords = kMarkSliceBlocks * kScanBlock * kWordsPerThread;   // 4096
 
+// SEARCH: shards with more than 16 slices (2 M passages and up).  Re-reading every list in every slice would cost
+// nslices x the list bytes, so the work-group first finds ITS part of each list -- the lists hold non-decreasing
+// passage ids (checked once at load: ivf_lists_sorted_kernel; an index without that property keeps the atomic path) --
+// which slice_bounds_kernel has found for all slices at once (one thread per list and slice boundary: the searches are
+// chains of ~12 dependent loads, far too long to sit in front of every marking work-group -- that version was no faster
+// than the atomic path).
+// bounds[b][l][j] = first entry of list l of query b with passage id >= j * (passages per slice); j = 0..nslices.
+// grid = (ceil(nl * (nslices + 1) / 256), B), block = 256.
+static __global__ __launch_bounds__(256) void slice_bounds_kernel(const int* __restrict__ sel, const uint32_t* __restrict__ ivf_off,
+                                                                  const uint32_t* __restrict__ ivf_pid, int T, int Tpad, int NP,
+                                                                  int nprobe, int nslices, uint32_t slice_passages,
+                                                                  uint32_t* __restrict__ bounds) {
+    const int b = blockIdx.y, nl = T * nprobe;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nl * (nslices + 1)) return;
+    const int l = idx / (nslices + 1), j = idx % (nslices + 1);
+    const int cid = sel[(size_t)b * Tpad * NP + (l / nprobe) * NP + (l % nprobe)];
+    uint32_t a = ivf_off[cid], e = ivf_off[cid + 1];
+    if (j == nslices) {
+        a = e;                                            // everything is below the end of the last slice
+    } else {
+        const uint32_t target = (uint32_t)j * slice_passages;
+        while (a < e) {
+            const uint32_t mid = a + ((e - a) >> 1);
+            if (ivf_pid[mid] < target) a = mid + 1; else e = mid;
+        }
+    }
+    bounds[((size_t)b * nl + l) * (nslices + 1) + j] = a;
+}
+
+// SB = count blocks (1 024 bitmap words = 32 768 passages each) per slice: 4 (16 KB of LDS) for small shards, 16 (64 KB) with
+// SEARCH -- a work-group's fixed costs (zeroing, two rounds of list loads, the write-out) are ~30 us whatever the slice
+// holds, and a 10 M-passage shard has 77 four-block slices per query.
+template <bool SEARCH, int SB>
 static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __restrict__ sel,
                                                                  const uint32_t* __restrict__ ivf_off,
                                                                  const uint32_t* __restrict__ ivf_pid,
                                                                  uint32_t* __restrict__ bitmap,
                                                                  int* __restrict__ blocksum, int T, int Tpad, int NP,
-                                                                 int nprobe, int W, int nblk) {
-    __shared__ uint32_t lbm[kMarkSliceWords];
-    __shared__ int cnt[kMarkSliceBlocks];
+                                                                 int nprobe, int W, int nblk,
+                                                                 const uint32_t* __restrict__ bounds = nullptr) {
+    __shared__ uint32_t lbm[(SB * 1024)];
+    __shared__ int cnt[SB];
     const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < kMarkSliceWords; i += 1024) lbm[i] = 0u;
-    if (tid < kMarkSliceBlocks) cnt[tid] = 0;
+    for (int i = tid; i < (SB * 1024); i += 1024) lbm[i] = 0u;
+    if (tid < SB) cnt[tid] = 0;
     __syncthreads();
     const int* s = sel + (size_t)b * Tpad * NP;
-    const uint32_t p_lo = (uint32_t)slice * kMarkSliceWords * 32u, p_n = (uint32_t)kMarkSliceWords * 32u;
+    const uint32_t p_lo = (uint32_t)slice * (SB * 1024) * 32u, p_n = (uint32_t)(SB * 1024) * 32u;
     const int nl = T * nprobe;
     for (int l0 = 0; l0 < nl; l0 += kMarkLists) {
         uint32_t lo[kMarkLists], hi[kMarkLists], pid[kMarkLists];
+        if (SEARCH) {
+            const uint32_t* bq = bounds + ((size_t)b * nl) * (gridDim.x + 1) + slice;      // [query][list][slice boundary]
 #pragma unroll
-        for (int u = 0; u < kMarkLists; ++u) {
-            const int l = l0 + u < nl ? l0 + u : nl - 1;            // past the end: the last list again (idempotent)
-            const int cid = s[(l / nprobe) * NP + (l % nprobe)];
-            lo[u] = ivf_off[cid];
-            hi[u] = ivf_off[cid + 1];
+            for (int u = 0; u < kMarkLists; ++u) {
+                const int l = l0 + u < nl ? l0 + u : nl - 1;
+                lo[u] = bq[(size_t)l * (gridDim.x + 1)];
+                hi[u] = bq[(size_t)l * (gridDim.x + 1) + 1];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kMarkLists; ++u) {
+                const int l = l0 + u < nl ? l0 + u : nl - 1;            // past the end: the last list again (idempotent)
+                const int cid = s[(l / nprobe) * NP + (l % nprobe)];
+                lo[u] = ivf_off[cid];
+                hi[u] = ivf_off[cid + 1];
+            }
         }
 #pragma unroll
         for (int u = 0; u < kMarkLists; ++u) {
@@ -401,9 +447,9 @@ static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __re
     }
     __syncthreads();
     uint32_t* bm = bitmap + (size_t)b * W;
-    const int w0 = slice * kMarkSliceWords;
+    const int w0 = slice * (SB * 1024);
 #pragma unroll
-    for (int j = 0; j < kMarkSliceBlocks; ++j) {
+    for (int j = 0; j < SB; ++j) {
         const int wi = j * 1024 + tid;
         const uint32_t word = lbm[wi];
         if (w0 + wi < W) bm[w0 + wi] = word;
@@ -413,8 +459,8 @@ static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __re
         if ((tid & 63) == 0 && c) atomicAdd(&cnt[j], c);
     }
     __syncthreads();
-    if (tid < kMarkSliceBlocks && slice * kMarkSliceBlocks + tid < nblk)
-        blocksum[(size_t)b * nblk + slice * kMarkSliceBlocks + tid] = cnt[tid];
+    if (tid < SB && slice * SB + tid < nblk)
+        blocksum[(size_t)b * nblk + slice * SB + tid] = cnt[tid];
 }
 
 // grid = (nblk, B)
@@ -1239,6 +1285,18 @@ static __global__ void ivf_to_pid_kernel(const int64_t* __restrict__ ivf, const 
         if ((int64_t)doc_off[mid] <= eid) lo = mid; else hi = mid;
     }
     ivf_pid[i] = (uint32_t)lo;
+}
+
+// *unsorted |= 4 when some IVF list does not hold non-decreasing passage ids (the reference's sortperm-built lists do).
+// One wave per list.  grid = ceil(K / 4), block = 256.
+static __global__ void ivf_lists_sorted_kernel(const uint32_t* __restrict__ ivf_off, const uint32_t* __restrict__ ivf_pid,
+                                               int K, int* __restrict__ unsorted) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= K) return;
+    const uint32_t lo = ivf_off[c], hi = ivf_off[c + 1];
+    bool bad = false;
+    for (uint32_t i = lo + 1 + lane; i < hi; i += 64) bad |= ivf_pid[i] < ivf_pid[i - 1];
+    if (bad) atomicOr(unsorted, 4);
 }
 
 // Load-time reordering of every passage's embeddings by centroid code (MaxSim takes a maximum over a passage's

@@ -539,6 +539,38 @@ def test_two_phase_sharded_search(oracle, world, k, wide):
         s.close()
 
 
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_candidate_marking_large_shard(oracle, shuffled):
+    """More than 16 bitmap slices (2.2 M passages): a batch marks its candidates slice by slice, every slice cutting its part
+    out of each IVF list by binary search -- valid because the lists hold non-decreasing passage ids.  With the entries of
+    every list shuffled (the reference never needs an order inside a list) the handle must notice at load and keep the
+    atomic path.  Candidates and results equal the oracle's either way."""
+    idx = synthetic.make_index(seed=61, n_docs=2_200_000, K=4096, doclen_mean=3, doclen_std=1)
+    if shuffled:
+        rng = np.random.default_rng(62)
+        ivf = idx["ivf"].copy()
+        off = np.concatenate([[0], np.cumsum(idx["ivf_lengths"])])
+        for c in rng.integers(0, 4096, size=600):                  # enough lists to hit the probed ones
+            ivf[off[c]:off[c + 1]] = rng.permutation(ivf[off[c]:off[c + 1]])
+        top = np.argsort(idx["ivf_lengths"])[-64:]
+        for c in top:
+            ivf[off[c]:off[c + 1]] = rng.permutation(ivf[off[c]:off[c + 1]])
+        idx = dict(idx, ivf=ivf)
+    Qs = synthetic.make_queries(idx, 63, 8)                        # 8: the smallest batch that marks slice by slice
+    s = clb.Searcher(index=idx)
+    try:
+        bp, bs, bn = s.search_batch(Qs, 100, nprobe=2)
+        for j in (0, 3, 7):
+            rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=2, k=100)
+            assert bn[j] == rn and np.array_equal(bp[:, j], rp), j
+            assert_same_f32(bs[:, j], rs, f"large shard q={j}")
+        cand = s.retrieve(Qs[:, :, 0])
+        assert np.array_equal(cand, oracle.retrieve(idx["ivf"], idx["ivf_lengths"], idx["centroids"],
+                                                    oracle.build_emb2pid(idx["doclens"]), 2, Qs[:, :, 0]))
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("n_docs", [131071, 131073, 262145])
 def test_candidate_bitmap_slice_boundaries(oracle, n_docs):
     """Batches mark their candidates in LDS slices of 131 072 passages (mark_count_kernel): corpora that end one passage
