@@ -542,8 +542,12 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
             // run of passages -- the pipeline fill otherwise dominates.
             const int approx_2d = CLB_KNOB("CLB_DEBUG_APPROX_2D", -1);
             const double est_cand = 0.5 * T * nprobe * (double)s->n_emb / (double)std::max<int64_t>(1, s->K);
-            const int gx2d = approx_2d >= 0 ? approx_2d : (est_cand < 6000.0 ? 256 : 0);
-            const dim3 approx_grid = gx2d > 0 && B > 1 ? dim3(std::max(1, gx2d / B), B) : dim3(8 * wgpg);
+            // work-groups per query of the (G, B) launch (0 = the 1-D launch): enough to fill the chip for small batches,
+            // eight for large ones (measured at 4 and 8 shards, B = 8 ... 256: one or two per query cost 12 % of the pass
+            // at B = 256, sixteen and more cost as much at B = 32)
+            int gxq = est_cand < 6000.0 ? std::max(8, 256 / B) : 0;
+            if (approx_2d >= 0) gxq = approx_2d > 0 ? std::max(1, approx_2d / B) : 0;
+            const dim3 approx_grid = gxq > 0 && B > 1 ? dim3(gxq, B) : dim3(8 * wgpg);
 #define CLB_LAUNCH_APPROX(ABL)                                                                                        \
     hipLaunchKernelGGL((score_approx32_kernel<false, ABL>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(), \
                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,  \
