@@ -74,6 +74,73 @@ def test_two_rank_sharded_search_equals_unsharded(k, packed):
     assert q.get(timeout=5) is True
 
 
+def _worker_two_phase(rank, world, port, k, q):
+    """The two-phase protocol of the sharded search over gloo: phase 1 publishes the shard's k largest scores per query,
+    `all_gather_scores` moves them, the k-th largest of the union is the global threshold, phase 2 returns only the
+    shard's passages at or above it, one packed all-gather + merge.  The oracle's exact scores stand in for the approximate
+    ones (a bound of zero), so the merged result must be the unsharded top-k and the shards together must list exactly
+    k passages per query (more only through ties at the threshold)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import colbert_jl_amd as clb
+    from colbert_jl_amd.distributed import all_gather_packed, all_gather_scores, merge_packed, pack_topk
+    from colbert_jl_amd.sharding import shard_index
+    from oracle import oracle as orc
+    orc.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = clb.synthetic.make_index(seed=45, n_docs=1500, K=128)
+    Qs = clb.synthetic.make_queries(idx, 46, 4)
+    B = Qs.shape[2]
+    sub, off = shard_index(idx, rank, world)
+    local = []
+    top = torch.full((B, k), -np.inf, dtype=torch.float32)
+    for b in range(B):                                    # phase 1: every candidate of the shard, best first
+        n = orc.retrieve(sub["ivf"], sub["ivf_lengths"], sub["centroids"], orc.build_emb2pid(sub["doclens"]), 2, Qs[:, :, b]).size
+        p, s = (np.zeros(0, np.int64), np.zeros(0, np.float32)) if n == 0 else orc.search(sub, Qs[:, :, b], 2, n)[:2]
+        local.append((p + off, s))
+        top[b, :min(k, n)] = torch.from_numpy(s[:k].copy())
+    gathered = all_gather_scores(top)                     # (world, B, k)
+    assert gathered.shape == (world, B, k) and torch.equal(gathered[rank], top)
+    tau = torch.sort(gathered.permute(1, 0, 2).reshape(B, world * k), dim=1, descending=True).values[:, k - 1]
+    P = torch.zeros((B, k), dtype=torch.int64); S = torch.full((B, k), -np.inf, dtype=torch.float32)
+    listed = torch.zeros(B, dtype=torch.int64)
+    for b in range(B):                                    # phase 2: only what reaches the global threshold
+        p, s = local[b]
+        keep = s >= tau[b].item()
+        kk = min(k, int(keep.sum()))
+        P[b, :kk] = torch.from_numpy(p[keep][:kk]); S[b, :kk] = torch.from_numpy(s[keep][:kk])
+        listed[b] = int(keep.sum())
+    mp, ms = merge_packed(all_gather_packed(pack_topk(P, S)), B, k)
+    dist.all_reduce(listed)
+    if rank == 0:
+        ok = True
+        for b in range(B):
+            rp, rs, _ = orc.search(idx, Qs[:, :, b], 2, k)
+            ok = ok and np.array_equal(mp[b].numpy(), rp) and np.array_equal(ms[b].numpy().view(np.uint32), rs.view(np.uint32))
+            ok = ok and k <= int(listed[b]) <= k + 8
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_two_phase_protocol():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_phase, args=(r, 2, port, 100, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_shard_bounds_balance_embeddings():
     sys.path.insert(0, ROOT)
     import colbert_jl_amd as clb
