@@ -2,6 +2,8 @@
 oracle on the same seeded inputs, against the reference's golden vectors, and -- at BASELINE.json's
 sizes -- through size-independent properties.  Bar: pids bit-exact, fp32 scores bit-exact against the
 oracle's canonical arithmetic (tolerance 0; north_star allows 1e-4), bytes/indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -158,7 +160,7 @@ def test_codec_stats_match_oracle(oracle):
         assert np.isclose(avg, ravg, rtol=1e-6)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("COLBERT_TEST_FUZZ_SEEDS", "8"))))
 def test_index_build_stages_random_configurations(oracle, seed):
     """The index-build stages chained at randomly drawn shapes (dim a multiple of 8, nbits, K, sample and chunk sizes,
     k-means batch size): every stage's output is bit-identical to the oracle's, and each stage is fed the PRODUCT's
@@ -333,7 +335,7 @@ def test_search_many_candidates(oracle):
     check_search(oracle, idx, Qs, k=1000)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("COLBERT_TEST_FUZZ_SEEDS", "10"))))   # more seeds for a one-off sweep
 def test_search_random_configurations(oracle, seed):
     """Randomly drawn shapes (corpus size, centroid count, nbits, passage lengths, query length, batch, k, nprobe,
     topical or uniform codes, scaled queries): pids identical and scores bit-identical to the oracle, both modes."""
