@@ -7,6 +7,12 @@ A step = one pass of the search hot path (centroid scoring -> candidates -> fuse
 that are already resident in HBM.  The passage collection is sharded over the N ranks (strong scaling:
 the corpus is fixed).  Prints ONE JSON line on rank 0.
 
+Besides the headline the line carries (N = 1): `worst_case_uniform_codes` (the same corpus size with uniformly drawn
+centroid codes: no id-adjacent codes, the largest candidate sets), `built_index` (BASELINE config 2: 100k passages
+of mixture embeddings -> this repo's own k-means / codec / compress / IVF build -> search, oracle-checked, with an
+`index_build` record) and `batch_sweep` (N = 1 at the batch sizes the N-GPU runs use); for N > 1: `fixed_batch_32`
+(the same 32-query batch at every N) and `single_exchange` (one all-gather per batch instead of two).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--batch B] [--mode {0,1}]
 """
 import argparse
@@ -30,20 +36,22 @@ FLOP_PER_EMB = 8192.0        # 2 * 32 * 128
 
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
-    has touched HIP or imported torch, wait for them, and forward rank 0's single JSON line.  Never re-execs."""
-    import socket
+    has touched HIP or imported torch, wait for them, and forward rank 0's single JSON line.  Never re-execs.  The
+    ranks meet through a file store (no port is picked here, so there is nothing to race for)."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+    import threading
+    store = tempfile.NamedTemporaryFile(prefix="colbert_bench_store_", delete=False)
+    store.close()
+    os.unlink(store.name)
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   COLBERT_BENCH_INIT_FILE=store.name,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # wait for all ranks; a rank that dies must not leave the others waiting in a collective forever
-    import threading
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
@@ -60,11 +68,192 @@ def launch_ranks(args):
         time.sleep(0.2)
     rcs = [p.wait() for p in procs]
     reader.join(timeout=10)
+    try:
+        os.unlink(store.name)
+    except OSError:
+        pass
     out = b"".join(c for c in chunks if c)
     if failed is None:
         sys.stdout.write(out.decode())
         sys.stdout.flush()
     return failed[1] if failed else next((rc for rc in rcs if rc), 0)
+
+
+def roofline_of(kname, prof, stats, mode, T, K, B):
+    """Roofline record of one search kernel: ALGORITHMIC bytes / flops of a launch over its HIP-event time."""
+    ms_launch = prof[kname]["ms"] / max(prof[kname]["launches"], 1)
+    embs, docs = stats["cand_embs"], stats["cand_docs"]
+    if kname == "score_exact" and mode == 1:
+        embs, docs = stats["rescored_embs"], stats["rescored_docs"]
+    if kname == "score_exact":
+        ach = FLOP_PER_EMB * embs / (ms_launch * 1e-3) / 1e12
+        r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
+             "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
+    elif kname == "centroid_scores":
+        # S1 runs as three bf16 MFMA products per fp32 product (bf16x3 split): count the bf16 flops it
+        # really issues against the dense bf16 peak
+        ach = 3 * 2.0 * 128 * T * K * B / (ms_launch * 1e-3) / 1e12
+        r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TF,
+             "unit": "TFLOP/s (bf16, 3 products per fp32 product)", "frac": round(ach / BF16_MFMA_PEAK_TF, 4)}
+        embs, docs = K * B, 0
+    else:
+        alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
+        ach = alg_bytes / (ms_launch * 1e-3) / 1e9
+        r = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4)}
+    r["ms_per_launch"] = round(ms_launch, 4)
+    r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
+    return r
+
+
+def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_queries, dev, in_flight=2, T=32):
+    """A short single-GPU measurement of one workload (the sub-records of the line): sustained queries/s with
+    `in_flight` batches in flight, the per-kernel HIP-event times of a one-batch-at-a-time pass with the roofline of
+    pass 1, candidates per query, and `cpu_queries` queries checked against the CPU oracle (pids identical, scores
+    within 1e-4)."""
+    from colbert_jl_amd.distributed import DeviceSearch
+    K = int(np.asarray(index["centroids"]).shape[1])
+    n_queries = Q.shape[2]
+    Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).to(dev)               # (nq, T, dim)
+    NF = max(1, min(4, in_flight))
+    runs = [DeviceSearch(s, T, B, k, nprobe, slot=i) for i in range(NF)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
+
+    def step(i, overlap=True):
+        off = (i * B) % (n_queries - B + 1)
+        with torch.cuda.stream(streams[i % NF] if overlap else streams[0]):
+            return runs[i % NF](Qdev[off:off + B])
+
+    def timed(n, overlap=True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i, overlap)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for i in range(3):
+        step(i)
+    probe = timed(steps)
+    reps = max(1, int(np.ceil(min_seconds / max(probe, 1e-6))))
+    n = reps * steps
+    dt = timed(n)
+    serial = timed(steps, overlap=False)
+    s.profile_enable(True)
+    timed(steps, overlap=False)
+    prof = s.profile_read()
+    s.profile_enable(True, counters=True)
+    step(0, overlap=False)
+    torch.cuda.synchronize()
+    stats = s.last_batch_stats()
+    s.profile_read()
+    s.profile_enable(False)
+    rec = {"value": round(B * n / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n,
+           "seconds": round(dt, 4), "batch": B, "batches_in_flight": NF,
+           "one_batch_at_a_time": {"value": round(B * steps / serial, 2), "ms_per_step": round(serial / steps * 1e3, 4)},
+           "candidates_per_query": {"passages": round(stats["cand_docs"] / B, 1), "embeddings": round(stats["cand_embs"] / B, 1),
+                                    "rescored_passages": round(stats["rescored_docs"] / B, 1)}}
+    if prof:
+        dom = "score_approx" if "score_approx" in prof and prof["score_approx"]["launches"] else max(prof.items(), key=lambda kv: kv[1]["ms"])[0]
+        roof = roofline_of(dom, prof, stats, s.mode, T, K, B)
+        roof["traffic"] = None
+        roof["traffic_source"] = "null: profiles/pmc_summary.json is measured on the headline workload only"
+        roof["all_kernels_ms_per_step"] = {kn: round(v["ms"] / max(steps, 1), 4) for kn, v in prof.items()}
+        rec["roofline"] = roof
+    if cpu_queries > 0:
+        from oracle import oracle as orc
+        orc.build()
+        idx = dict(index, emb2pid=orc.build_emb2pid(index["doclens"]))
+        r = runs[0]
+        with torch.cuda.stream(streams[0]):
+            r(Qdev[0:B])
+        torch.cuda.synchronize()
+        gp, gs = r.out_p.cpu().numpy(), r.out_s.cpu().numpy()
+        ok, t_cpu = True, 0.0
+        nq = min(cpu_queries, B)
+        for j in range(nq):
+            t1 = time.perf_counter()
+            rp, rs, _ = orc.search(idx, Q[:, :, j], nprobe, k)
+            t_cpu += time.perf_counter() - t1
+            ok = ok and bool(np.array_equal(rp, gp[j])) and bool(np.max(np.abs(rs - gs[j])) <= 1e-4)
+        rec["gpu_matches_cpu_top_k"] = ok
+        rec["cpu_baseline"] = {"value": round(nq / t_cpu, 4), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
+                               "sample": f"{nq} queries of this workload, one at a time, OpenMP over the host cores"}
+    return rec
+
+
+def build_config2_index(clb, docs, kmeans_iters, device):
+    """BASELINE config 2: `docs` passages of mixture embeddings through THIS repo's index build -- sample, k-means,
+    codec statistics, compress, IVF (src/indexing.jl:63-147, collection_indexer.jl:219-237,349-353) -- timed per stage.
+    The stand-alone entry points take host buffers, so their PCIe copies are inside the stage times."""
+    from colbert_jl_amd import codec, synthetic
+    t0 = time.time()
+    embs, doclens = synthetic.make_embeddings(seed=61, n_docs=docs)
+    t_gen = time.time() - t0
+    n_emb = embs.shape[1]
+    rng = np.random.default_rng(62)
+    t0 = time.time()
+    n_s = codec.num_sampled_pids(docs)
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    pids = np.unique(rng.integers(0, docs, size=n_s))
+    cols = np.concatenate([np.arange(off[p], off[p + 1]) for p in pids])
+    sample = np.asfortranarray(embs[:, rng.permutation(cols)])
+    h = codec.heldout_size(sample.shape[1])
+    sample, held = sample[:, :-h], sample[:, -h:]
+    plan = codec.setup(docs, float(doclens[pids].mean()), sample.shape[1], 25000, 1)
+    K = plan["num_partitions"]
+    init = sample[:, rng.permutation(sample.shape[1])[:K]]
+    t_sample = time.time() - t0
+    rec = {"passages": int(docs), "embeddings": int(n_emb), "sample_points": int(sample.shape[1]), "K": int(K),
+           "generate_input_s": round(t_gen, 1), "sample_and_split_s": round(t_sample, 2)}
+    t0 = time.time()
+    cent, _, it = codec.kmeans(sample, init, max_iters=kmeans_iters, device=device)
+    dt = time.time() - t0
+    it = max(int(it), 1)
+    rec["kmeans_s"] = round(dt, 3)
+    rec["kmeans_iters"] = it
+    rec["kmeans_s_per_iter"] = round(dt / it, 3)
+    # assignment = three bf16 MFMA products per fp32 product (bf16x3 split): bf16 flops against the dense bf16 peak
+    bf16_tf = 3 * 2.0 * 128 * sample.shape[1] * K * it / dt / 1e12
+    rec["kmeans_roofline"] = {"bound": "mfma", "achieved": round(bf16_tf, 1), "peak": BF16_MFMA_PEAK_TF,
+                              "unit": "TFLOP/s (bf16, 3 products per fp32 product; host copies and the centroid update inside the time)",
+                              "frac": round(bf16_tf / BF16_MFMA_PEAK_TF, 4)}
+    t0 = time.time()
+    cut, w, avg, _ = codec.compute_avg_residuals(2, cent, held, device=device)
+    rec["codec_stats_s"] = round(time.time() - t0, 3)
+    t0 = time.time()
+    chunk = 2_000_000
+    parts = [codec.compress(cent, cut, 128, 2, embs[:, i:i + chunk], device=device) for i in range(0, n_emb, chunk)]
+    dt = time.time() - t0
+    codes = np.concatenate([p[0] for p in parts])
+    residuals = np.asfortranarray(np.concatenate([p[1] for p in parts], axis=1))
+    rec["compress_s"] = round(dt, 3)
+    rec["compress_Membeddings_per_s"] = round(n_emb / dt / 1e6, 2)
+    t0 = time.time()
+    ivf, lens = codec.build_ivf(codes, K, device=device)
+    rec["build_ivf_s"] = round(time.time() - t0, 3)
+    assert int(lens.sum()) == n_emb
+    rec["total_build_s"] = round(rec["sample_and_split_s"] + rec["kmeans_s"] + rec["codec_stats_s"] + rec["compress_s"] + rec["build_ivf_s"], 2)
+    index = {"dim": 128, "nbits": 2, "centroids": cent, "bucket_weights": w, "bucket_cutoffs": cut, "doclens": doclens,
+             "codes": codes, "residuals": residuals, "ivf": ivf, "ivf_lengths": lens, "pid_offset": 0}
+    return index, rec
+
+
+def encoder_l2_operand_bytes(M, N, Kd):
+    """fp32 operand bytes the work-groups of one Linear layer pull through L2, mirroring linear_split's tile choice
+    (csrc/encoder.hip): every work-group streams its A rows and B rows of the K range it owns."""
+    def wgs(bm, bn):
+        return -(-N // bn) * -(-M // bm)
+    if wgs(128, 128) >= 384:
+        bm, bn, ks = 128, 128, 1
+    elif wgs(64, 128) >= 384 and N >= 128:
+        bm, bn, ks = 64, 128, 1
+    else:
+        bm, bn, ks = 64, 64, 1
+        min_slice = 192 if wgs(64, 64) < 64 else 256
+        while ks < 8 and wgs(64, 64) * ks < 512 and Kd % (ks * 2 * 32) == 0 and Kd // (ks * 2) >= min_slice:
+            ks *= 2
+    return wgs(bm, bn) * (bm + bn) * Kd * 4, (bm, bn, ks)
 
 
 def main():
@@ -84,13 +273,19 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-at-a-time latency loop (profiling runs)")
     ap.add_argument("--force-gather", action="store_true", help="exercise the all-gather + merge path even with one rank (testing)")
     ap.add_argument("--uniform-codes", action="store_true",
-                    help="passages draw their centroid codes uniformly (worst case for the candidate count) instead of topically")
+                    help="the HEADLINE corpus draws its centroid codes uniformly (worst case for the candidate count) instead of topically")
     ap.add_argument("--no-overlap", action="store_true", help="one compute stream: batches strictly one after the other")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight (compute streams / workspace slots), 1..4")
     ap.add_argument("--no-encoder", action="store_true",
                     help="skip the second measurement with the query encoder (bert-base geometry) in front of the search")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="the timed region is repeated (whole multiples of --steps) until it lasts at least this long")
+    ap.add_argument("--no-sub", action="store_true",
+                    help="headline only: skip worst_case_uniform_codes, built_index and batch_sweep (profiling runs)")
+    ap.add_argument("--built-index", action="store_true",
+                    help="make the config-2 built index (100k passages through this repo's own index build) the HEADLINE workload")
+    ap.add_argument("--built-docs", type=int, default=100_000, help="passages of the built_index workload (BASELINE config 2)")
+    ap.add_argument("--built-kmeans-iters", type=int, default=20, help="k-means iterations of the built index (reference default)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -109,42 +304,58 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1 or args.force_gather:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         # COLBERT_BENCH_BACKEND / COLBERT_BENCH_DEVICE: test hooks to run several ranks on ONE GPU over gloo
         # (RCCL refuses two ranks on the same device); the measured configuration is always nccl, one GPU per rank
         backend = os.environ.get("COLBERT_BENCH_BACKEND", "nccl")
         if "COLBERT_BENCH_DEVICE" in os.environ:
             local_rank = int(os.environ["COLBERT_BENCH_DEVICE"])
+        kw = {}
+        if "COLBERT_BENCH_INIT_FILE" in os.environ:     # started by launch_ranks: file rendezvous, no port to pick
+            kw["init_method"] = "file://" + os.environ["COLBERT_BENCH_INIT_FILE"]
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     if world != args.gpus:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different job size",
               file=sys.stderr)
         sys.exit(2)
-    ranks_seen = world
-    if world > 1 or args.force_gather:
-        ranks_seen = dist.get_world_size()
-        if ranks_seen != args.gpus and not args.force_gather:
-            print(f"[bench] the process group has {ranks_seen} ranks, --gpus {args.gpus}", file=sys.stderr)
-            sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = world
+    if world > 1 or args.force_gather:
+        # counted by the communicator that moves the data (RCCL when the backend is nccl): every rank adds one
+        one_t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one_t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one_t.item())
+        if ranks_seen != args.gpus and not args.force_gather:
+            print(f"[bench] the communicator counts {ranks_seen} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
     # ---- this rank's passage shard (generated directly, identical to the same passages of the full index)
     T, B, k = 32, (args.batch if args.batch > 0 else min(32 * world, 256)), args.k
     n_blocks = 8
     assert n_blocks % world == 0, "shards are aligned to the 8 generation blocks: use 1, 2, 4 or 8 GPUs"
     per = n_blocks // world
+    index_build = None
     t0 = time.time()
-    K = synthetic.num_partitions_for(args.docs, 80.0)
-    shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks,
-                                 blocks=range(rank * per, (rank + 1) * per), topical=not args.uniform_codes)
+    if args.built_index:
+        assert world == 1, "--built-index is a single-GPU workload (BASELINE config 2)"
+        shard, index_build = build_config2_index(clb, args.built_docs, args.built_kmeans_iters, local_rank)
+        K = int(shard["centroids"].shape[1])
+        n_docs_total = args.built_docs
+    else:
+        K = synthetic.num_partitions_for(args.docs, 80.0)
+        shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks,
+                                     blocks=range(rank * per, (rank + 1) * per), topical=not args.uniform_codes)
+        n_docs_total = args.docs
     t_gen = time.time() - t0
     t0 = time.time()
     s = clb.Searcher(index=shard, device=local_rank, pid_offset=int(shard["pid_offset"]))
@@ -155,7 +366,10 @@ def main():
         sync_bound_consts(s)            # one error bound on every shard (the threshold of the two-phase search is global)
     t_load = time.time() - t0
     n_queries = max(B * 8, 256)
-    Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=n_queries, T=T)   # (dim, T, nq)
+    if args.built_index:
+        Q = synthetic.make_queries(shard, seed=77, n_queries=n_queries, T=T)
+    else:
+        Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=n_queries, T=T)   # (dim, T, nq)
     Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).to(dev)               # (nq, T, dim)
     gather = world > 1 or args.force_gather
     # Two result buffers alternate so that the exchange of batch i (one RCCL all-gather of the packed per-shard
@@ -164,63 +378,75 @@ def main():
     # the latency-bound kernels of one batch (selection, top-k: one work-group per query) overlap the scoring kernels
     # of the other.  --no-overlap puts every batch on one stream.
     NF = max(1, min(4, args.in_flight))
-    runs = [DeviceSearch(s, T, B, k, args.nprobe, slot=i) for i in range(NF)]
-    run = runs[0]
     compute = [torch.cuda.Stream(device=dev) for _ in range(NF)]
-    merged = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev))
-              for _ in range(NF)]
     comm = torch.cuda.Stream(device=dev) if gather else None
-    free_ev = [None] * NF          # buffer set i may be overwritten once its exchange has finished
     # With several shards the search runs in two phases around a second, small all-gather (every shard's k largest
     # approximate scores): all shards then cut at the GLOBAL k-th score and re-score ~k/N passages each instead of
     # ~k.  COLBERT_BENCH_TWO_PHASE=0/1 overrides.
-    two_phase = gather and s.mode == 1 and (world >= 2 if "COLBERT_BENCH_TWO_PHASE" not in os.environ
-                                            else os.environ["COLBERT_BENCH_TWO_PHASE"] == "1")
+    two_phase_default = gather and s.mode == 1 and (world >= 2 if "COLBERT_BENCH_TWO_PHASE" not in os.environ
+                                                    else os.environ["COLBERT_BENCH_TWO_PHASE"] == "1")
     import torch.distributed as _dist
-    gath = [torch.empty((max(world, 1) * B, k), dtype=torch.float32, device=dev) for _ in range(NF)] if two_phase else None
-
-    def search_shard(r, Qb, i):
-        """This rank's part of one batch on the main stream (results in r.packed)."""
-        if not two_phase:
-            r(Qb)
-            return
-        main = torch.cuda.current_stream(dev)
-        lt = r.phase1(Qb)
-        e1 = torch.cuda.Event()
-        e1.record(main)
-        with torch.cuda.stream(comm):
-            comm.wait_event(e1)
-            _dist.all_gather_into_tensor(gath[i % NF], lt)
-            e2 = torch.cuda.Event()
-            e2.record(comm)
-        main.wait_event(e2)
-        r.phase2(Qb, gath[i % NF].view(world, B, k))
-
     overlap = [not args.no_overlap]
 
-    def step(i):
-        with torch.cuda.stream(compute[i % NF] if overlap[0] else compute[0]):
-            return step_on_current_stream(i)
+    class Plan:
+        """One batch size / exchange mode: its DeviceSearch objects (one per batch in flight), result buffers, and the
+        step that runs batch i."""
 
-    def step_on_current_stream(i):
-        off = (i * B) % (n_queries - B + 1)
-        r = runs[i % NF]
-        if not gather:
-            return r(Qdev[off:off + B])
-        main = torch.cuda.current_stream(dev)
-        if free_ev[i % NF] is not None:
-            main.wait_event(free_ev[i % NF])
-        search_shard(r, Qdev[off:off + B], i)
-        done = torch.cuda.Event()
-        done.record(main)
-        with torch.cuda.stream(comm):
-            comm.wait_event(done)
-            g = all_gather_packed(r.packed)
-            out = merge_packed(g, B, k, out_p=merged[i % NF][0], out_s=merged[i % NF][1])
-            ev = torch.cuda.Event()
-            ev.record(comm)
-            free_ev[i % NF] = ev
-        return out
+        def __init__(self, Bp, two_phase):
+            self.B, self.two_phase = Bp, two_phase
+            self.runs = [DeviceSearch(s, T, Bp, k, args.nprobe, slot=i) for i in range(NF)]
+            self.merged = [(torch.empty((Bp, k), dtype=torch.int64, device=dev), torch.empty((Bp, k), dtype=torch.float32, device=dev))
+                           for _ in range(NF)]
+            self.free_ev = [None] * NF          # buffer set i may be overwritten once its exchange has finished
+            self.gath = [torch.empty((max(world, 1) * Bp, k), dtype=torch.float32, device=dev) for _ in range(NF)] if two_phase else None
+
+        def search_shard(self, r, Qb, i):
+            """This rank's part of one batch on the current stream (results in r.packed)."""
+            if not self.two_phase:
+                r(Qb)
+                return
+            main = torch.cuda.current_stream(dev)
+            lt = r.phase1(Qb)
+            e1 = torch.cuda.Event()
+            e1.record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(e1)
+                _dist.all_gather_into_tensor(self.gath[i % NF], lt)
+                e2 = torch.cuda.Event()
+                e2.record(comm)
+            main.wait_event(e2)
+            r.phase2(Qb, self.gath[i % NF].view(world, self.B, k))
+
+        def queries(self, i):
+            off = (i * self.B) % (n_queries - self.B + 1)
+            return Qdev[off:off + self.B]
+
+        def step(self, i):
+            with torch.cuda.stream(compute[i % NF] if overlap[0] else compute[0]):
+                return self.step_on_current_stream(i, self.queries(i))
+
+        def step_on_current_stream(self, i, Qb):
+            r = self.runs[i % NF]
+            if not gather:
+                return r(Qb)
+            main = torch.cuda.current_stream(dev)
+            if self.free_ev[i % NF] is not None:
+                main.wait_event(self.free_ev[i % NF])
+            self.search_shard(r, Qb, i)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(done)
+                g = all_gather_packed(r.packed)
+                out = merge_packed(g, self.B, k, out_p=self.merged[i % NF][0], out_s=self.merged[i % NF][1])
+                ev = torch.cuda.Event()
+                ev.record(comm)
+                self.free_ev[i % NF] = ev
+            return out
+
+    plan = Plan(B, two_phase_default)
+    two_phase = two_phase_default
+    run = plan.runs[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -228,12 +454,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, first):
+    def timed(n_steps, first, pl=None):
         """n_steps steps between two barrier + synchronize pairs; MAX over ranks of the wall time."""
+        pl = pl or plan
         barrier()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            step(first + i)
+            pl.step(first + i)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -242,23 +469,27 @@ def main():
             dt = float(tmax.item())
         return dt
 
-    # (0) pre-conditioning + the sustained figure: the same loop repeated in whole multiples of --steps until the region
-    #     lasts --min-seconds (a 20-step region is ~25 ms: too short to trust on its own, and a GPU that has just
-    #     come out of index generation idles at a low clock); every rank uses the same count
-    for i in range(args.warmup):
-        step(i)
-    probe = timed(args.steps, args.warmup)
-    reps = max(1, int(np.ceil(args.min_seconds / max(probe, 1e-6))))
-    if world > 1:
-        r_t = torch.tensor([reps], dtype=torch.int64, device=dev)
-        dist.all_reduce(r_t, op=dist.ReduceOp.MAX)
-        reps = int(r_t.item())
-    sustained_steps = reps * args.steps
-    sustained_s = timed(sustained_steps, args.warmup + args.steps)
+    def sustained_of(pl, min_seconds):
+        """The same loop repeated in whole multiples of --steps until the region lasts `min_seconds`; every rank uses the
+        same count."""
+        for i in range(args.warmup):
+            pl.step(i)
+        probe = timed(args.steps, args.warmup, pl)
+        reps = max(1, int(np.ceil(min_seconds / max(probe, 1e-6))))
+        if world > 1:
+            r_t = torch.tensor([reps], dtype=torch.int64, device=dev)
+            dist.all_reduce(r_t, op=dist.ReduceOp.MAX)
+            reps = int(r_t.item())
+        n = reps * args.steps
+        return n, timed(n, args.warmup + args.steps, pl)
+
+    # (0) pre-conditioning + the sustained figure (a 20-step region is ~25 ms: too short to trust on its own, and a GPU
+    #     that has just come out of index generation idles at a low clock)
+    sustained_steps, sustained_s = sustained_of(plan, args.min_seconds)
     # (1) the contract's measurement on the warm device: --warmup untimed steps, then exactly --steps steps between
     #     barrier + synchronize pairs, per-kernel event timing OFF
     for i in range(args.warmup):
-        step(i)
+        plan.step(i)
     elapsed = timed(args.steps, args.warmup)
     qps = B * args.steps / elapsed
     # (3) a separate pass with HIP events around every kernel (on the stream they are launched on) for the roofline
@@ -276,7 +507,7 @@ def main():
     # ---- batches in flight do not disturb each other: one batch computed alone == the same batch computed in the middle
     # of NF batches in flight on NF streams (every rank checks its own results)
     def result_of(i):
-        out = step(i)
+        out = plan.step(i)
         st = comm if gather else (compute[i % NF] if overlap[0] else compute[0])
         with torch.cuda.stream(st):
             return out[0].clone(), out[1].clone()
@@ -288,10 +519,10 @@ def main():
     barrier()
     overlap[0] = was
     for i in range(probe_i - NF, probe_i):
-        step(i)
+        plan.step(i)
     busy = result_of(probe_i)
     for i in range(probe_i + 1, probe_i + 1 + NF):
-        step(i)
+        plan.step(i)
     barrier()
     in_flight_ok = bool(torch.equal(alone[0], busy[0]) and torch.equal(alone[1], busy[1]))
     if world > 1:
@@ -299,11 +530,29 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         in_flight_ok = bool(okt.item())
 
+    # ---- N > 1: the same 32-query batch at every N (so that the N-GPU point and the 1-GPU point of a strong-scaling
+    # curve run the same batch), and the single-exchange mode north_star describes (ONE all-gather of the per-shard top-k
+    # per batch, every shard cutting at its own threshold) beside the two-phase default
+    fixed32 = single_exchange = None
+    if world > 1:
+        if B != 32:
+            p32 = Plan(32, two_phase_default)
+            n32, s32 = sustained_of(p32, min(args.min_seconds, 0.3))
+            fixed32 = {"batch": 32, "value": round(32 * n32 / s32, 2), "unit": "queries/s", "ms_per_step": round(s32 / n32 * 1e3, 4),
+                       "steps": n32, "note": "the headline run of N = 1 uses this batch; value above uses 32 queries per GPU"}
+        if two_phase_default:
+            p1x = Plan(B, False)
+            n1x, s1x = sustained_of(p1x, min(args.min_seconds, 0.3))
+            single_exchange = {"batch": B, "value": round(B * n1x / s1x, 2), "unit": "queries/s",
+                               "ms_per_step": round(s1x / n1x * 1e3, 4), "steps": n1x,
+                               "note": "one all-gather (packed per-shard top-k) per batch; every shard re-scores against its own k-th approximate score"}
+
     # ---- the metric as the reference's search(::String) defines it (src/searching.jl:93-128): encode_queries first.
     # No checkpoint exists in the build image, so the encoder has bert-base-uncased GEOMETRY with random weights and
     # runs on synthetic token ids; random weights give meaningless embeddings that would change the candidate
     # statistics, so the search half of the step still consumes the synthetic queries of the headline line: the
-    # step costs exactly "encode B queries + search B queries", back to back on one stream.
+    # step costs exactly "encode B queries + search B queries", back to back on one stream.  With N ranks every rank
+    # encodes B / N of the batch's queries and one all-gather (B x 32 x 128 fp32) gives every shard all of them.
     e2e = None
     if not args.no_encoder:
         from colbert_jl_amd.encoder import BERT_BASE, random_weights
@@ -312,22 +561,28 @@ def main():
         d_ids = torch.from_numpy(rng.integers(1, BERT_BASE["vocab_size"] + 1, size=(n_queries, T)).astype(np.int32)).to(dev)
         d_mask = torch.ones((n_queries, T), dtype=torch.uint8, device=dev)
         d_skip = torch.tensor([1], dtype=torch.int64, device=dev)
-        q_enc = torch.empty((B, T, 128), dtype=torch.float32, device=dev)
-
-        q_encs = [q_enc] + [torch.empty_like(q_enc) for _ in range(NF - 1)]
+        split = world > 1 and B % world == 0 and backend == "nccl"
+        Bl = B // world if split else B                      # queries this rank encodes
+        q_encs = [torch.empty((B, T, 128), dtype=torch.float32, device=dev) for _ in range(NF)]
+        q_part = [torch.empty((Bl, T, 128), dtype=torch.float32, device=dev) for _ in range(NF)] if split else q_encs
         enc_done = [None]          # the encoder has ONE activation workspace: its calls are chained by an event
 
+        def encode_into(i, st):
+            off = (i * B) % (n_queries - B + 1) + (rank * Bl if split else 0)
+            if enc_done[0] is not None:
+                st.wait_event(enc_done[0])
+            enc.query_embeddings_device(d_ids[off:off + Bl], d_mask[off:off + Bl], d_skip, q_part[i % NF])
+            ev = torch.cuda.Event()
+            ev.record(st)
+            enc_done[0] = ev
+            if split:
+                _dist.all_gather_into_tensor(q_encs[i % NF], q_part[i % NF])
+
         def step_e2e(i):
-            off = (i * B) % (n_queries - B + 1)
             st = compute[i % NF] if overlap[0] else compute[0]
             with torch.cuda.stream(st):
-                if enc_done[0] is not None:
-                    st.wait_event(enc_done[0])
-                enc.query_embeddings_device(d_ids[off:off + B], d_mask[off:off + B], d_skip, q_encs[i % NF])
-                ev = torch.cuda.Event()
-                ev.record(st)
-                enc_done[0] = ev
-                return step_on_current_stream(i)
+                encode_into(i, st)
+                return plan.step_on_current_stream(i, plan.queries(i))
 
         for i in range(3):
             step_e2e(i)
@@ -339,25 +594,58 @@ def main():
         dt = time.perf_counter() - t0
         t0 = time.perf_counter()
         for i in range(args.steps):
-            off = (i * B) % (n_queries - B + 1)
-            enc.query_embeddings_device(d_ids[off:off + B], d_mask[off:off + B], d_skip, q_enc)
+            with torch.cuda.stream(compute[0]):
+                encode_into(i, compute[0])
         barrier()
         dt_enc = time.perf_counter() - t0
         if world > 1:
             tm = torch.tensor([dt, dt_enc], dtype=torch.float64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt, dt_enc = float(tm[0].item()), float(tm[1].item())
+        # per-stage HIP-event times of the encoder (on the launching stream) -> roofline of its dominant Linear layer
+        enc.profile_enable(True)
+        n_prof = 5
+        for i in range(n_prof):
+            with torch.cuda.stream(compute[0]):
+                enc.query_embeddings_device(d_ids[0:Bl], d_mask[0:Bl], d_skip, q_part[0])
+        torch.cuda.synchronize()
+        eprof = enc.profile_read()
+        enc.profile_enable(False)
+        enc_roof = None
+        if eprof:
+            H, I, Lyr = BERT_BASE["hidden_size"], BERT_BASE["intermediate_size"], BERT_BASE["num_hidden_layers"]
+            M = Bl * T
+            shapes = {"linear_qkv": (3 * H, H), "linear_attn_out_ln": (H, H), "linear_ffn_in_gelu": (I, H),
+                      "linear_ffn_out_ln": (H, I), "linear_projection": (128, H)}
+            lin = {kname: v for kname, v in eprof.items() if kname in shapes}
+            domk = max(lin.items(), key=lambda kv: kv[1]["ms"])[0]
+            nprod = {"bf16x6": 6, "bf16x3": 3}.get(enc.gemm, 1)
+            Nn, Kd = shapes[domk]
+            ms1 = eprof[domk]["ms"] / max(eprof[domk]["launches"], 1)
+            peak = BF16_MFMA_PEAK_TF if nprod > 1 else F32_MFMA_PEAK_TF
+            ach = nprod * 2.0 * M * Nn * Kd / (ms1 * 1e-3) / 1e12
+            l2b, tile = encoder_l2_operand_bytes(M, Nn, Kd)
+            enc_roof = {"kernel": f"{domk} ({M} x {Nn} x {Kd}, gemm_bf16split_kernel {tile[0]}x{tile[1]} tiles, split-K {tile[2]})",
+                        "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
+                        "unit": f"TFLOP/s ({'bf16, ' + str(nprod) + ' products per fp32 product' if nprod > 1 else 'fp32 MFMA'})",
+                        "frac": round(ach / peak, 4), "ms_per_launch": round(ms1, 4),
+                        "l2_operand_bytes": int(l2b), "l2_operand_GBps": round(l2b / (ms1 * 1e-3) / 1e9, 1),
+                        "note": "l2_operand_bytes = fp32 operand bytes the work-groups stream through L2 (tile rule of csrc/encoder.hip), "
+                                "the bound of these small-M GEMMs; kernel statistics: profiles/r03_encoder_kernel_stats.csv",
+                        "all_stages_ms_per_encode": {kn: round(v["ms"] / n_prof, 4) for kn, v in eprof.items()}}
         e2e = {"value": round(B * args.steps / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
                "encoder_ms_per_step": round(dt_enc / args.steps * 1e3, 4),
                "dtype": "f32" if enc.gemm == "f32" else f"f32 ({enc.gemm}: every fp32 product of the Linear layers as exact bf16 MFMA products of split operands, fp32 accumulation)",
                "encoder": "bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072) + Dense 768->128, random weights, "
-                          "synthetic token ids; every rank encodes the whole batch",
+                          "synthetic token ids; " + (f"every rank encodes {Bl} of the batch's {B} queries, one all-gather of Q"
+                                                     if split else "this rank encodes the whole batch"),
+               "roofline": enc_roof,
                "note": "encode_queries + search per step; the search consumes the synthetic queries of the headline line"}
         enc.close()
 
     # ---- work counters of one batch (for the roofline) and p50 latency, outside the timed region
     s.profile_enable(True, counters=True)
-    step(args.warmup)
+    plan.step(args.warmup)
     torch.cuda.synchronize()
     stats = s.last_batch_stats()
     s.profile_read()
@@ -381,39 +669,15 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
     roof = None
     if dom:
-        def roof_of(kname):
-            ms_launch = prof[kname]["ms"] / max(prof[kname]["launches"], 1)
-            embs = stats["cand_embs"]; docs = stats["cand_docs"]
-            if kname == "score_exact" and s.mode == 1:
-                embs, docs = stats["rescored_embs"], stats["rescored_docs"]
-            if kname == "score_exact":
-                ach = FLOP_PER_EMB * embs / (ms_launch * 1e-3) / 1e12
-                r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF,
-                     "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
-            elif kname == "centroid_scores":
-                # S1 runs as three bf16 MFMA products per fp32 product (bf16x3 split): count the bf16 flops it
-                # really issues against the dense bf16 peak
-                ach = 3 * 2.0 * 128 * T * K * B / (ms_launch * 1e-3) / 1e12
-                r = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TF,
-                     "unit": "TFLOP/s (bf16, 3 products per fp32 product)", "frac": round(ach / BF16_MFMA_PEAK_TF, 4)}
-                embs, docs = K * B, 0
-            else:
-                alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
-                ach = alg_bytes / (ms_launch * 1e-3) / 1e9
-                r = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBS, 4)}
-            r["ms_per_launch"] = round(ms_launch, 4)
-            r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
-            return r
-        roof = roof_of(dom)
+        roof = roofline_of(dom, prof, stats, s.mode, T, K, B)
         # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the committed
         # rocprofv3 --pmc passes of this same command (tools/pmc_summary.py), which record the hash of the kernel
         # sources they were measured on.  A summary taken on different sources is stale: traffic stays null.
         roof["traffic"] = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
         # ... and on THIS workload (tools/gpu_profile.sh profiles the default one): bytes per launch do not transfer
-        default_workload = (args.docs == 1_000_000 and not args.uniform_codes and B == 32 and k == 1000
-                            and args.nprobe == 2 and args.mode < 0)
+        default_workload = (args.docs == 1_000_000 and not args.uniform_codes and not args.built_index and B == 32
+                            and k == 1000 and args.nprobe == 2 and args.mode < 0)
         if world == 1 and not default_workload:
             roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on the default workload, not this one"
         elif world == 1 and os.path.exists(pmc_file):
@@ -435,7 +699,7 @@ def main():
             else:
                 roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on different kernel sources"
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(prof_steps, 1), 4) for kname, v in prof.items()}
-        roof["other_kernels"] = [roof_of(kn) for kn in ("score_approx", "score_exact", "centroid_scores")
+        roof["other_kernels"] = [roofline_of(kn, prof, stats, s.mode, T, K, B) for kn in ("score_approx", "score_exact", "centroid_scores")
                                  if kn in prof and kn != dom and prof[kn]["launches"]]
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N = 1
@@ -446,7 +710,7 @@ def main():
         emb2pid = orc.build_emb2pid(shard["doclens"])
         idx = dict(shard, emb2pid=emb2pid)
         nq_cpu, t_cpu, ok = 0, 0.0, True
-        search_shard(run, Qdev[0:B], 0); p, sc = run.out_p, run.out_s; torch.cuda.synchronize()
+        plan.search_shard(run, Qdev[0:B], 0); p, sc = run.out_p, run.out_s; torch.cuda.synchronize()
         gp_host = p.cpu().numpy(); gs_host = sc.cpu().numpy()
         while nq_cpu < B and (t_cpu < args.cpu_seconds or nq_cpu == 0):
             t1 = time.perf_counter()
@@ -458,16 +722,67 @@ def main():
                "sample": f"{nq_cpu} queries of the same workload, one at a time, OpenMP over the host cores",
                "gpu_matches_cpu_top_k": ok}
 
+    # ---- N = 1 sub-records: the batch sizes the N-GPU runs use, the worst-case code distribution, and BASELINE config 2
+    batch_sweep = worst = built = None
+    device_bytes = s.device_bytes
+    if world == 1 and not args.no_sub and not args.force_gather:
+        batch_sweep = {}
+        for Bs in (64, 128, 256):
+            if Bs == B or Bs > n_queries:
+                continue
+            pl = Plan(Bs, False)
+            n_s, s_s = sustained_of(pl, 0.25)
+            batch_sweep[str(Bs)] = {"value": round(Bs * n_s / s_s, 2), "ms_per_step": round(s_s / n_s * 1e3, 4), "steps": n_s}
+            del pl
+        s.close()
+        s = None
+        del shard
+        if not args.uniform_codes and not args.built_index:
+            t0 = time.time()
+            u_idx = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks, blocks=range(n_blocks), topical=False)
+            tg = time.time() - t0
+            su = clb.Searcher(index=u_idx, device=local_rank, pid_offset=0)
+            if args.mode >= 0:
+                su.set_mode(args.mode)
+            worst = measure_sub(torch, clb, su, u_idx, Q, 32, k, args.nprobe, args.steps, 0.4,
+                                0 if args.no_cpu else 4, dev, in_flight=NF, T=T)
+            worst["workload"] = (f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}, UNIFORM centroid codes: no "
+                                 f"id-adjacent codes, the largest candidate sets), top-{k}, nprobe {args.nprobe}, batch 32")
+            worst["setup_seconds"] = {"generate": round(tg, 1)}
+            su.close()
+            del u_idx
+        if not args.built_index:
+            bidx, brec = build_config2_index(clb, args.built_docs, args.built_kmeans_iters, local_rank)
+            t0 = time.time()
+            sb = clb.Searcher(index=bidx, device=local_rank, pid_offset=0)
+            brec["upload_and_searcher_s"] = round(time.time() - t0, 2)
+            if args.mode >= 0:
+                sb.set_mode(args.mode)
+            Qb = synthetic.make_queries(bidx, seed=78, n_queries=256, T=T)
+            built = measure_sub(torch, clb, sb, bidx, Qb, 32, k, args.nprobe, args.steps, 0.4,
+                                0 if args.no_cpu else 8, dev, in_flight=NF, T=T)
+            built["workload"] = (f"BASELINE config 2: synthetic {args.built_docs} passages of 4096-component mixture embeddings "
+                                 f"(dim 128, doclen~80) indexed by this repo's own build (k-means K={brec['K']}, nbits 2), "
+                                 f"top-{k}, nprobe {args.nprobe}, batch 32; queries = noisy decompressed passage tokens")
+            built["index_build"] = brec
+            sb.close()
+            del bidx
+
     if rank == 0:
         out = {"metric": "queries/sec, top-1000 on 1M-passage corpus", "value": round(qps, 2), "unit": "queries/s",
                "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+               "batch_policy": (f"fixed --batch {B}" if args.batch > 0 else
+                                f"{B} queries per step = 32 per GPU (at most 256); the corpus is fixed (strong scaling of the passages), "
+                                "fixed_batch_32 / batch_sweep give the same batch at every N"),
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}"
-                                      f"{', uniform codes' if args.uniform_codes else ''}), "
+               "config": {"workload": (f"BASELINE config 2: {n_docs_total} passages of mixture embeddings indexed by this repo's own build "
+                                       f"(K={K}), " if args.built_index else
+                                       f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}"
+                                       f"{', uniform codes' if args.uniform_codes else ''}), ") +
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
-                          "search_mode": ("two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if s.mode == 1 else "exact fp32 single pass")
+                          "search_mode": ("two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if (prof and "score_approx" in prof) else "exact fp32 single pass")
                                          + (", global threshold exchange between the passes" if two_phase else "")},
                "batches_in_flight": NF if overlap[0] else 1, "in_flight_matches_serial": in_flight_ok,
                "one_batch_at_a_time": {"value": round(B * args.steps / serial_s, 2), "ms_per_step": round(serial_s / args.steps * 1e3, 4)},
@@ -476,13 +791,16 @@ def main():
                              "note": "the same loop repeated until the timed region lasts --min-seconds"},
                "end_to_end_with_query_encoder": e2e,
                "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4), "roofline": roof, "cpu_baseline": cpu,
+               "worst_case_uniform_codes": worst, "built_index": built, "batch_sweep": batch_sweep,
+               "fixed_batch_32": fixed32, "single_exchange": single_exchange, "index_build": index_build,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
-               "hbm_bytes": s.device_bytes}
+               "hbm_bytes": device_bytes}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    s.close()
+    if s is not None:
+        s.close()
     if gather:
         dist.destroy_process_group()
 

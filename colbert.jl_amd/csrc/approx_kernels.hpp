@@ -710,7 +710,24 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
 // stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
 // access in the loop at all.
-template <bool ROWS, int ABL = 0>
+// GL = 1 ("LDS-DMA gather", round 3): the score rows reach the wave through LDS instead of VGPRs.  Four ADJACENT lanes
+// fetch the 64 bytes of one row with global_load_lds_dwordx4 (16 rows per instruction, 2 instructions per step) -- one
+// L1 tag look-up per row where the VGPR form (lane (r, h) fetching 2 x 16 B of row r, the lanes of a row 32 apart)
+// costs four: the texture-address unit was the busiest unit of the kernel (TA_BUSY 75 %) whenever the codes of a
+// passage are not id-adjacent (uniform codes, a k-means-built index).  The DMA writes lane l's 16 bytes at slot + 16 l,
+// so WHICH (row, piece) a lane fetches decides the LDS image: row m of an instruction at 64 m, its four pieces rotated by
+// (m >> 2) & 3 -- the ds_read_b128 of lane (r, h) (the A fragments of the two score-row MFMAs) is then conflict-free.
+// The code of row m is taken from lane m with one ds_bpermute per instruction.  A ring of three 2-KB slots per wave
+// (one per step in flight).  The two DMAs of a step are issued by inline assembly, NOT by __builtin_amdgcn_global_load_lds:
+// hipcc orders every LDS instruction that may touch DMA-written memory -- here the ring reads AND the ds_bpermutes --
+// behind ALL pending DMAs with s_waitcnt vmcnt(0), which drains the stage-A loads issued a moment earlier and exposes
+// the full memory latency in every step.  Stage C instead waits for its own slot with s_waitcnt vmcnt(4): the VMEM
+// operations issued after a step's two DMAs are at least the two loads of the next stage A and the two DMAs of the next
+// stage G (the passage-end stores only add to that), and vector memory operations complete in order.  The compiler's
+// own vmcnt arithmetic for the VGPR loads does not see the DMAs; its waits are therefore stronger than needed by the
+// DMAs in between, never weaker.  A slot is re-filled three stages after its reads were waited for (lgkmcnt) -- both
+// in program order, and the "memory" clobbers keep the compiler from moving the ring reads across either.
+template <bool ROWS, int ABL = 0, int GL = 0>
 static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
     int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
@@ -730,6 +747,9 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     // ~2 extra LDS cycles per read on random bytes and made the LDS pipe the busiest unit of the kernel)
     __shared__ __attribute__((aligned(16))) unsigned char lut_s[kApproxLdsLut];
     __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][kStepRows];
+    static_assert(GL == 0 || ABL == 0, "the ablation variants exist for the VGPR gather only");
+    constexpr int kRingBytes = 3 * 2048;                 // three steps in flight x 32 rows x 64 B, per wave
+    __shared__ __attribute__((aligned(16))) unsigned char ring_s[GL ? (kApproxThreads / 64) * kRingBytes : 16];
     for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
         const int v = i >> 5;
         *reinterpret_cast<uint2*>(lut_s + (size_t)i * 8) =
@@ -739,6 +759,16 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     const char* lut = reinterpret_cast<const char*>(lut_s);
     float* myinv = invx[wave];
     const uint32_t lane8 = 8u * (uint32_t)r;
+    // GL: lane l = 4 m + q of a DMA instruction fetches, for row m (rows 0..15 / 16..31), the piece that belongs at
+    // position q of the rotated row image; lane (r, h) later reads pieces h and 2 + h of row r
+    unsigned char* myring = ring_s + (GL ? wave * kRingBytes : 0);
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)myring;
+    const uint32_t gl_poff = 16u * (((uint32_t)lane - (((uint32_t)lane >> 4) & 3u)) & 3u);   // piece = (q - rot(m)) & 3, rot(m) = (m >> 2) & 3
+    const int gl_src0 = (int)((uint32_t)lane & ~3u);            // ds_bpermute byte address of lane m = lane >> 2
+    const int gl_src1 = gl_src0 + 64;                           // lane 16 + m
+    const uint32_t gl_rot = ((uint32_t)r >> 2) & 3u;
+    const uint32_t gl_x0 = (uint32_t)r * 64u + 16u * (((uint32_t)h + gl_rot) & 3u);
+    const uint32_t gl_x1 = (uint32_t)r * 64u + 16u * (((uint32_t)h + 2u + gl_rot) & 3u);
 
     // selection matrices of the two score-row MFMAs: B1[k][col] = (col == k), B2[k][col] = (col == 16 + k), with
     // k = 8h + j held by lane (col = r, h) in element j
@@ -836,8 +866,16 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         }                                                                                                   \
     }
         // stage G: the score row of the lane's embedding: tokens 8h..8h+7 and 16+8h..16+8h+7 (fp16), 2 x 16 B
-#define CLB_STAGE_G(CV, X0, X1)                                                                             \
-    {                                                                                                       \
+#define CLB_STAGE_G(CV, X0, X1, SLOT)                                                                       \
+    if (GL) {                                                                                               \
+        const uint32_t ca_ = (uint32_t)__builtin_amdgcn_ds_bpermute(gl_src0, (int)CV) & cmask;              \
+        const uint32_t cb_ = (uint32_t)__builtin_amdgcn_ds_bpermute(gl_src1, (int)CV) & cmask;              \
+        /* hand-issued (see the kernel header): M0 = LDS byte address of the slot, lane l lands at M0 + 16 l  */ \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, off\n\t"                            \
+                     "s_add_u32 m0, m0, 0x400\n\tglobal_load_lds_dwordx4 %1, off"                          \
+                     :: "v"(c16 + ((ca_ << 6) + gl_poff)), "v"(c16 + ((cb_ << 6) + gl_poff)),               \
+                        "s"(ring_lds + (SLOT) * 2048u) : "memory", "scc");                                   \
+    } else {                                                                                                \
         const char* row_ = c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);                   \
         if (ABL == 1 || ABL == 7) { X0 = u32x4{CV, CV, CV, CV}; X1 = X0; }                                  \
         else {                                                                                              \
@@ -846,8 +884,14 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         }                                                                                                   \
     }
 #define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + lut_offset<N>(W, lane8)))
-#define CLB_STAGE_C(RB, CV, X0, X1, PM, TAG)                                                                \
+#define CLB_STAGE_C(RB, CV, X0, X1, PM, TAG, SLOT)                                                          \
     {                                                                                                       \
+        if (GL) {                                                                                           \
+            /* this step's two DMAs have landed once at most the 4 youngest VMEM operations are pending     */ \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                \
+            X0 = *reinterpret_cast<const u32x4*>(myring + (SLOT) * 2048 + gl_x0);                           \
+            X1 = *reinterpret_cast<const u32x4*>(myring + (SLOT) * 2048 + gl_x1);                           \
+        }                                                                                                   \
         /* inv_norm: lane layout (row = r) -> accumulator layout (register i = row (i&3) + 8(i>>2) + 4h)  */ \
         __builtin_amdgcn_wave_barrier();                                                                    \
         myinv[r] = fmaf((float)(CV >> cbits), inv_step, inv_lo);                                            \
@@ -944,17 +988,17 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         StepTag t0, t1, t2;
         CLB_STAGE_A(rb0, cv0, pm0, t0);
         CLB_STAGE_A(rb1, cv1, pm1, t1);
-        CLB_STAGE_G(cv0, xa0, xb0); cw0 = cv0;
+        CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
         while (t0.j >= 0) {
             CLB_STAGE_A(rb2, cv2, pm2, t2);
-            CLB_STAGE_G(cv1, xa1, xb1); cw1 = cv1;
-            CLB_STAGE_C(rb0, cw0, xa0, xb0, pm0, t0);
+            CLB_STAGE_G(cv1, xa1, xb1, 1); cw1 = cv1;
+            CLB_STAGE_C(rb0, cw0, xa0, xb0, pm0, t0, 0);
             CLB_STAGE_A(rb0, cv0, pm0, t0);
-            CLB_STAGE_G(cv2, xa2, xb2); cw2 = cv2;
-            CLB_STAGE_C(rb1, cw1, xa1, xb1, pm1, t1);
+            CLB_STAGE_G(cv2, xa2, xb2, 2); cw2 = cv2;
+            CLB_STAGE_C(rb1, cw1, xa1, xb1, pm1, t1, 1);
             CLB_STAGE_A(rb1, cv1, pm1, t1);
-            CLB_STAGE_G(cv0, xa0, xb0); cw0 = cv0;
-            CLB_STAGE_C(rb2, cw2, xa2, xb2, pm2, t2);
+            CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
+            CLB_STAGE_C(rb2, cw2, xa2, xb2, pm2, t2, 2);
         }
         }   // chunk of 64 passages
 #undef CLB_STAGE_A
@@ -962,6 +1006,18 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
 #undef CLB_STAGE_C
 #undef CLB_LUT
     }
+}
+
+// How often do two consecutive embeddings (passages are stored sorted by code) read the same 128-byte line of the
+// fp16 score table, i.e. codes c, c' with c >> 1 == c' >> 1?  Decides pass 1's gather form at index load.
+static __global__ __launch_bounds__(256) void code_adjacency_kernel(const uint32_t* __restrict__ codes0, int64_t n,
+                                                                   unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * 256)
+        c += (codes0[i] >> 1) == (codes0[i - 1] >> 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
 // -------------------------------------------------------------------------------------------------------------

@@ -3,6 +3,8 @@
 // (`_doc_embeddings_and_doclens` :27-52, `_query_embeddings` :54-71).
 #include <algorithm>
 #include <cmath>
+#include <utility>
+#include <vector>
 
 #include "codec_kernels.hpp"
 #include "encoder_kernels.hpp"
@@ -24,7 +26,38 @@ struct clb_encoder {
     int64_t r_wqkv = 0, r_bqkv = 0, r_wo = 0, r_bo = 0, r_g1 = 0, r_b1n = 0, r_w1 = 0, r_b1 = 0, r_w2 = 0, r_b2 = 0, r_g2 = 0, r_b2n = 0;
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part;
+    // per-stage HIP-event timing (clb_encoder_profile_*): off in timed runs
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[8];
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[8] = {0};
+    int64_t prof_launches[8] = {0};
 };
+
+namespace {
+enum EncStage { ES_EMBED = 0, ES_QKV, ES_ATTENTION, ES_ATTN_OUT, ES_FFN_IN, ES_FFN_OUT, ES_PROJECTION, ES_EPILOGUE, ES_COUNT };
+const char* kEncStageNames[ES_COUNT] = {"embed_layernorm", "linear_qkv", "attention", "linear_attn_out_ln", "linear_ffn_in_gelu",
+                                        "linear_ffn_out_ln", "linear_projection", "epilogue"};
+// events around one stage of the forward, on the stream the kernels are launched on
+struct EncTimed {
+    clb_encoder* e; int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(clb_encoder* e) {
+        if (!e->prof_pool.empty()) { hipEvent_t v = e->prof_pool.back(); e->prof_pool.pop_back(); return v; }
+        hipEvent_t v = nullptr;
+        return hipEventCreate(&v) == hipSuccess ? v : nullptr;
+    }
+    EncTimed(clb_encoder* e_, int id_, hipStream_t st_) : e(e_), id(id_), st(st_) {
+        if (!e->prof_on) return;
+        a = get(e); b = get(e);
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    ~EncTimed() {
+        if (!e->prof_on || !a || !b) return;
+        (void)hipEventRecord(b, st);
+        e->prof_pending[id].push_back({a, b});
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -153,9 +186,12 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     float* part = short_batch ? e->part.as<float>() : nullptr;
     CLB_TRY(e->err.ensure(sizeof(int)));
     CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, d_ids, T, (int)L,
-                       (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
-                       e->x.as<float>(), e->err.as<int>());
+    {
+        EncTimed tm(e, ES_EMBED, st);
+        hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, d_ids, T, (int)L,
+                           (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
+                           e->x.as<float>(), e->err.as<int>());
+    }
     float* x = e->x.as<float>();
     float* qkv = e->qkv.as<float>();
     float* sc = e->scores.as<float>();
@@ -166,7 +202,9 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     for (int64_t l = 0; l < e->layers; ++l) {
         const float* P = W + e->o_layer0 + l * e->layer_stride;
         // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
-        linear(e, st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr);
+        { EncTimed tm(e, ES_QKV, st);
+        linear(e, st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
+        EncTimed* t_att = new EncTimed(e, ES_ATTENTION, st);
         if (fused) {
             // softmax(Q K^T / sqrt(dh) + mask) V, one wave per (sequence, head, 32 queries), scores never leave registers
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
@@ -186,15 +224,20 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
                  heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
         }
+        delete t_att;
         // attention output + residual, LayerNorm
         const LnArgs ln1{P + e->r_g1, P + e->r_b1n, e->eps}, ln2{P + e->r_g2, P + e->r_b2n, e->eps};
-        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1);
+        { EncTimed tm(e, ES_ATTN_OUT, st);
+        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1); }
         // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
-        linear(e, st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr);
-        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2);
+        { EncTimed tm(e, ES_FFN_IN, st);
+        linear(e, st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr); }
+        { EncTimed tm(e, ES_FFN_OUT, st);
+        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2); }
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
-    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part);
+    { EncTimed tm(e, ES_PROJECTION, st);
+    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part); }
     CLB_HIP(hipGetLastError());
     if (!sync) return CLB_OK;
     int herr = 0;
@@ -276,6 +319,8 @@ int clb_encoder_destroy(clb_encoder* e) {
     if (!e) return CLB_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    for (auto& v : e->prof_pending) for (auto& ab : v) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
+    for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     delete e;
     return CLB_OK;
 }
@@ -359,12 +404,42 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
     CLB_TRY(e->qmask.ensure((size_t)L * N));
     CLB_TRY(e->qlens.ensure(sizeof(int64_t) * N));
     CLB_TRY(forward(e, L, N, st, d_integer_ids, d_bitmask, /*sync=*/false));
-    hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
-                       d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
-    hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
-                       (int)L, (int)N, e->qmask.as<uint8_t>(), (const int64_t*)nullptr, d_out);
+    {
+        EncTimed tm(e, ES_EPILOGUE, st);
+        hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
+                           d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
+        hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                           (int)L, (int)N, e->qmask.as<uint8_t>(), (const int64_t*)nullptr, d_out);
+    }
     CLB_HIP(hipGetLastError());
     return CLB_OK;
+}
+
+int clb_encoder_profile_enable(clb_encoder* e, int on) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    e->prof_on = on != 0;
+    return CLB_OK;
+}
+
+int clb_encoder_profile_read(clb_encoder* e, const char** names, double* total_ms, int64_t* launches, int cap) {
+    if (!e || !names || !total_ms || !launches) return -1;
+    if (use_device(e->device) != CLB_OK) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    int n = 0;
+    for (int id = 0; id < ES_COUNT; ++id) {
+        for (auto& ab : e->prof_pending[id]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ab.first, ab.second) == hipSuccess) { e->prof_ms[id] += ms; e->prof_launches[id] += 1; }
+            e->prof_pool.push_back(ab.first); e->prof_pool.push_back(ab.second);
+        }
+        e->prof_pending[id].clear();
+        if (n < cap && e->prof_launches[id]) {
+            names[n] = kEncStageNames[id]; total_ms[n] = e->prof_ms[id]; launches[n] = e->prof_launches[id];
+            ++n;
+        }
+        e->prof_ms[id] = 0; e->prof_launches[id] = 0;
+    }
+    return n;
 }
 
 }  // extern "C"

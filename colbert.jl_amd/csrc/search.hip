@@ -2,6 +2,8 @@
 // Replaces: struct Searcher / Searcher(index_path) (src/searching.jl:1-91) and search() after the
 // encoder (src/searching.jl:102-127), retrieve/gather/maxsim (src/search/ranking.jl).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "approx_kernels.hpp"
@@ -93,6 +95,8 @@ struct clb_searcher {
     float inv_lo = 0.f, inv_step = 0.f;
     DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
+    int gather_lds = 0; // pass 1: score rows through LDS-DMA, four adjacent lanes per row (0: the per-lane VGPR gather); set at load
+    double code_adjacency = 0.0;   // fraction of consecutive embeddings that share a 128-B line of the score table
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
     Workspace ws[kWorkspaceSlots];   // per-batch scratch, grown on demand (ensure_workspace); slots 1..: further batches in flight
@@ -156,7 +160,10 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     CLB_HIP(hipDeviceSynchronize());       // buffers may be in use on any of the caller's streams
     B = std::max(B, w.Bcap); T = std::max(T, w.Tcap);
     nprobe = std::max(nprobe, w.npcap); k = std::max(k, w.kcap);
-    const int64_t Tpad = token_tiles(T) * 32;
+    // T is the LARGEST query length this slot has seen; queries of up to 128 tokens take the tuned kernels whatever came
+    // before them on the handle, so the tuned-path buffers are sized for min(T, 128) whenever the index has the tuned
+    // shape -- a longer query earlier on (general path) must not leave them unallocated or short
+    const int64_t Tpad = token_tiles(std::min<int64_t>(T, 128)) * 32;
     // candidates of one query <= sum of the T*nprobe longest IVF lists (and <= n_docs)
     size_t lists = (size_t)std::min<int64_t>(T * nprobe, s->K);
     size_t cap = 0;
@@ -168,7 +175,7 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     w.nblk_bitmap = (w.W + kScanBlock * kWordsPerThread - 1) / (kScanBlock * kWordsPerThread);
     w.topn_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, s->K / 512));
     const int64_t NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
-    const bool general = s->generic || T > 128;
+    const bool general = s->generic;
     CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * s->dim));
     // the fp32 T x K score matrix is only materialised by the unfused S1/S2 path (nprobe > 2 or T > 32)
     if (!general && !(nprobe <= 2 && T <= 32)) CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
@@ -566,7 +573,14 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 default: CLB_LAUNCH_APPROX(0);
             }
 #else
-            CLB_LAUNCH_APPROX(0);
+            if (s->gather_lds)
+                hipLaunchKernelGGL((score_approx32_kernel<false, 0, 1>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+                                   s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
+                                   w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                                   (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                                   (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
+            else
+                CLB_LAUNCH_APPROX(0);
 #endif
 #undef CLB_LAUNCH_APPROX
         }
@@ -590,7 +604,9 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         // the pass-1 pipeline again, over the listed passages only: marks the rows that can hold a token maximum
         const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 256);
         const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 32);
-        hipLaunchKernelGGL(score_approx32_kernel<true>, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+        // (the row sweep keeps the VGPR gather: its ~1 200 passages per query are faster with it on every workload measured)
+        auto rows_kernel = score_approx32_kernel<true, 0, 0>;
+        hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                            s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                            (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
@@ -775,6 +791,25 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     while (((int64_t)1 << s->cbits) < K) ++s->cbits;
     // the packed word leaves 32 - cbits bits for inv_norm: at least 12 (K <= 2^20), otherwise exact mode only
     s->approx_ok = approx_supported((int)dim, nbits) && s->cbits <= 20;
+    {   // Pass 1's gather form, by the index's own code statistics: when neighbouring embeddings of a passage often share
+        // a 128-byte line of the score table (id-adjacent codes: the L1 merges those requests of the per-lane VGPR
+        // gather) the VGPR form is faster (1 M topical passages: 0.67 against 0.76 ms per batch); when they do not
+        // (uniform codes, a k-means-built index) the LDS-DMA form is (uniform: 1.47 against 1.61 ms)
+        DevBuf cnt;
+        if ((rc = cnt.alloc(sizeof(unsigned long long)))) return bail(rc);
+        unsigned long long adj = 0;
+        const int64_t n_sample = std::min<int64_t>(n_emb, (int64_t)1 << 24);
+        if (hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
+        if (n_sample > 1)
+            hipLaunchKernelGGL(code_adjacency_kernel, dim3(1024), dim3(256), 0, s->stream, s->codes0.as<uint32_t>(), n_sample,
+                               cnt.as<unsigned long long>());
+        if (hipMemcpyAsync(&adj, cnt.p, sizeof adj, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+            hipStreamSynchronize(s->stream) != hipSuccess)
+            return bail(fail(CLB_EHIP, "code statistics failed"));
+        s->code_adjacency = n_sample > 1 ? (double)adj / (double)(n_sample - 1) : 0.0;
+        s->gather_lds = s->code_adjacency < 0.2;
+        if (const char* g = getenv("COLBERT_PASS1_GATHER")) s->gather_lds = strcmp(g, "vgpr") != 0;   // "vgpr" / "lds": comparison runs
+    }
     if (s->approx_ok) {
         if ((rc = s->codeinv.alloc(sizeof(uint32_t) * (n_emb + kStepRows)))) return bail(rc);
         if (hipMemsetAsync(s->codeinv.p, 0, s->codeinv.bytes, s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
@@ -830,6 +865,18 @@ int clb_searcher_set_wide_select(clb_searcher* s, int on) {
     if (on < -1 || on > 1) return fail(CLB_EARGUMENT, "wide select must be -1 (by candidate capacity), 0 (never) or 1 (always)");
     s->wide_select = on;
     return CLB_OK;
+}
+
+int clb_searcher_set_pass1_gather(clb_searcher* s, int form) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "pass-1 gather form must be -1 (by the code statistics), 0 (VGPR) or 1 (LDS-DMA)");
+    s->gather_lds = form < 0 ? (s->code_adjacency < 0.2) : form;
+    return CLB_OK;
+}
+int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
+    if (!s) return -1;
+    if (adjacency) *adjacency = s->code_adjacency;
+    return s->gather_lds;
 }
 
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {
@@ -1018,7 +1065,8 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
-    hipLaunchKernelGGL(score_approx32_kernel<false>, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+    auto dbg_kernel = s->gather_lds ? score_approx32_kernel<false, 0, 1> : score_approx32_kernel<false, 0, 0>;
+    hipLaunchKernelGGL(dbg_kernel, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                        (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,

@@ -153,6 +153,19 @@ class BertEncoder:
                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
         return d_out
 
+    # -- profiling (bench.py) -----------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        """HIP events around every stage of the forward, on the launching stream (not for timed regions)."""
+        check(lib().clb_encoder_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile_read(self) -> dict:
+        cap = 16
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); cnt = (C.c_int64 * cap)()
+        n = lib().clb_encoder_profile_read(self._h, names, ms, cnt, cap)
+        if n < 0:
+            check(10)
+        return {names[i].decode(): {"ms": ms[i], "launches": cnt[i]} for i in range(n)}
+
     # -- the reference's batching loops -----------------------------------------------------------------
     def encode_passages(self, passages: List[str], skiplist=None, doc_token: Optional[str] = None):
         """encode_passages (checkpoint.jl:159-189) -> (embs (dim, sum(doclens)), doclens)."""

@@ -73,6 +73,16 @@ class Searcher:
         """-1: the selection step picks one or sixteen work-groups per query by the candidate capacity; 0 / 1 force it."""
         check(lib().clb_searcher_set_wide_select(self._h, C.c_int(on)))
 
+    def set_pass1_gather(self, form: int):
+        """-1: pass 1 picks its gather form from the index's code statistics; 0 / 1 force the VGPR / LDS-DMA form."""
+        check(lib().clb_searcher_set_pass1_gather(self._h, C.c_int(form)))
+
+    @property
+    def pass1_gather(self):
+        """(form in use: 0 VGPR / 1 LDS-DMA, code adjacency statistic of the index)"""
+        adj = C.c_double(0)
+        return int(lib().clb_searcher_get_pass1_gather(self._h, C.byref(adj))), adj.value
+
     @property
     def mode(self) -> int:
         return int(lib().clb_searcher_get_mode(self._h))

@@ -115,6 +115,13 @@ int clb_searcher_get_mode(const clb_searcher* s);
  * GPU: ~96 k per query).  on = -1: chosen by the handle's candidate capacity (default), 0: never, 1: always.  The
  * results are identical either way. */
 int clb_searcher_set_wide_select(clb_searcher* s, int on);
+/* Gather form of pass 1 of the two-pass mode (how the fp16 centroid-score rows of ranking.jl:27 reach the scorer; no call
+ * site of its own in the reference): 0 = per-lane VGPR loads, 1 = LDS-DMA with four adjacent lanes per row, -1 = chosen at
+ * load from the index's own code statistics (default).  Results are identical either way.  The getter returns the form
+ * in use and, through *adjacency (may be null), the statistic: the fraction of consecutive embeddings whose score rows
+ * share a 128-byte line. */
+int clb_searcher_set_pass1_gather(clb_searcher* s, int form);
+int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency);
 /* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, [1] = sqrt(dim) * max |bucket
  * weight|, [2] = max over the shard's embeddings of 1/(||c + r|| + eps), [3] = max ||bf16-rounded residual vector||,
  * [4] = sqrt(dim) * max |w - bf16(w)|, [5] = the quantisation error of the packed inv_norm.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE
@@ -277,6 +284,12 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
  * cannot be reported from an asynchronous call: it is clamped (use clb_encode_queries to validate inputs). */
 int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
                               const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream);
+/* Per-stage HIP-event timing of the encoder forward (bench.py's encoder roofline; the stages are the Linear layers of
+ * `doc`, src/modelling/checkpoint.jl:21-25, by role).  enable, run encodes, then read: names[i] (static strings), total
+ * milliseconds and stage executions since the last read.  Returns the number of entries written (<= cap), -1 on error. */
+int clb_encoder_profile_enable(clb_encoder* e, int on);
+int clb_encoder_profile_read(clb_encoder* e, const char** names, double* total_ms, int64_t* launches, int cap);
+
 
 /* Encoder epilogue as stand-alone calls  (src/modelling/checkpoint.jl:27-71, embedding_utils.jl:172-205) */
 /* _doc_embeddings_and_doclens after doc(): clear skiplist tokens, normalise, doclens, compaction.

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "40000", "--steps", "3", "--warmup", "1",
-                          "--no-encoder", "--cpu-seconds", "1", "--min-seconds", "0.05", "--k", "100"],
+                          "--no-encoder", "--cpu-seconds", "1", "--min-seconds", "0.05", "--k", "100", "--built-docs", "3000",
+                          "--built-kmeans-iters", "3"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -35,3 +36,13 @@ def test_bench_line_has_the_contract_fields():
         assert key in c, key
     assert c["kind"] == "port" and c["gpu_matches_cpu_top_k"] is True
     assert d["in_flight_matches_serial"] is True
+    # the sub-records of the line: worst case (uniform codes), BASELINE config 2 on this repo's own index build, batch sweep
+    w = d["worst_case_uniform_codes"]
+    assert w["value"] > 0 and w["gpu_matches_cpu_top_k"] is True and "frac" in w["roofline"] and "uniform" in w["workload"].lower()
+    b = d["built_index"]
+    assert b["value"] > 0 and b["gpu_matches_cpu_top_k"] is True and "frac" in b["roofline"]
+    ib = b["index_build"]
+    for key in ("kmeans_s", "kmeans_iters", "codec_stats_s", "compress_s", "build_ivf_s", "kmeans_roofline", "K"):
+        assert key in ib, key
+    assert b["candidates_per_query"]["passages"] > 0
+    assert set(d["batch_sweep"]) == {"64", "128", "256"}

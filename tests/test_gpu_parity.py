@@ -222,18 +222,22 @@ def test_encoder_epilogue_bit_exact(oracle):
 # search vs the oracle
 # ---------------------------------------------------------------------------------------------------
 def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0, wide=None):
+    """Both search modes against the oracle; the two-pass mode with BOTH gather forms of pass 1 (mode 2 below = two-pass
+    with the form the index statistics did not pick)."""
     s = clb.Searcher(index=idx, pid_offset=pid_offset)
     if wide is not None:
         s.set_wide_select(wide)
     refs = [oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k) for j in range(Qs.shape[2])]   # the oracle, once per query
+    auto_form = s.pass1_gather[0]
     try:
-        for mode in modes:
-            if mode == 1 and s.mode != 1:
+        for mode in tuple(modes) + ((2,) if 1 in modes else ()):
+            if mode >= 1 and s.mode != 1:
                 try:
                     s.set_mode(1)
                 except clb.Unsupported:
                     continue
-            s.set_mode(mode)
+            s.set_mode(min(mode, 1))
+            s.set_pass1_gather(-1 if mode < 2 else 1 - auto_form)
             for j in range(Qs.shape[2]):
                 rp, rs, rn = refs[j]
                 pids, scores = s.search_embeddings(Qs[:, :, j], k, nprobe=nprobe)
@@ -297,6 +301,36 @@ def test_search_batch_sizes(oracle, T):
                     rp, rs, rn = ref[j]
                     assert np.array_equal(bp[:, j], rp) and bn[j] == rn, (mode, B, j)
                     assert_same_f32(bs[:, j], rs, f"mode={mode} B={B} q={j}")
+    finally:
+        s.close()
+
+
+def test_search_mixed_shapes_on_one_handle(oracle):
+    """One Searcher, calls of different shapes in the order that used to leave the tuned-path buffers unallocated or
+    short (round-2 advisor finding: a T > 128 query switched `general` on for every later workspace growth): T = 150
+    first (general path), then T = 64 with nprobe = 4 and a batch of 32, then T = 32 / nprobe 2, then T = 150 again."""
+    idx = synthetic.make_index(seed=61, n_docs=3000, K=256, doclen_mean=24, doclen_std=6)
+    s = clb.Searcher(index=idx)
+    try:
+        def run(T, nprobe, B, k, seed):
+            Qs = synthetic.make_queries(idx, seed, B, T=T)
+            if B == 1:
+                got = [s.search_embeddings(Qs[:, :, 0], k, nprobe=nprobe)]
+            else:
+                bp, bs, _ = s.search_batch(Qs, k, nprobe=nprobe)
+                got = [(bp[:, j], bs[:, j]) for j in range(B)]
+            for j, (pids, scores) in enumerate(got):
+                rp, rs, _ = oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k)
+                assert np.array_equal(pids, rp), (T, nprobe, B, j)
+                assert_same_f32(scores, rs, f"T={T} nprobe={nprobe} B={B} q={j}")
+        for mode in (0, 1):
+            s.set_mode(mode)
+            run(64, 2, 1, 20, 70)
+            run(150, 2, 1, 20, 71)
+            run(64, 4, 32, 20, 72)
+            run(32, 2, 9, 20, 73)
+            run(150, 3, 2, 20, 74)
+            run(100, 9, 5, 20, 75)
     finally:
         s.close()
 
