@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
         l.clb_searcher_device_bytes.restype = C.c_int64
         l.clb_packed_topk_bytes.restype = C.c_int64
         l.clb_comm_unique_id_bytes.restype = C.c_int64
+        l.clb_kmeans_shard_block_bytes.restype = C.c_int64
         _lib = l
     return _lib
 

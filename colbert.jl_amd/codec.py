@@ -98,6 +98,39 @@ class KMeansShard:
                                           fptr(assign) if want_assignments else None))
         return (sums, counts, assign) if want_assignments else (sums, counts)
 
+    # -- the exchange on the device (torch CUDA tensors; enqueued on torch's current stream) ---------------------------
+    @property
+    def block_bytes(self) -> int:
+        return int(lib().clb_kmeans_shard_block_bytes(self._h))
+
+    def set_centroids(self, centroids):
+        c = colmajor(centroids, np.float32)
+        assert c.shape == (self.dim, self.K)
+        check(lib().clb_kmeans_shard_set_centroids(self._h, fptr(c)))
+
+    def get_centroids(self):
+        c = np.zeros((self.dim, self.K), dtype=np.float32, order="F")
+        check(lib().clb_kmeans_shard_get_centroids(self._h, fptr(c)))
+        return c
+
+    def pass_device(self, d_block):
+        """this rank's [sums | counts] block into the uint8 CUDA tensor `d_block` (block_bytes long)"""
+        import torch
+        assert d_block.is_cuda and d_block.is_contiguous() and d_block.numel() * d_block.element_size() >= self.block_bytes
+        st = torch.cuda.current_stream(d_block.device).cuda_stream
+        check(lib().clb_kmeans_shard_pass_device(self._h, C.c_void_p(d_block.data_ptr()), C.c_void_p(st)))
+
+    def update_device(self, d_gathered, world: int, tol: float = 1e-4):
+        """rank-ordered reduction of the `world` gathered blocks + centroid update -> (delta, converged)"""
+        import torch
+        assert d_gathered.is_cuda and d_gathered.is_contiguous()
+        assert d_gathered.numel() * d_gathered.element_size() >= world * self.block_bytes
+        st = torch.cuda.current_stream(d_gathered.device).cuda_stream
+        delta = C.c_float(0); conv = C.c_int(0)
+        check(lib().clb_kmeans_shard_update_device(self._h, C.c_void_p(d_gathered.data_ptr()), i64(world), C.c_float(tol),
+                                                   C.byref(delta), C.byref(conv), C.c_void_p(st)))
+        return delta.value, bool(conv.value)
+
     def close(self):
         if getattr(self, "_h", None):
             lib().clb_kmeans_shard_destroy(self._h)

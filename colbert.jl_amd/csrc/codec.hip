@@ -321,7 +321,13 @@ int clb_kmeans_shard_create(int device, const float* data, int64_t dim, int64_t 
     int rc;
     if ((rc = h->s.init())) return bail(rc);
     const int64_t n1 = std::max<int64_t>(n, 1);
-    if ((rc = upload(h->dX, data, sizeof(float) * dim * n1, h->s.st))) return bail(rc);
+    if (n > 0) {
+        if (!data) return bail(fail(CLB_EARGUMENT, "data is null"));
+        if ((rc = upload(h->dX, data, sizeof(float) * dim * n, h->s.st))) return bail(rc);
+    } else {      // a rank whose part of the clustering sample is empty: nothing to read from the host
+        if ((rc = h->dX.alloc(sizeof(float) * dim))) return bail(rc);
+        if (hipMemsetAsync(h->dX.p, 0, sizeof(float) * dim, h->s.st) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
+    }
     if ((rc = h->dC.alloc(sizeof(float) * dim * K)) || (rc = h->dNew.alloc(sizeof(float) * dim * K)) ||
         (rc = h->dC2.alloc(sizeof(float) * K)) || (rc = h->dAssign.alloc(sizeof(uint32_t) * n1)) ||
         (rc = h->dOrder.alloc(sizeof(uint32_t) * n1)) || (rc = h->dIota.alloc(sizeof(uint32_t) * n1)) ||
@@ -344,6 +350,9 @@ int clb_kmeans_shard_destroy(clb_kmeans_shard* h) {
     return CLB_OK;
 }
 
+// one pass over the shard's points with the centroids in h->dC: sums -> h->dNew, counts -> h->dCnt64 (enqueued on st)
+static int kmeans_shard_pass_core(clb_kmeans_shard* h, hipStream_t st);
+
 int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids, float* sums, int64_t* counts,
                           int32_t* assignments) {
     if (!h || !centroids || !sums || !counts) return fail(CLB_EARGUMENT, "null argument");
@@ -351,6 +360,17 @@ int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids, float* su
     hipStream_t st = h->s.st;
     const int64_t n = h->n, K = h->K, dim = h->dim;
     CLB_HIP(hipMemcpyAsync(h->dC.p, centroids, sizeof(float) * dim * K, hipMemcpyHostToDevice, st));
+    CLB_TRY(kmeans_shard_pass_core(h, st));
+    CLB_HIP(hipMemcpyAsync(sums, h->dNew.p, sizeof(float) * dim * K, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(counts, h->dCnt64.p, sizeof(int64_t) * K, hipMemcpyDeviceToHost, st));
+    if (assignments && n > 0)
+        CLB_HIP(hipMemcpyAsync(assignments, h->dAssign.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    return CLB_OK;
+}
+
+static int kmeans_shard_pass_core(clb_kmeans_shard* h, hipStream_t st) {
+    const int64_t n = h->n, K = h->K, dim = h->dim;
     hipLaunchKernelGGL(centroid_sumsq_kernel, dim3(blocks_for(K, 64)), dim3(64), 0, st, h->dC.as<float>(), (int)dim,
                        (int)K, h->dC2.as<float>());
     CLB_TRY(nearest_centroids<1>(st, h->dC.as<float>(), h->dC2.as<float>(), (int)dim, (int)K, h->dX.as<float>(), n,
@@ -370,11 +390,86 @@ int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids, float* su
     hipLaunchKernelGGL(widen_counts_kernel, dim3(blocks_for(K)), dim3(256), 0, st, h->dCnt32.as<int>(),
                        h->dCnt64.as<long long>(), (int)K);
     CLB_HIP(hipGetLastError());
-    CLB_HIP(hipMemcpyAsync(sums, h->dNew.p, sizeof(float) * dim * K, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(counts, h->dCnt64.p, sizeof(int64_t) * K, hipMemcpyDeviceToHost, st));
-    if (assignments && n > 0)
-        CLB_HIP(hipMemcpyAsync(assignments, h->dAssign.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    return CLB_OK;
+}
+
+// ---- the same iteration with the exchange on the device (no host round trip of the 64-MB blocks) -----------------
+// offset of the counts inside a block: the sums padded to a multiple of 8 bytes
+static inline size_t kmeans_block_counts_offset(const clb_kmeans_shard* h) {
+    return ((size_t)sizeof(float) * h->dim * h->K + 7) / 8 * 8;
+}
+
+int64_t clb_kmeans_shard_block_bytes(const clb_kmeans_shard* h) {
+    return h ? (int64_t)(kmeans_block_counts_offset(h) + sizeof(int64_t) * h->K) : 0;
+}
+
+int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids) {
+    if (!h || !centroids) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(h->device));
+    CLB_HIP(hipMemcpyAsync(h->dC.p, centroids, sizeof(float) * h->dim * h->K, hipMemcpyHostToDevice, h->s.st));
+    CLB_HIP(hipStreamSynchronize(h->s.st));
+    return CLB_OK;
+}
+
+int clb_kmeans_shard_get_centroids(clb_kmeans_shard* h, float* centroids) {
+    if (!h || !centroids) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(h->device));
+    CLB_HIP(hipMemcpy(centroids, h->dC.p, sizeof(float) * h->dim * h->K, hipMemcpyDeviceToHost));
+    return CLB_OK;
+}
+
+int clb_kmeans_shard_pass_device(clb_kmeans_shard* h, void* d_block, void* hip_stream) {
+    if (!h || !d_block) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    // the pass runs on the shard's own stream (its scratch lives there); the caller's stream waits for it
+    hipEvent_t ev = nullptr, ev2 = nullptr;
+    CLB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CLB_HIP(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+    int rc = CLB_OK;
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(h->s.st, ev, 0) != hipSuccess) rc = fail(CLB_EHIP, "event failed");
+    if (!rc) rc = kmeans_shard_pass_core(h, h->s.st);
+    if (!rc) {
+        char* blk = static_cast<char*>(d_block);
+        if (hipMemcpyAsync(blk, h->dNew.p, sizeof(float) * h->dim * h->K, hipMemcpyDeviceToDevice, h->s.st) != hipSuccess ||
+            hipMemcpyAsync(blk + kmeans_block_counts_offset(h), h->dCnt64.p, sizeof(int64_t) * h->K, hipMemcpyDeviceToDevice, h->s.st) != hipSuccess ||
+            hipEventRecord(ev2, h->s.st) != hipSuccess || hipStreamWaitEvent(st, ev2, 0) != hipSuccess)
+            rc = fail(CLB_EHIP, "block copy failed");
+    }
+    (void)hipEventDestroy(ev); (void)hipEventDestroy(ev2);
+    return rc;
+}
+
+int clb_kmeans_shard_update_device(clb_kmeans_shard* h, const void* d_gathered, int64_t world, float tol, float* delta_out,
+                                   int* converged, void* hip_stream) {
+    if (!h || !d_gathered) return fail(CLB_EARGUMENT, "null argument");
+    if (world < 1) return fail(CLB_EDIMENSION, "world must be >= 1");
+    CLB_TRY(use_device(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int64_t K = h->K, dim = h->dim;
+    const size_t blk = (size_t)clb_kmeans_shard_block_bytes(h);
+    DevBuf dDelta, dNext;
+    CLB_TRY(dDelta.alloc(sizeof(unsigned int)));
+    CLB_TRY(dNext.alloc(sizeof(float) * dim * K));
+    CLB_HIP(hipMemsetAsync(dDelta.p, 0, sizeof(unsigned int), st));
+    const char* g = static_cast<const char*>(d_gathered);
+    hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(g), reinterpret_cast<const long long*>(g + kmeans_block_counts_offset(h)),
+                       (int)world, h->dC.as<float>(), (int)dim, (int)K, dNext.as<float>(), dDelta.as<unsigned int>(),
+                       blk / sizeof(float), blk / sizeof(long long));
+    CLB_HIP(hipGetLastError());
+    unsigned int bits = 0;
+    CLB_HIP(hipMemcpyAsync(&bits, dDelta.p, sizeof bits, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
+    float delta;
+    memcpy(&delta, &bits, sizeof delta);
+    if (delta_out) *delta_out = delta;
+    const int conv = delta < tol;      // utils.jl:308-311: the previous centroids stay
+    if (converged) *converged = conv;
+    if (!conv) {
+        CLB_HIP(hipMemcpyAsync(h->dC.p, dNext.p, sizeof(float) * dim * K, hipMemcpyDeviceToDevice, st));
+        CLB_HIP(hipStreamSynchronize(st));
+    }
     return CLB_OK;
 }
 
@@ -393,7 +488,7 @@ int clb_kmeans_reduce_update(int device, float* centroids, const float* gathered
     CLB_HIP(hipMemsetAsync(dDelta.p, 0, sizeof(unsigned int), s.st));
     hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, s.st, dS.as<float>(),
                        dCt.as<long long>(), (int)world, dOld.as<float>(), (int)dim, (int)K, dNew.as<float>(),
-                       dDelta.as<unsigned int>());
+                       dDelta.as<unsigned int>(), (size_t)K * dim, (size_t)K);
     CLB_HIP(hipGetLastError());
     unsigned int bits = 0;
     CLB_HIP(hipMemcpyAsync(&bits, dDelta.p, sizeof bits, hipMemcpyDeviceToHost, s.st));

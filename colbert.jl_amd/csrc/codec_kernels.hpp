@@ -320,18 +320,22 @@ static __global__ void kmeans_finalize_kernel(float* __restrict__ newc, const in
 // Sharded k-means (one shard per GPU): total = ((p_0 + p_1) + p_2) + ... over the ranks' partial sums in RANK order
 // (deterministic whatever order the exchange delivered them in), counts added, then the centroid update of
 // utils.jl:302-306.  gathered_sums: [world][K*dim], gathered_counts: [world][K].
+// sums_stride / counts_stride: distance between two ranks' blocks in floats / in int64 words ([world][K*dim] and
+// [world][K] for the separate arrays of clb_kmeans_reduce_update; the packed [sums | counts] blocks of the device
+// exchange have both inside one record per rank)
 static __global__ void kmeans_reduce_update_kernel(const float* __restrict__ gathered_sums,
                                                    const long long* __restrict__ gathered_counts, int world,
                                                    const float* __restrict__ oldc, int dim, int K,
-                                                   float* __restrict__ newc, unsigned int* __restrict__ delta_bits) {
+                                                   float* __restrict__ newc, unsigned int* __restrict__ delta_bits,
+                                                   size_t sums_stride, size_t counts_stride) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float diff = 0.f;
     if (gid < (int64_t)K * dim) {
         const int c = (int)(gid / dim);
         long long cnt = 0;
-        for (int r = 0; r < world; ++r) cnt += gathered_counts[(size_t)r * K + c];
+        for (int r = 0; r < world; ++r) cnt += gathered_counts[(size_t)r * counts_stride + c];
         float total = gathered_sums[gid];
-        for (int r = 1; r < world; ++r) total = total + gathered_sums[(size_t)r * K * dim + gid];
+        for (int r = 1; r < world; ++r) total = total + gathered_sums[(size_t)r * sums_stride + gid];
         const float v = total / (float)(cnt > 1 ? cnt : 1);
         newc[gid] = v;
         diff = fabsf(oldc[gid] - v);

@@ -78,6 +78,7 @@ struct clb_searcher {
     int mode = 0;
     int wide_select = -1;      // selection by kWideBlocks work-groups per query: -1 by candidate capacity, 0 never, 1 always
     bool approx_ok = false;
+    bool bounds_synced = false;   // clb_searcher_set_bound_consts has been called: the error bound is the shard group's, not this shard's
     bool ivf_sorted = false;   // every IVF list holds non-decreasing passage ids (mark_count_kernel<true> needs it)
     bool generic = false;      // dim != 128 or nbits == 8: every query takes the general-shape path
     int64_t max_doclen = 0;
@@ -867,6 +868,19 @@ int clb_searcher_set_wide_select(clb_searcher* s, int on) {
     return CLB_OK;
 }
 
+int clb_searcher_sync_bound_consts(clb_searcher* s, clb_comm* c) {
+    if (!s || !c) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(s->device));
+    float consts[6];
+    CLB_TRY(clb_searcher_get_bound_consts(s, consts));
+    DevBuf d;
+    CLB_TRY(upload(d, consts, sizeof consts, s->stream));
+    CLB_TRY(clb_comm_all_reduce_max_f32(c, d.as<float>(), 6, s->stream));
+    CLB_HIP(hipMemcpyAsync(consts, d.p, sizeof consts, hipMemcpyDeviceToHost, s->stream));
+    CLB_HIP(hipStreamSynchronize(s->stream));
+    return clb_searcher_set_bound_consts(s, consts);
+}
+
 int clb_searcher_set_pass1_gather(clb_searcher* s, int form) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
     if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "pass-1 gather form must be -1 (by the code statistics), 0 (VGPR) or 1 (LDS-DMA)");
@@ -895,6 +909,7 @@ int clb_searcher_set_bound_consts(clb_searcher* s, const float* consts) {
     s->approx_consts.rb_max = std::max(s->approx_consts.rb_max, consts[3]);
     s->approx_consts.dw_rn = std::max(s->approx_consts.dw_rn, consts[4]);
     s->approx_consts.inv_qerr = std::max(s->approx_consts.inv_qerr, consts[5]);
+    s->bounds_synced = true;
     return CLB_OK;
 }
 
@@ -958,6 +973,12 @@ int clb_search_shard_phase2_slot(clb_searcher* s, int slot, const float* d_Q, in
     if (!pd.valid || pd.dQ != d_Q || pd.T != T || pd.B != B || pd.nprobe != nprobe || pd.k != k || pd.stream != hip_stream)
         return fail(CLB_EARGUMENT, "clb_search_shard_phase2 without a matching clb_search_shard_phase1 "
                                    "on this workspace slot (same queries, T, B, nprobe, k and stream, and no other search on the slot in between)");
+    // every shard must cut at tau_global - 2 eps with ONE eps (the largest): a shard still on its own bound constants
+    // could drop a member of the global top-k silently, so phase 2 with other shards' scores is refused until the host
+    // has shared them (clb_searcher_get_bound_consts on every shard -> element-wise maximum -> clb_searcher_set_bound_consts)
+    if (n_shards > 1 && !s->bounds_synced)
+        return fail(CLB_EARGUMENT, "clb_search_shard_phase2 with %lld shards before clb_searcher_set_bound_consts: the shards "
+                                   "must share one error bound (all-reduce MAX of clb_searcher_get_bound_consts)", (long long)n_shards);
     w.pending.valid = false;
     return run_search(s, w, (hipStream_t)hip_stream, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores,
                       d_n_cand, 2, nullptr, d_all_top, (int)n_shards);

@@ -87,11 +87,7 @@ class LibraryComm:
 
     def sync_bound_consts(self, searcher):
         """one error bound on every shard (see sync_bound_consts below), over this communicator"""
-        import torch
-        t = torch.from_numpy(searcher.bound_consts.copy()).to(torch.device("cuda", self.device))
-        self.all_reduce_max_(t)
-        torch.cuda.current_stream(t.device).synchronize()
-        searcher.raise_bound_consts(t.cpu().numpy())
+        check(lib().clb_searcher_sync_bound_consts(searcher._h, self._h))     # the round trip inside the library
         return searcher.bound_consts
 
 

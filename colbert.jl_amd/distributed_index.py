@@ -30,6 +30,11 @@ class HipBackend:
         sh = codec.KMeansShard(data, K, point_bsize, device=self.device)
         return sh.pass_
 
+    def device_shard(self, data, K, point_bsize):
+        """The shard handle itself: kmeans_sharded then keeps centroids, partial sums and the exchange on the device."""
+        from . import codec
+        return codec.KMeansShard(data, K, point_bsize, device=self.device)
+
     def reduce_update(self, centroids, gs, gc, tol):
         from . import codec
         return codec.kmeans_reduce_update(centroids, gs, gc, tol, device=self.device)
@@ -58,7 +63,7 @@ def _all_gather(t, group):
 
 
 def kmeans_sharded(local_points, init_centroids, backend, max_iters: int = 10, tol: float = 1e-4, point_bsize: int = 1000,
-                   group=None, comm_device=None):
+                   group=None, comm_device=None, all_gather=None):
     """kmeans_gpu_onehot! over points sharded across the ranks of `group` (contiguous, rank order).
     local_points (dim, n_local) fp32; init_centroids (dim, K), identical on every rank.
     Returns (centroids, iterations executed) -- identical on every rank."""
@@ -66,6 +71,28 @@ def kmeans_sharded(local_points, init_centroids, backend, max_iters: int = 10, t
     import torch.distributed as dist
     c = np.asfortranarray(init_centroids, dtype=np.float32).copy(order="F")
     dim, K = c.shape
+    if comm_device is not None and comm_device.type == "cuda" and hasattr(backend, "device_shard"):
+        # product path: centroids stay in the shard handle, every rank's [sums | counts] block goes straight from the
+        # accumulation kernels into the all-gather (RCCL) and from there into the reduction kernel -- no numpy round trip
+        sh = backend.device_shard(local_points, K, point_bsize)
+        world = dist.get_world_size(group)
+        sh.set_centroids(c)
+        blk = torch.empty(sh.block_bytes, dtype=torch.uint8, device=comm_device)
+        gathered = torch.empty(world * sh.block_bytes, dtype=torch.uint8, device=comm_device)
+        it = 0
+        with torch.cuda.device(comm_device):
+            for it in range(1, max_iters + 1):
+                sh.pass_device(blk)
+                if all_gather is not None:
+                    gathered = all_gather(blk).reshape(-1)          # e.g. LibraryComm.all_gather (clb_comm_all_gather)
+                else:
+                    dist.all_gather_into_tensor(gathered, blk, group=group)
+                _delta, conv = sh.update_device(gathered, world, tol)
+                if conv:
+                    break
+        c = sh.get_centroids()
+        sh.close()
+        return c, (it if max_iters > 0 else 0)
     pass_ = backend.shard(local_points, K, point_bsize)
     dev = comm_device if comm_device is not None else torch.device("cpu")
     it = 0

@@ -208,6 +208,18 @@ int clb_kmeans_shard_create(int device, const float* data /* (dim, n) */, int64_
 int clb_kmeans_shard_destroy(clb_kmeans_shard* h);
 int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids /* (dim,K) */, float* sums /* (dim,K) */,
                           int64_t* counts /* K */, int32_t* assignments /* n, 1-based; may be NULL */);
+/* The same iteration with the exchange kept on the device (the blocks are 64 MB per rank at K = 131 072: no host round
+ * trip).  The centroids live in the shard handle: set_centroids uploads the initial ones (utils.jl:261), pass_device
+ * writes this rank's block -- (dim,K) fp32 sums, padded to 8 bytes, then K int64 counts: clb_kmeans_shard_block_bytes --
+ * into d_block on `hip_stream`, the ranks all-gather the blocks (clb_comm_all_gather / RCCL) and update_device reduces
+ * the n_ranks gathered blocks in rank order and applies utils.jl:302-314 to the handle's centroids (one 4-byte
+ * read-back per iteration: delta).  Bit-identical to clb_kmeans_shard_pass + clb_kmeans_reduce_update. */
+int64_t clb_kmeans_shard_block_bytes(const clb_kmeans_shard* h);
+int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids /* (dim,K) host */);
+int clb_kmeans_shard_get_centroids(clb_kmeans_shard* h, float* centroids /* (dim,K) host */);
+int clb_kmeans_shard_pass_device(clb_kmeans_shard* h, void* d_block, void* hip_stream);
+int clb_kmeans_shard_update_device(clb_kmeans_shard* h, const void* d_gathered /* n_ranks blocks */, int64_t n_ranks,
+                                   float tol, float* delta_out, int* converged, void* hip_stream);
 int clb_kmeans_reduce_update(int device, float* centroids /* (dim,K) in/out */,
                              const float* gathered_sums /* [world][dim*K] */,
                              const int64_t* gathered_counts /* [world][K] */, int64_t world, int64_t dim, int64_t K,
@@ -241,6 +253,11 @@ int clb_comm_size(const clb_comm* c);
 int clb_comm_all_gather(clb_comm* c, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* hip_stream);
 /* element-wise maximum over the ranks, in place (the six bound constants of clb_searcher_get/set_bound_consts) */
 int clb_comm_all_reduce_max_f32(clb_comm* c, float* d_buf, int64_t n, void* hip_stream);
+/* The whole round trip the two-phase sharded search needs once per shard group, inside the library (a host without its
+ * own device arrays -- the Julia shim -- cannot hand clb_comm_all_reduce_max_f32 a device pointer):
+ * clb_searcher_get_bound_consts -> all-reduce MAX over the communicator -> clb_searcher_set_bound_consts.  Collective:
+ * every rank of `c` calls it with its shard's handle.  Blocks until done. */
+int clb_searcher_sync_bound_consts(clb_searcher* s, clb_comm* c);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder  (src/modelling/checkpoint.jl)

@@ -203,3 +203,13 @@ comm_all_gather(c::Communicator, d_send::Ptr{Cvoid}, d_recv::Ptr{Cvoid}, bytes_p
 comm_all_reduce_max!(c::Communicator, d_buf::Ptr{Cvoid}, n::Integer, stream::Ptr{Cvoid} = C_NULL) =
     _check(ccall((:clb_comm_all_reduce_max_f32, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
         c.handle, d_buf, n, stream))
+
+"""
+    sync_bound_consts!(searcher_handle, c::Communicator)
+
+The two-phase sharded search (clb_search_shard_phase1 / phase2) cuts every shard at one global threshold, which is only
+sound when every shard uses the SAME (the largest) error bound: collective over `c`, once after the shards are loaded.
+The library refuses phase 2 with more than one shard until this (or clb_searcher_set_bound_consts) has run.
+"""
+sync_bound_consts!(handle::Ptr{Cvoid}, c::Communicator) =
+    _check(ccall((:clb_searcher_sync_bound_consts, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle, c.handle))

@@ -1,5 +1,6 @@
 """Multi-GPU index build, orchestration on CPU: world_size 2 over gloo with the CPU oracle as the compute backend
-(the HIP library has no CPU fallback; the same orchestration runs over libcolbert_hip in tests/test_gpu_sizes.py).
+(the HIP library has no CPU fallback; the same orchestration runs over libcolbert_hip -- distributed_index.HipBackend -- in
+tests/test_gpu_dist_index.py: device-resident exchange, RCCL with one rank, two rank processes on one GPU).
 Stage-wise parity: the distributed k-means equals the oracle's sharded restatement bit for bit, a single shard equals
 the reference loop bit for bit, the 2-shard centroids agree with the single-device loop to fp32 rounding, and the
 per-shard codes / residual bytes / IVF equal the oracle's on the same inputs."""

@@ -541,7 +541,7 @@ def test_two_phase_sharded_search(oracle, world, k, wide):
     the full index, and the shards together list far fewer passages than with shard-local thresholds.  k = 5000
     exceeds what some queries can return (padding, tau = -inf)."""
     torch = pytest.importorskip("torch")
-    from colbert_jl_amd.distributed import DeviceSearch, merge_packed
+    from colbert_jl_amd.distributed import DeviceSearch, merge_packed, share_bound_consts
     full = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8)
     Qs = synthetic.make_topic_queries(full["centroids"], seed=78, n_queries=9)
     Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
@@ -555,6 +555,11 @@ def test_two_phase_sharded_search(oracle, world, k, wide):
         runs.append(DeviceSearch(s, 32, 9, kk, 2)); keep.append(s)
     tops = torch.stack([r.phase1(Qdev).clone() for r in runs])           # (world, B, k) as an all-gather delivers
     torch.cuda.synchronize()
+    # the protocol checks itself: phase 2 against other shards' scores is refused until the shards share ONE error bound
+    with pytest.raises(clb.ArgumentError):
+        runs[0].phase2(Qdev, tops)
+    share_bound_consts(keep)
+    runs[0].phase1(Qdev)                                                  # (the refused call consumed nothing; redo phase 1)
     packed = []
     for r in runs:
         r.phase2(Qdev, tops)

@@ -45,6 +45,7 @@ def main():
             if rank:
                 sr.close()
         tops = [torch.stack(t) for t in tops]
+        s.raise_bound_consts(s.bound_consts)      # one rank stands in for the group: marks the bound as shared
 
     def step(i):
         if args.two_phase:
