@@ -634,9 +634,16 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (k <= kMaxTopK) {
         Timed t(s, KID_TOPK, st);
         allow_large_topk_lds();
+        // two-pass mode: the ~1.2 k listed passages of a query are ranked by kRankBlocks work-groups (no sorting network);
+        // a query whose list is longer than kRankMax falls through to the one-work-group select + sort
+        const int ranked = list != nullptr && !CLB_KNOB("CLB_DEBUG_NO_RANK", 0);
+        if (ranked)
+            hipLaunchKernelGGL(topk_rank_kernel, dim3(kRankBlocks, B), dim3(1024), 0, st, w.scores.as<float>(),
+                               w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k, w.cand_cap, s->pid_offset,
+                               d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
         hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st,
                            w.scores.as<float>(), w.cand.as<uint32_t>(), w.ncand.as<int>(), list, nlist, k,
-                           kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
+                           kpow2, w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand, ranked);
     } else {      // k above the single-work-group sort: a full stable sort per query (synchronises)
         s->prof.chain = nullptr;
         for (int b = 0; b < B; ++b) CLB_TRY(topk_by_sort(s, w, st, b, list, nlist, k, d_out_pids, d_out_scores, d_n_cand));

@@ -1115,6 +1115,11 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
 // When `list` is given, only the listed candidate slots take part (two-pass mode).
 // grid = B, block = 1024, LDS = 8 * next_pow2(k) + small.
 // -------------------------------------------------------------------------------------------------
+// Short lists (the two-pass mode: ~1.2 k re-scored passages per query for k = 1000) are ranked instead of sorted
+// (topk_rank_kernel below); this kernel then leaves them alone.
+constexpr int kRankMax = 4096;       // listed passages per query the rank kernel takes (32 KB of keys in LDS)
+constexpr int kRankBlocks = 8;       // work-groups per query of the rank kernel
+
 static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores,
                                                     const uint32_t* __restrict__ cand,
                                                     const int* __restrict__ ncand,
@@ -1124,7 +1129,8 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
                                                     int64_t* __restrict__ out_pids,
                                                     float* __restrict__ out_scores,
                                                     int* __restrict__ short_flag,
-                                                    int64_t* __restrict__ n_cand_out /*optional*/) {
+                                                    int64_t* __restrict__ n_cand_out /*optional*/,
+                                                    int ranked_elsewhere = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];  // kpow2 entries
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[32];
@@ -1132,6 +1138,7 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
     __shared__ int s_remaining;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = list ? nlist[b] : ncand[b];
+    if (ranked_elsewhere && list && n <= kRankMax) return;     // topk_rank_kernel has this query
     const float* sc = scores + (size_t)b * cand_cap;
     const int* lst = list ? list + (size_t)b * cand_cap : nullptr;
     const int keff = n < k ? n : k;
@@ -1267,6 +1274,71 @@ static __global__ __launch_bounds__(1024) void topk_kernel(const float* __restri
         }
         out_pids[(size_t)b * k + i] = pid;
         out_scores[(size_t)b * k + i] = s;
+    }
+}
+
+// S7 for short lists: sortperm(scores, rev=true)[1:k] (searching.jl:125-127) by RANKING -- entry i goes to position
+// #{ j : key_j > key_i } with key = (score order key, ~slot), so equal scores keep ascending candidate order = ascending
+// pid exactly as the stable sort does, and no sorting network (55 barrier-separated steps for 1 024 keys, ~28 us on the
+// one work-group a query used to get) is needed: n^2 comparisons spread over kRankBlocks work-groups per query.
+// Every work-group holds all n keys in LDS; thread (e = tid & 255, quarter = tid >> 8) counts the keys of its quarter
+// that beat element e of the work-group's share (a wave reads one key at a time: LDS broadcast), the four partial
+// counts meet in LDS.  Queries with more than kRankMax listed passages (or no list: single-pass mode) are left to
+// topk_kernel.  grid = (kRankBlocks, B), block = 1024.
+static __global__ __launch_bounds__(1024) void topk_rank_kernel(const float* __restrict__ scores,
+                                                                const uint32_t* __restrict__ cand,
+                                                                const int* __restrict__ ncand,
+                                                                const int* __restrict__ list,
+                                                                const int* __restrict__ nlist, int k, size_t cand_cap,
+                                                                int64_t pid_offset, int64_t* __restrict__ out_pids,
+                                                                float* __restrict__ out_scores,
+                                                                int* __restrict__ short_flag,
+                                                                int64_t* __restrict__ n_cand_out /*optional*/) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[kRankMax];
+    __shared__ int ranks[256];
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int n = nlist[b];
+    if (n > kRankMax) return;
+    const float* sc = scores + (size_t)b * cand_cap;
+    const int* lst = list + (size_t)b * cand_cap;
+    const int keff = n < k ? n : k;
+    if (g == 0) {
+        if (tid == 0) {
+            short_flag[b] = n < k ? 1 : 0;
+            if (n_cand_out) n_cand_out[b] = ncand[b];
+        }
+        for (int i = keff + tid; i < k; i += 1024) {          // fewer than k candidates: (0, -Inf) padding
+            out_pids[(size_t)b * k + i] = 0;
+            out_scores[(size_t)b * k + i] = kNegInf;
+        }
+    }
+    for (int i = tid; i < n; i += 1024) {
+        const int slot = lst[i];
+        keys[i] = ((unsigned long long)f32_order_key(sc[slot]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
+    }
+    __syncthreads();
+    const uint32_t* cnd = cand + (size_t)b * cand_cap;
+    const int e = tid & 255, quarter = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int q0 = (int)(((long long)n * quarter) >> 2), q1 = (int)(((long long)n * (quarter + 1)) >> 2);
+    for (int base = g * 256; base < n; base += kRankBlocks * 256) {
+        const int i = base + e;
+        if (tid < 256) ranks[tid] = 0;
+        __syncthreads();
+        const unsigned long long mine = i < n ? keys[i] : ~0ull;
+        int cnt = 0;
+#pragma unroll 4
+        for (int j = q0; j < q1; ++j) cnt += keys[j] > mine;
+        if (cnt) atomicAdd(&ranks[e], cnt);
+        __syncthreads();
+        if (tid < 256 && i < n) {
+            const int r = ranks[e];
+            if (r < keff) {
+                const uint32_t slot = 0xffffffffu - (uint32_t)(mine & 0xffffffffull);
+                out_pids[(size_t)b * k + r] = pid_offset + (int64_t)cnd[slot] + 1;
+                out_scores[(size_t)b * k + r] = sc[slot];
+            }
+        }
+        __syncthreads();
     }
 }
 
