@@ -727,7 +727,13 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // own vmcnt arithmetic for the VGPR loads does not see the DMAs; its waits are therefore stronger than needed by the
 // DMAs in between, never weaker.  A slot is re-filled three stages after its reads were waited for (lgkmcnt) -- both
 // in program order, and the "memory" clobbers keep the compiler from moving the ring reads across either.
-template <bool ROWS, int ABL = 0, int GL = 0>
+// PIPE = 1 (round-3 experiment, instantiated in -DCLB_ABLATIONS builds only): the epilogue of step i-1 (16 multiplies by
+// inv_norm, the maxima, the row-mask bits) is issued in the shadow of step i's MFMA chain -- a wave issues in order and
+// the ten MFMAs of a step depend on each other (SQ_WAIT_INST_ANY: 36 % of the wave cycles).  hipcc does interleave the
+// two streams, but the second accumulator set takes the kernel to the 168-VGPR cap of three waves per SIMD (7-24 spilled
+// registers) and the pass got SLOWER on every workload (0.662 -> 0.672 ms, uniform codes 1.46 -> 1.56, built index
+// 0.653 -> 0.699; the row sweep 0.069 -> 0.107): the pass is not short of issue slots, it waits on memory.
+template <bool ROWS, int ABL = 0, int GL = 0, int PIPE = 0>
 static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
     int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
@@ -746,7 +752,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     // bank pair, so the 16 table reads of a step are conflict-free whatever the bytes are (a single 2-KB table costs
     // ~2 extra LDS cycles per read on random bytes and made the LDS pipe the busiest unit of the kernel)
     __shared__ __attribute__((aligned(16))) unsigned char lut_s[kApproxLdsLut];
-    __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][kStepRows];
+    __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][2 * kStepRows];   // two patches (PIPE)
     static_assert(GL == 0 || ABL == 0, "the ablation variants exist for the VGPR gather only");
     constexpr int kRingBytes = 3 * 2048;                 // three steps in flight x 32 rows x 64 B, per wave
     __shared__ __attribute__((aligned(16))) unsigned char ring_s[GL ? (kApproxThreads / 64) * kRingBytes : 16];
@@ -884,7 +890,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         }                                                                                                   \
     }
 #define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + lut_offset<N>(W, lane8)))
-#define CLB_STAGE_C(RB, CV, X0, X1, PM, TAG, SLOT)                                                          \
+#define CLB_STAGE_CM(RB, CV, X0, X1, SLOT, ACC, INVB)                                                       \
     {                                                                                                       \
         if (GL) {                                                                                           \
             /* this step's two DMAs have landed once at most the 4 youngest VMEM operations are pending     */ \
@@ -894,7 +900,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         }                                                                                                   \
         /* inv_norm: lane layout (row = r) -> accumulator layout (register i = row (i&3) + 8(i>>2) + 4h)  */ \
         __builtin_amdgcn_wave_barrier();                                                                    \
-        myinv[r] = fmaf((float)(CV >> cbits), inv_step, inv_lo);                                            \
+        myinv[(INVB) * kStepRows + r] = fmaf((float)(CV >> cbits), inv_step, inv_lo);                                            \
         __builtin_amdgcn_wave_barrier();                                                                    \
         /* residual byte -> 4 bf16 bucket weights through the LDS table; k-step s = bytes 2s, 2s+1.  All 16  */ \
         /* reads are issued before the first MFMA (an LDS read takes longer than an MFMA: interleaved one  */ \
@@ -907,28 +913,30 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
             tl[12] = CLB_LUT(RB[3], 0); tl[13] = CLB_LUT(RB[3], 1); tl[14] = CLB_LUT(RB[3], 2); tl[15] = CLB_LUT(RB[3], 3); \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        f32x4 iq[4];                                                                                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                       \
-            iq[q] = *reinterpret_cast<const f32x4*>(myinv + 8 * q + 4 * h);                                 \
-        f32x16 acc;                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                        \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X0), sel1, acc, 0, 0, 0);    \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, acc, 0, 0, 0);    \
-        if (ABL == 5) { acc[0] += __uint_as_float(RB[0] ^ RB[1]); acc[1] += __uint_as_float(RB[2] ^ RB[3]); } \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X0), sel1, ACC, 0, 0, 0);    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, ACC, 0, 0, 0);    \
+        if (ABL == 5) { ACC[0] += __uint_as_float(RB[0] ^ RB[1]); ACC[1] += __uint_as_float(RB[2] ^ RB[3]); } \
         else {                                                                                              \
             _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                              \
+                ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                              \
                     __builtin_bit_cast(bf16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
-                    __builtin_bit_cast(bf16x8, qb[s_]), acc, 0, 0, 0);                                      \
+                    __builtin_bit_cast(bf16x8, qb[s_]), ACC, 0, 0, 0);                                      \
         }                                                                                                   \
+    }
+#define CLB_STAGE_E(ACC, INVB, PM, TAG)                                                                     \
+    {                                                                                                       \
+        f32x4 iq[4];                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                       \
+            iq[q] = *reinterpret_cast<const f32x4*>(myinv + (INVB) * kStepRows + 8 * q + 4 * h);                                 \
         /* plain v_mul_f32: packed f32 ops (v_pk_mul_f32) do not overlap the MFMAs of the co-resident waves  */ \
         /* (tools/microbench/issue_overlap: 3 per MFMA gap cost 27 cycles, 6 plain multiplies cost 3); the  */ \
         /* empty asm keeps the SLP vectoriser from re-packing them.  ABL 6: the packed form, for comparison */ \
         float v[16];                                                                                        \
-        if (ABL != 6) { _Pragma("unroll") for (int i = 0; i < 16; ++i) { v[i] = acc[i] * iq[i >> 2][i & 3]; asm volatile("" : "+v"(v[i])); } } \
+        if (ABL != 6) { _Pragma("unroll") for (int i = 0; i < 16; ++i) { v[i] = ACC[i] * iq[i >> 2][i & 3]; asm volatile("" : "+v"(v[i])); } } \
         else                                                                                                \
         _Pragma("unroll") for (int i = 0; i < 16; i += 2) {    /* v_pk_mul_f32: two rows per instruction */ \
-            const f32x2 p_ = f32x2{acc[i], acc[i + 1]} * f32x2{iq[i >> 2][i & 3], iq[i >> 2][(i & 3) + 1]}; \
+            const f32x2 p_ = f32x2{ACC[i], ACC[i + 1]} * f32x2{iq[i >> 2][i & 3], iq[i >> 2][(i & 3) + 1]}; \
             v[i] = p_[0]; v[i + 1] = p_[1];                                                                 \
         }                                                                                                   \
         if (ROWS) {                                                                                         \
@@ -986,24 +994,72 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         uint32_t cv0, cv1, cv2, cw0, cw1, cw2;       // cv: as loaded (stage A); cw: the copy stage C dequantises
         uint16_t pm0 = 0, pm1 = 0, pm2 = 0;
         StepTag t0, t1, t2;
+        f32x16 acc0, acc1;
         CLB_STAGE_A(rb0, cv0, pm0, t0);
         CLB_STAGE_A(rb1, cv1, pm1, t1);
         CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
-        while (t0.j >= 0) {
-            CLB_STAGE_A(rb2, cv2, pm2, t2);
-            CLB_STAGE_G(cv1, xa1, xb1, 1); cw1 = cv1;
-            CLB_STAGE_C(rb0, cw0, xa0, xb0, pm0, t0, 0);
-            CLB_STAGE_A(rb0, cv0, pm0, t0);
-            CLB_STAGE_G(cv2, xa2, xb2, 2); cw2 = cv2;
-            CLB_STAGE_C(rb1, cw1, xa1, xb1, pm1, t1, 1);
-            CLB_STAGE_A(rb1, cv1, pm1, t1);
-            CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
-            CLB_STAGE_C(rb2, cw2, xa2, xb2, pm2, t2, 2);
+        if (!PIPE) {
+            while (t0.j >= 0) {
+                CLB_STAGE_A(rb2, cv2, pm2, t2);
+                CLB_STAGE_G(cv1, xa1, xb1, 1); cw1 = cv1;
+                CLB_STAGE_CM(rb0, cw0, xa0, xb0, 0, acc0, 0);
+                CLB_STAGE_E(acc0, 0, pm0, t0);
+                CLB_STAGE_A(rb0, cv0, pm0, t0);
+                CLB_STAGE_G(cv2, xa2, xb2, 2); cw2 = cv2;
+                CLB_STAGE_CM(rb1, cw1, xa1, xb1, 1, acc0, 0);
+                CLB_STAGE_E(acc0, 0, pm1, t1);
+                CLB_STAGE_A(rb1, cv1, pm1, t1);
+                CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
+                CLB_STAGE_CM(rb2, cw2, xa2, xb2, 2, acc0, 0);
+                CLB_STAGE_E(acc0, 0, pm2, t2);
+            }
+        } else {
+            // tp / pmp: tag and stored maximum of the step whose epilogue is pending; the dummy "previous step" of a
+            // chunk's first iteration ends a passage nobody stores (j < 0), which also resets mx and the row mask
+            StepTag tp; tp.j = -1; tp.rows = kStepRows; tp.last = 1; tp.base = 0;
+            uint16_t pmp = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            for (;;) {
+                if (t0.j < 0) { CLB_STAGE_E(acc1, 1, pmp, tp); break; }
+                CLB_STAGE_A(rb2, cv2, pm2, t2);
+                CLB_STAGE_G(cv1, xa1, xb1, 1); cw1 = cv1;
+                CLB_STAGE_CM(rb0, cw0, xa0, xb0, 0, acc0, 0);
+                CLB_STAGE_E(acc1, 1, pmp, tp);
+                tp = t0; pmp = pm0;
+                CLB_STAGE_A(rb0, cv0, pm0, t0);
+                CLB_STAGE_G(cv2, xa2, xb2, 2); cw2 = cv2;
+                CLB_STAGE_CM(rb1, cw1, xa1, xb1, 1, acc1, 1);
+                CLB_STAGE_E(acc0, 0, pmp, tp);
+                tp = t1; pmp = pm1;
+                CLB_STAGE_A(rb1, cv1, pm1, t1);
+                CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
+                CLB_STAGE_CM(rb2, cw2, xa2, xb2, 2, acc0, 0);
+                CLB_STAGE_E(acc1, 1, pmp, tp);
+                tp = t2; pmp = pm2;
+                if (t0.j < 0) { CLB_STAGE_E(acc0, 0, pmp, tp); break; }
+                CLB_STAGE_A(rb2, cv2, pm2, t2);
+                CLB_STAGE_G(cv1, xa1, xb1, 1); cw1 = cv1;
+                CLB_STAGE_CM(rb0, cw0, xa0, xb0, 0, acc1, 1);
+                CLB_STAGE_E(acc0, 0, pmp, tp);
+                tp = t0; pmp = pm0;
+                CLB_STAGE_A(rb0, cv0, pm0, t0);
+                CLB_STAGE_G(cv2, xa2, xb2, 2); cw2 = cv2;
+                CLB_STAGE_CM(rb1, cw1, xa1, xb1, 1, acc0, 0);
+                CLB_STAGE_E(acc1, 1, pmp, tp);
+                tp = t1; pmp = pm1;
+                CLB_STAGE_A(rb1, cv1, pm1, t1);
+                CLB_STAGE_G(cv0, xa0, xb0, 0); cw0 = cv0;
+                CLB_STAGE_CM(rb2, cw2, xa2, xb2, 2, acc1, 1);
+                CLB_STAGE_E(acc0, 0, pmp, tp);
+                tp = t2; pmp = pm2;
+            }
         }
         }   // chunk of 64 passages
 #undef CLB_STAGE_A
 #undef CLB_STAGE_G
-#undef CLB_STAGE_C
+#undef CLB_STAGE_CM
+#undef CLB_STAGE_E
 #undef CLB_LUT
     }
 }

@@ -563,6 +563,14 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                        (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,                    \
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
 #ifdef CLB_ABLATIONS
+            if (CLB_KNOB("CLB_DEBUG_APPROX_PIPE", 0)) {     // round-3 experiment: epilogue of step i-1 under step i's MFMAs (slower: profiles/r03_experiments.md)
+                auto kern = s->gather_lds ? score_approx32_kernel<false, 0, 1, 1> : score_approx32_kernel<false, 0, 0, 1>;
+                hipLaunchKernelGGL(kern, approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+                                   s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
+                                   w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                                   (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                                   (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
+            } else
             switch (CLB_KNOB("CLB_DEBUG_APPROX_VARIANT", 0)) {
                 case 1: CLB_LAUNCH_APPROX(1); break;
                 case 2: CLB_LAUNCH_APPROX(2); break;
@@ -574,14 +582,14 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 default: CLB_LAUNCH_APPROX(0);
             }
 #else
-            if (s->gather_lds)
-                hipLaunchKernelGGL((score_approx32_kernel<false, 0, 1>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+            {
+                auto kern = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
+                hipLaunchKernelGGL(kern, approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                                    s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                                    w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                                    (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
                                    (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
-            else
-                CLB_LAUNCH_APPROX(0);
+            }
 #endif
 #undef CLB_LAUNCH_APPROX
         }
@@ -606,7 +614,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 256);
         const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 32);
         // (the row sweep keeps the VGPR gather: its ~1 200 passages per query are faster with it on every workload measured)
-        auto rows_kernel = score_approx32_kernel<true, 0, 0>;
+        auto rows_kernel = score_approx32_kernel<true, 0, 0, 0>;
         hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                            s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
@@ -1093,7 +1101,7 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
-    auto dbg_kernel = s->gather_lds ? score_approx32_kernel<false, 0, 1> : score_approx32_kernel<false, 0, 0>;
+    auto dbg_kernel = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
     hipLaunchKernelGGL(dbg_kernel, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
