@@ -1,4 +1,4 @@
-// approx_kernels.hpp -- two-pass search, pass 1: approximate MaxSim on the bf16 MFMA straight from the
+// approx_kernels.hpp -- two-pass search, pass 1: approximate MaxSim on the 16-bit-input MFMA (fp16 operands since round 3; bf16 before) straight from the
 // packed index, plus the selection of the candidates that must be re-scored exactly.
 //
 // Why: an exact fp32 score costs 8 192 flop per 36 packed bytes (227 flop/B; the fp32-MFMA ridge is ~25), so
@@ -14,9 +14,9 @@
 //     S[t][e] = Q_t . x / den  =  ( Q_t . c  +  Q_t . r ) * inv_norm[e]
 //   * Q_t . c  = cells[t][code]  -- already computed exactly by centroid_scores_kernel (S1); stored for this
 //                pass as fp16 rows [K][32 tokens] (64 B per centroid) to halve the gather;
-//   * Q_t . r  -- r[d] = bucket_weight[idx[d]] takes only 2^nbits values: a 4-entry bf16 LUT applied with
+//   * Q_t . r  -- r[d] = bucket_weight[idx[d]] takes only 2^nbits values: a 4-entry fp16 LUT applied with
 //                v_perm_b32 to 2 dims at a time (selector built from the packed nibble with one u24 multiply),
-//                fed as the A operand of v_mfma_f32_16x16x32_bf16 against bf16(Q) -- no centroid row is read,
+//                fed as the A operand of v_mfma_f32_16x16x32_bf16 against fp16(Q) -- no centroid row is read,
 //                nothing is normalised per element;
 //   * inv_norm[e] = 1/(sqrtf(sumsq(c+r)) + eps32), precomputed once per index (fp32, canonical sumsq).
 // Per embedding this pass reads 32 B residual + ONE 4-B word (code | quantised inv_norm) from HBM (streaming) and gathers one
@@ -27,8 +27,8 @@
 //   cells:   bf16x3 MFMA value vs canonical fp32 chain <= 1.25*7.4e-5*qn*cn       (centroid_top_bf16x3_kernel)
 //            fp16 storage                            <= 2^-11 * qn*cn + 2^-25  (|cells| <= qn*cn < 65504: guarded in
 //                                                       select_margin_kernel; 2^-25: values below the normal range)
-//   Q.r:     bf16(Q), bf16(w)                        <= dq * rb + qn * dw_rn  (dq = max_t ||Q_t - bf16(Q_t)|| per query,
-//                                                       rb = max ||bf16 residual vector||, dw_rn = sqrt(dim) * max |w - bf16(w)|
+//   Q.r:     fp16(Q), fp16(w)                        <= dq * rb + qn * dw_rn  (dq = max_t ||Q_t - fp16(Q_t)|| per query,
+//                                                       rb = max ||fp16 residual vector||, dw_rn = sqrt(dim) * max |w - fp16(w)|
 //                                                       per index: measured, not the generic 2^-9 relative bounds)
 //            fp32 accumulation in the MFMA           <= 2*128*u*qn*rn
 //   scaling: add, multiply, inv_norm rounding        <= 8*u*qn
@@ -62,6 +62,14 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
 }
+// fp16 (round to nearest even, subnormals kept: v_cvt_f16_f32) -- the operand format of pass 1's Q.r MFMAs since round 3:
+// 11 significant bits where bf16 has 8, so the measured rounding terms of the error bound (dq, dw_rn) are 8x smaller;
+// v_mfma_f32_32x32x16_f16 multiplies subnormal inputs exactly (tools/microbench/mfma_f16_denorm.hip, checked on MI355X)
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    const __half2 h = __floats2half2_rn(lo, hi);
+    return *reinterpret_cast<const uint32_t*>(&h);
+}
 
 // NOTE: never feed an MFMA accumulator straight into this helper.  The wait states an MFMA result needs before a
 // VALU read are inserted by the compiler only for instructions it can see through; through the inline asm a stale
@@ -82,11 +90,11 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __res
                                                              unsigned int* __restrict__ r2_max_bits,
                                                              unsigned int* __restrict__ inv_min_bits) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    float w[4], wb2[4];      // wb2: squares of the bf16-rounded weights (the residual vector pass 1 multiplies)
+    float w[4], wb2[4];      // wb2: squares of the fp16-rounded weights (the residual vector pass 1 multiplies)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         w[j] = weights[j];
-        const float wb = __uint_as_float(f32_to_bf16_rne(weights[j]) << 16);
+        const float wb = round_f16(weights[j]);
         wb2[j] = wb * wb;
     }
     const int64_t groups = (n + 15) / 16;
@@ -624,10 +632,10 @@ static __global__ __launch_bounds__(256) void cells_to_half_kernel(const float* 
 // -------------------------------------------------------------------------------------------------------------
 // Pass 1.  A wave walks its candidate passages in steps of 32 embeddings; one step is one 32 x 32 tile
 // S[e][t] = ( X[code_e][t] + sum_d w[idx_e,d] * Q[t][d] ) * inv_norm[e]  on v_mfma_f32_32x32x16:
-//   * Q.r: A (32 embeddings x 16 dims per k-step) = bf16 bucket weights expanded from the packed residual through a
+//   * Q.r: A (32 embeddings x 16 dims per k-step) = fp16 bucket weights expanded from the packed residual through a
 //     2-KB LDS table (one ds_read_b64 per residual byte: 4 dims); lane (r = lane & 31, h = lane >> 5) owns bytes
 //     16h .. 16h+15 of embedding r -- ONE 16-byte load per lane and step -- i.e. dims 64h + 8s + j in k-step s;
-//     B = bf16(Q) resident in registers in the same dim order (8 k-steps x 4 VGPRs);
+//     B = fp16(Q) resident in registers in the same dim order (8 k-steps x 4 VGPRs);
 //   * X (the fp16 centroid scores of S1, rows of 32 tokens = 64 B): two more MFMAs (f16 inputs) against a 0/1
 //     selection matrix ADD the gathered row into the accumulator: lane (r, h) fetches tokens 8h..8h+7 and
 //     16+8h..16+8h+7 of row code_r as two 16-byte loads, which are exactly the A fragments of those MFMAs (k = token).
@@ -747,7 +755,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     const int wg = blockIdx.x >> 3;           // index inside the group
     const int wg_per_group = gridDim.x >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // byte LUT in LDS: entry v = bf16 bucket weights of the 4 dims packed in residual byte v (LSB-first 2-bit fields),
+    // byte LUT in LDS: entry v = fp16 bucket weights of the 4 dims packed in residual byte v (LSB-first 2-bit fields),
     // replicated once per lane slot (lane & 31) at v * 256 + slot * 8: every lane of a ds_read_b64 group reads its own
     // bank pair, so the 16 table reads of a step are conflict-free whatever the bytes are (a single 2-KB table costs
     // ~2 extra LDS cycles per read on random bytes and made the LDS pipe the busiest unit of the kernel)
@@ -759,7 +767,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
         const int v = i >> 5;
         *reinterpret_cast<uint2*>(lut_s + (size_t)i * 8) =
-            make_uint2(pack_bf16(weights[v & 3], weights[(v >> 2) & 3]), pack_bf16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
+            make_uint2(pack_f16(weights[v & 3], weights[(v >> 2) & 3]), pack_f16(weights[(v >> 4) & 3], weights[(v >> 6) & 3]));
     }
     __syncthreads();
     const char* lut = reinterpret_cast<const char*>(lut_s);
@@ -796,7 +804,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     if (grid2d) { b_first = blockIdx.y; b_step = B; sub = 0; nsub = 1; }
 
     for (int b = b_first; b < B; b += b_step) {
-        // B operand: bf16 Q[t = r][64h + 8s + j], k-steps s = 0..7
+        // B operand: fp16 Q[t = r][64h + 8s + j], k-steps s = 0..7
         u32x4 qb[8];
         {
             const float* qrow = Q + ((size_t)b * T + (r < T ? r : T - 1)) * kDim + 64 * h;
@@ -805,7 +813,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
                 float4 lo = *reinterpret_cast<const float4*>(qrow + 8 * s);
                 float4 hi = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
                 if (r >= T) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
-                qb[s] = u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
+                qb[s] = u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)};
             }
         }
         const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
@@ -902,7 +910,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         __builtin_amdgcn_wave_barrier();                                                                    \
         myinv[(INVB) * kStepRows + r] = fmaf((float)(CV >> cbits), inv_step, inv_lo);                                            \
         __builtin_amdgcn_wave_barrier();                                                                    \
-        /* residual byte -> 4 bf16 bucket weights through the LDS table; k-step s = bytes 2s, 2s+1.  All 16  */ \
+        /* residual byte -> 4 fp16 bucket weights through the LDS table; k-step s = bytes 2s, 2s+1.  All 16  */ \
         /* reads are issued before the first MFMA (an LDS read takes longer than an MFMA: interleaved one  */ \
         /* pair ahead, as the compiler schedules them on its own, the MFMA chain runs at the LDS latency)   */ \
         uint2 tl[16];                                                                                       \
@@ -919,9 +927,9 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         if (ABL == 5) { ACC[0] += __uint_as_float(RB[0] ^ RB[1]); ACC[1] += __uint_as_float(RB[2] ^ RB[3]); } \
         else {                                                                                              \
             _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
-                ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                              \
-                    __builtin_bit_cast(bf16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
-                    __builtin_bit_cast(bf16x8, qb[s_]), ACC, 0, 0, 0);                                      \
+                ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                               \
+                    __builtin_bit_cast(f16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
+                    __builtin_bit_cast(f16x8, qb[s_]), ACC, 0, 0, 0);                                       \
         }                                                                                                   \
     }
 #define CLB_STAGE_E(ACC, INVB, PM, TAG)                                                                     \
@@ -1084,8 +1092,8 @@ struct ApproxConsts {
     float cn_max;   // max ||centroid||
     float rn_max;   // sqrt(dim) * max |bucket weight|  (>= ||r|| of every embedding)
     float inv_max;  // max inv_norm
-    float rb_max;   // max over the shard's embeddings of ||r'||, r' = the bf16-rounded residual vector
-    float dw_rn;    // sqrt(dim) * max_b |bf16(w_b) - w_b|  (>= ||r - r'|| of every embedding)
+    float rb_max;   // max over the shard's embeddings of ||r'||, r' = the fp16-rounded residual vector
+    float dw_rn;    // sqrt(dim) * max_b |fp16(w_b) - w_b|  (>= ||r - r'|| of every embedding)
     float inv_qerr; // max |dequantised inv_norm - inv_norm| = half a quantisation step of the packed code|inv word
 };
 
@@ -1099,15 +1107,15 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
     if (tid == 0) { *s_qn = 0.f; *s_dq = 0.f; }
     __syncthreads();
-    {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - bf16(Q_t)||: what the
-        // bf16 query operand of pass 1 really loses (at most 2^-9 ||Q_t||, ~0.6 of that for typical values)
+    {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - fp16(Q_t)||: what the
+        // fp16 query operand of pass 1 really loses (at most 2^-12 ||Q_t|| in the normal range)
         const int t = tid >> 5, part = tid & 31;
         float a = 0.f, dd = 0.f;
         if (t < T) {
             const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
             a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
-            const float dx = v.x - __uint_as_float(f32_to_bf16_rne(v.x) << 16), dy = v.y - __uint_as_float(f32_to_bf16_rne(v.y) << 16);
-            const float dz = v.z - __uint_as_float(f32_to_bf16_rne(v.z) << 16), dw = v.w - __uint_as_float(f32_to_bf16_rne(v.w) << 16);
+            const float dx = v.x - round_f16(v.x), dy = v.y - round_f16(v.y);
+            const float dz = v.z - round_f16(v.z), dw = v.w - round_f16(v.w);
             dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
         }
 #pragma unroll
@@ -1122,7 +1130,7 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     const float qn = *s_qn;
     // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
     const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
-    // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the bf16 operands (their products are exact
+    // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the fp16 operands (their products are exact
     // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
     // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
     const float e_qr = 1.001f * (*s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
@@ -1134,7 +1142,7 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
     // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
     // scored by the exact kernel alone, exactly as in mode 0.  (NaN-safe: written with negated comparisons.)
-    r.unsafe = !(qn * ac.cn_max < 3.0e4f) || !(eps_t < 1.0e30f);
+    r.unsafe = !(qn * ac.cn_max < 3.0e4f) || !(qn < 6.0e4f) /* the fp16 query operand */ || !(eps_t < 1.0e30f);
     r.eps_sum = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
     return r;
 }
@@ -1605,6 +1613,17 @@ static __global__ void max_abs_kernel(const float* __restrict__ v, int n, unsign
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
 }
+// max_b |w_b - fp16(w_b)| with the device's own conversion (the one the LUT of pass 1 is built with); a weight beyond
+// the fp16 range makes the bound infinite (such an index is searched exactly)
+static __global__ void max_f16_err_kernel(const float* __restrict__ v, int n, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float w = v[i];
+        m = fmaxf(m, fabsf(w) < 6.0e4f ? fabsf(round_f16(w) - w) : __builtin_inff());
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(m));
+}
 static __global__ void max_row_norm_kernel(const float* __restrict__ C, int K, unsigned int* __restrict__ out_bits) {
     float m = 0.f;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
@@ -1623,8 +1642,9 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
                                int cbits, int n_weights, ApproxConsts* out, float* inv_lo = nullptr,
                                float* inv_step = nullptr) {
     DevBuf tmp, inv;
-    CLB_TRY(tmp.alloc(5 * sizeof(unsigned int)));
+    CLB_TRY(tmp.alloc(6 * sizeof(unsigned int)));
     CLB_HIP(hipMemsetAsync(tmp.p, 0, 4 * sizeof(unsigned int), st));
+    CLB_HIP(hipMemsetAsync(static_cast<char*>(tmp.p) + 5 * sizeof(unsigned int), 0, sizeof(unsigned int), st));
     CLB_HIP(hipMemsetAsync(static_cast<char*>(tmp.p) + 4 * sizeof(unsigned int), 0x7f, sizeof(unsigned int), st));  // +huge
     unsigned int* bits = tmp.as<unsigned int>();
     const bool pack = n_emb > 0 && d_codeinv;
@@ -1635,30 +1655,21 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
                            bits + 3, bits + 4);
     }
     hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 1);
+    hipLaunchKernelGGL(max_f16_err_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 5);
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
     CLB_HIP(hipGetLastError());
-    unsigned int h[5];
-    float hw[16];
+    unsigned int h[6];
     CLB_HIP(hipMemcpyAsync(h, bits, sizeof h, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(hw, dW, sizeof(float) * std::min(n_weights, 16), hipMemcpyDeviceToHost, st));
     CLB_HIP(hipStreamSynchronize(st));
-    float f[5];
+    float f[6];
     memcpy(f, h, sizeof f);
     out->inv_max = f[0] * 1.0001f;
     out->rn_max = sqrtf((float)kDim) * f[1] * 1.0001f;
     out->cn_max = f[2];
-    float dw = 0.f;
-    for (int j = 0; j < std::min(n_weights, 16); ++j) {
-        uint32_t u32;
-        memcpy(&u32, &hw[j], 4);
-        const uint32_t b16 = (u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16 << 16;
-        float wb;
-        memcpy(&wb, &b16, 4);
-        dw = std::max(dw, std::fabs(wb - hw[j]));
-    }
+    const float dw = f[5];      // max_b |w_b - fp16(w_b)|
     out->dw_rn = sqrtf((float)kDim) * dw * 1.0001f;
-    // no inv_norm pass (constants only): fall back to the generic bound ||r'|| <= sqrt(dim) * max |w| * (1 + 2^-8)
-    out->rb_max = pack ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.004f;
+    // no inv_norm pass (constants only): fall back to the generic bound ||r'|| <= sqrt(dim) * max |w| * (1 + 2^-11)
+    out->rb_max = pack ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.0005f;
     out->inv_qerr = 0.f;
     if (pack) {
         // at most 20 bits for inv_norm: every level is then an exact float (a 26-bit qmax rounds UP as a float and the

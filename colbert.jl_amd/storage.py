@@ -21,6 +21,11 @@ def _save(path: str, a) -> None:
 
 
 def _load(path: str):
+    """`<path>.jld2` (the reference's format); an index directory written by round 1 of this package holds `<path>.npy`
+    instead and is still read."""
+    if not os.path.isfile(path + EXT) and os.path.isfile(path + ".npy"):
+        a = np.load(path + ".npy")
+        return a if a.ndim == 0 else np.asfortranarray(a)
     return jld2.load_object(path + EXT)
 
 

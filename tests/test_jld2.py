@@ -111,3 +111,109 @@ def test_index_directory_uses_the_reference_file_names(tmp_path):
     assert np.array_equal(jld2.load_object(os.path.join(d, "centroids.jld2")), C)
     assert jld2.load_object(os.path.join(d, "avg_residual.jld2")) == np.float32(0.03)
     assert jld2.load_object(os.path.join(d, "doclens.1.jld2")).dtype == np.int64
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Field-by-field conformance of what the writer emits with the HDF5 file-format specification (version 3.0, sections
+# II.A superblock, IV.A.1.b version-2 object header, IV.A.2 header messages) -- parsed HERE from the specification,
+# independently of jld2._File, plus the constants JLD2.jl itself uses for plain numbers (its h5fieldtype methods:
+# class | version 3 << 4, bit field 0x20 / 0x1f for IEEE floats, 0x08 for signed integers).  What JLD2.jl would have to
+# accept when it opens one of these files is exactly these structures (src/loaders.jl:10-38 -> JLD2.load_object).
+# ---------------------------------------------------------------------------------------------------------------------
+def _walk_v2_header(buf, p):
+    """[(type, flags, body)] of the version-2 object header at absolute offset p; asserts the prefix fields."""
+    assert buf[p:p + 4] == b"OHDR" and buf[p + 4] == 2
+    flags = buf[p + 5]
+    assert flags & 0xC0 == 0                                   # reserved bits
+    assert flags & 0x20 == 0 and flags & 0x10 == 0            # no times, no attribute phase-change fields
+    nsz = 1 << (flags & 3)
+    size = int.from_bytes(buf[p + 6:p + 6 + nsz], "little")
+    q = p + 6 + nsz
+    assert struct.unpack_from("<I", buf, q + size)[0] == jld2.lookup3(buf[p:q + size])
+    out, lo, hi = [], q, q + size
+    while lo < hi:
+        mtype, msize, mflags = buf[lo], struct.unpack_from("<H", buf, lo + 1)[0], buf[lo + 3]
+        assert flags & 0x04 == 0                               # creation order not tracked: 4-byte message headers
+        out.append((mtype, mflags, buf[lo + 4:lo + 4 + msize]))
+        lo += 4 + msize
+    assert lo == hi, "messages must fill the chunk exactly (no gap smaller than a message header)"
+    return out, q + size + 4
+
+
+@pytest.mark.parametrize("arr,julia_type", [
+    (np.float32(0.5), "Float32"),
+    (np.asfortranarray(np.arange(128 * 40, dtype=np.float32).reshape(128, 40, order="F")), "Matrix{Float32}"),
+    (np.arange(5, dtype=np.float32), "Vector{Float32}"),
+    (np.arange(7000, dtype=np.uint32), "Vector{UInt32}"),
+    (np.asfortranarray(np.arange(32 * 500, dtype=np.uint8).reshape(32, 500, order="F")), "Matrix{UInt8}"),
+    (np.arange(3000, dtype=np.int64), "Vector{Int64}"),
+])
+def test_written_structures_follow_the_hdf5_specification(tmp_path, arr, julia_type):
+    path = str(tmp_path / "s.jld2")
+    jld2.save_object(path, arr)
+    buf = open(path, "rb").read()
+    a = np.asarray(arr)
+    # --- JLD2 text header: 512 bytes, version string, NUL-terminated
+    assert len(buf) > 512 and buf[:37] == b"HDF5-based Julia Data Format, version " [:37]
+    assert buf[38:43] == b"0.1.1" and buf[43] == 0
+    # --- superblock version 2 (spec II.A): signature, version, size of offsets / lengths, consistency flags, four addresses
+    sb = 512
+    assert buf[sb:sb + 8] == b"\x89HDF\r\n\x1a\n"
+    ver, so, sl, cflags = buf[sb + 8:sb + 12]
+    assert (ver, so, sl, cflags) == (2, 8, 8, 0)
+    base, ext, eof, root = struct.unpack_from("<QQQQ", buf, sb + 12)
+    assert base == 512 and ext == 0xFFFFFFFFFFFFFFFF          # base address = where the superblock sits (JLD2's offset)
+    assert base + eof == len(buf) and root % 8 == 0
+    assert struct.unpack_from("<I", buf, sb + 44)[0] == jld2.lookup3(buf[sb:sb + 44])
+    # --- root group: link info (v0, no creation order, no dense storage), group info (v0), ONE hard link
+    msgs, _ = _walk_v2_header(buf, base + root)
+    types = [m[0] for m in msgs]
+    assert types == [2, 10, 6]
+    li = msgs[0][2]
+    assert li[0] == 0 and li[1] == 0 and struct.unpack_from("<QQ", li, 2) == (2 ** 64 - 1, 2 ** 64 - 1) and len(li) == 18
+    assert msgs[1][2] == b"\x00\x00"
+    lk = msgs[2][2]
+    assert lk[0] == 1                                          # link message version 1
+    assert lk[1] == 0x00                                       # hard link, 1-byte name length, no creation order / charset
+    assert lk[2] == 20 and lk[3:23] == b"single_stored_object"
+    ds_rel = struct.unpack_from("<Q", lk, 23)[0]
+    assert len(lk) == 31 and ds_rel == 48                      # the dataset header follows the 48-byte superblock
+    # --- dataset: dataspace, datatype (shared-message flag bit 0 set as constant), layout
+    msgs, end = _walk_v2_header(buf, base + ds_rel)
+    assert [m[0] for m in msgs] == [1, 3, 8]
+    sp = msgs[0][2]
+    assert sp[0] == 2 and sp[2] == 0                           # dataspace version 2, no maximum dimensions
+    if a.ndim == 0:
+        assert sp[1] == 0 and sp[3] == 0 and len(sp) == 4      # scalar
+    else:
+        assert sp[1] == a.ndim and sp[3] == 1 and len(sp) == 4 + 8 * a.ndim
+        dims = struct.unpack_from("<" + "Q" * a.ndim, sp, 4)
+        assert dims == tuple(reversed(a.shape))                # Julia (column-major) dims reversed: fastest LAST
+    dt = msgs[1][2]
+    cls, version = dt[0] & 0x0F, dt[0] >> 4
+    assert version == 3                                        # what JLD2.jl writes; HDF5 accepts 1..3
+    assert struct.unpack_from("<I", dt, 4)[0] == a.dtype.itemsize
+    if a.dtype.kind == "f":
+        # IEEE little-endian: byte order 0, padding 0, mantissa normalisation 2 (implied MSB), sign location 31
+        assert cls == 1 and dt[1] == 0x20 and dt[2] == 31 and dt[3] == 0
+        assert struct.unpack_from("<HHBBBBI", dt, 8) == (0, 32, 23, 8, 0, 23, 127) and len(dt) == 20
+    else:
+        assert cls == 0 and dt[1] == (0x08 if a.dtype.kind == "i" else 0x00) and dt[2] == 0 and dt[3] == 0
+        assert struct.unpack_from("<HH", dt, 8) == (0, 8 * a.dtype.itemsize) and len(dt) == 12
+    lay = msgs[2][2]
+    raw = np.asfortranarray(a).tobytes(order="F")
+    assert lay[0] == 3                                         # data layout message version 3
+    if lay[1] == 0:                                            # compact: size (2 bytes) + the data inside the header
+        assert struct.unpack_from("<H", lay, 2)[0] == len(raw) and lay[4:] == raw and len(raw) < 8192
+    else:                                                      # contiguous: address (relative to base) + size
+        assert lay[1] == 1 and len(lay) == 18
+        addr, size = struct.unpack_from("<QQ", lay, 2)
+        assert size == len(raw) and addr % 8 == 0 and base + addr >= end
+        assert buf[base + addr:base + addr + size] == raw
+        assert base + addr + size <= base + root               # data lies between the dataset header and the root group
+
+
+def test_npy_index_directories_of_round_one_still_load(tmp_path):
+    a = np.arange(12, dtype=np.int64)
+    np.save(str(tmp_path / "ivf.npy"), a)
+    assert np.array_equal(storage._load(str(tmp_path / "ivf")), a)
