@@ -782,7 +782,7 @@ def main():
                                        f"{', uniform codes' if args.uniform_codes else ''}), ") +
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
-                          "search_mode": ("two-pass (bf16 MFMA prefilter + exact fp32 re-score)" if (prof and "score_approx" in prof) else "exact fp32 single pass")
+                          "search_mode": ("two-pass (fp16 MFMA prefilter + exact fp32 re-score)" if (prof and "score_approx" in prof) else "exact fp32 single pass")
                                          + (", global threshold exchange between the passes" if two_phase else "")},
                "batches_in_flight": NF if overlap[0] else 1, "in_flight_matches_serial": in_flight_ok,
                "one_batch_at_a_time": {"value": round(B * args.steps / serial_s, 2), "ms_per_step": round(serial_s / args.steps * 1e3, 4)},

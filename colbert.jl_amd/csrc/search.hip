@@ -823,7 +823,9 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
             hipStreamSynchronize(s->stream) != hipSuccess)
             return bail(fail(CLB_EHIP, "code statistics failed"));
         s->code_adjacency = n_sample > 1 ? (double)adj / (double)(n_sample - 1) : 0.0;
-        s->gather_lds = s->code_adjacency < 0.2;
+        // ... and only pays when the query's score table (64 B per centroid) does not fit the 4-MB L2 of an XCD: with a
+        // resident table the two forms are equal within 2 % (built index, K = 32 768: 0.663 / 0.668 ms)
+        s->gather_lds = s->code_adjacency < 0.2 && (int64_t)K * 64 > ((int64_t)4 << 20);
         if (const char* g = getenv("COLBERT_PASS1_GATHER")) s->gather_lds = strcmp(g, "vgpr") != 0;   // "vgpr" / "lds": comparison runs
     }
     if (s->approx_ok) {
@@ -899,7 +901,7 @@ int clb_searcher_sync_bound_consts(clb_searcher* s, clb_comm* c) {
 int clb_searcher_set_pass1_gather(clb_searcher* s, int form) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
     if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "pass-1 gather form must be -1 (by the code statistics), 0 (VGPR) or 1 (LDS-DMA)");
-    s->gather_lds = form < 0 ? (s->code_adjacency < 0.2) : form;
+    s->gather_lds = form < 0 ? (s->code_adjacency < 0.2 && s->K * 64 > ((int64_t)4 << 20)) : form;
     return CLB_OK;
 }
 int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
