@@ -614,7 +614,9 @@ __device__ __forceinline__ void decompress_lane_dims_fast(const float* __restric
         // dim d = 4s+g starts at bit d*NBITS = 4s*NBITS + g*NBITS; a group of four dims never crosses a dword
         const int bit0 = 4 * s * NBITS;
         const uint32_t idx = __builtin_amdgcn_ubfe(R[bit0 >> 5], (uint32_t)((bit0 & 31) + g * NBITS), (uint32_t)NBITS);
-        const float c = ctile ? ctile[(s * 16 + (r ^ (s & 15))) * 4 + g] : cent_row[4 * s];
+        // staged tile: the four words of a 16-byte slot are rotated by two for slots >= 8 -- without it slots j and j + 8
+        // share their banks and every one of these 32 reads took a second LDS cycle (SQ_LDS_BANK_CONFLICT = one per MFMA)
+        const float c = ctile ? ctile[(s * 16 + (r ^ (s & 15))) * 4 + ((g + 2 * (((r >> 3) ^ ((s & 15) >> 3)) & 1)) & 3)] : cent_row[4 * s];
         const float val = c + tbl_lane[idx * 32];
         x[s] = val;
         const float sq = val * val;
@@ -699,7 +701,12 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
         row##m = *reinterpret_cast<const float4*>(C + (size_t)(rhalf ? cb : ca) * kDim + 4 * c4);              \
     }
 #define CLB_ROW_STORE(m)                                                                                       \
-    *reinterpret_cast<float4*>(ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4) = row##m;
+    {   /* two 8-byte stores: {x, y} and {z, w} swap places in the slots >= 8 (see decompress_lane_dims_fast) */   \
+        float* sl_ = ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4;                                    \
+        const int ro_ = 2 * ((((2 * m + rhalf) >> 3) ^ (c4 >> 3)) & 1);                                        \
+        *reinterpret_cast<float2*>(sl_ + ro_) = make_float2(row##m.x, row##m.y);                               \
+        *reinterpret_cast<float2*>(sl_ + (ro_ ^ 2)) = make_float2(row##m.z, row##m.w);                         \
+    }
 
     // with one token group the passage loop runs per wave; with several, all waves of the workgroup walk the
     // groups together (the staged operand is shared), so the loop order is group-major
@@ -866,7 +873,12 @@ static __global__ __launch_bounds__(256, 3) void score_exact_flat_kernel(
     CLB_ROW_LOAD(P, CODE, 0) CLB_ROW_LOAD(P, CODE, 1) CLB_ROW_LOAD(P, CODE, 2) CLB_ROW_LOAD(P, CODE, 3)        \
     CLB_ROW_LOAD(P, CODE, 4) CLB_ROW_LOAD(P, CODE, 5) CLB_ROW_LOAD(P, CODE, 6) CLB_ROW_LOAD(P, CODE, 7)
 #define CLB_ROW_STORE(P, m)                                                                                    \
-    *reinterpret_cast<float4*>(ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4) = row##P##m;
+    {   /* two 8-byte stores: {x, y} and {z, w} swap places in the slots >= 8 (see decompress_lane_dims_fast) */   \
+        float* sl_ = ctile + (c4 * 16 + ((2 * m + rhalf) ^ (c4 & 15))) * 4;                                    \
+        const int ro_ = 2 * ((((2 * m + rhalf) >> 3) ^ (c4 >> 3)) & 1);                                        \
+        *reinterpret_cast<float2*>(sl_ + ro_) = make_float2(row##P##m.x, row##P##m.y);                         \
+        *reinterpret_cast<float2*>(sl_ + (ro_ ^ 2)) = make_float2(row##P##m.z, row##P##m.w);                   \
+    }
 #define CLB_ROW_STORE8(P)                                                                                      \
     CLB_ROW_STORE(P, 0) CLB_ROW_STORE(P, 1) CLB_ROW_STORE(P, 2) CLB_ROW_STORE(P, 3)                            \
     CLB_ROW_STORE(P, 4) CLB_ROW_STORE(P, 5) CLB_ROW_STORE(P, 6) CLB_ROW_STORE(P, 7)
