@@ -700,6 +700,11 @@ __device__ __forceinline__ float max_lane_halves(float m) { return fmaxf(m, __sh
 #ifndef CLB_APPROX_WAVES
 #define CLB_APPROX_WAVES 12
 #endif
+#ifdef CLB_APPROX_SPLIT_LUT
+constexpr bool kSplitLut = true;    // experiment: the 16 table reads of a step in two halves (16 VGPRs less)
+#else
+constexpr bool kSplitLut = false;
+#endif
 constexpr int kApproxThreads = 64 * CLB_APPROX_WAVES;   // 12 waves per work-group = 3 per SIMD, one work-group per CU
 constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slots x 8 B
 
@@ -742,7 +747,7 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // registers) and the pass got SLOWER on every workload (0.662 -> 0.672 ms, uniform codes 1.46 -> 1.56, built index
 // 0.653 -> 0.699; the row sweep 0.069 -> 0.107): the pass is not short of issue slots, it waits on memory.
 template <bool ROWS, int ABL = 0, int GL = 0, int PIPE = 0>
-static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kernel(
+static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
     int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
@@ -763,6 +768,7 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
     __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][2 * kStepRows];   // two patches (PIPE)
     static_assert(GL == 0 || ABL == 0, "the ablation variants exist for the VGPR gather only");
     constexpr int kRingBytes = 3 * 2048;                 // three steps in flight x 32 rows x 64 B, per wave
+    static_assert(GL == 0 || CLB_APPROX_WAVES <= 12, "the 3-slot ring of the LDS-DMA form fits 160 KB of LDS up to 12 waves");
     __shared__ __attribute__((aligned(16))) unsigned char ring_s[GL ? (kApproxThreads / 64) * kRingBytes : 16];
     for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
         const int v = i >> 5;
@@ -917,8 +923,10 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         if (ABL != 5) {                                                                                     \
             tl[0] = CLB_LUT(RB[0], 0); tl[1] = CLB_LUT(RB[0], 1); tl[2] = CLB_LUT(RB[0], 2); tl[3] = CLB_LUT(RB[0], 3);     \
             tl[4] = CLB_LUT(RB[1], 0); tl[5] = CLB_LUT(RB[1], 1); tl[6] = CLB_LUT(RB[1], 2); tl[7] = CLB_LUT(RB[1], 3);     \
+            if (!kSplitLut) {                                                                               \
             tl[8] = CLB_LUT(RB[2], 0); tl[9] = CLB_LUT(RB[2], 1); tl[10] = CLB_LUT(RB[2], 2); tl[11] = CLB_LUT(RB[2], 3);   \
             tl[12] = CLB_LUT(RB[3], 0); tl[13] = CLB_LUT(RB[3], 1); tl[14] = CLB_LUT(RB[3], 2); tl[15] = CLB_LUT(RB[3], 3); \
+            }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
@@ -926,10 +934,18 @@ static __global__ __launch_bounds__(kApproxThreads, 3) void score_approx32_kerne
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, ACC, 0, 0, 0);    \
         if (ABL == 5) { ACC[0] += __uint_as_float(RB[0] ^ RB[1]); ACC[1] += __uint_as_float(RB[2] ^ RB[3]); } \
         else {                                                                                              \
-            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                              \
+                if (kSplitLut && s_ == 4) {      /* second half of the table reads, into the registers of the first */ \
+                    __builtin_amdgcn_sched_barrier(0);                                                      \
+                    tl[0] = CLB_LUT(RB[2], 0); tl[1] = CLB_LUT(RB[2], 1); tl[2] = CLB_LUT(RB[2], 2); tl[3] = CLB_LUT(RB[2], 3);   \
+                    tl[4] = CLB_LUT(RB[3], 0); tl[5] = CLB_LUT(RB[3], 1); tl[6] = CLB_LUT(RB[3], 2); tl[7] = CLB_LUT(RB[3], 3);   \
+                    __builtin_amdgcn_sched_barrier(0);                                                      \
+                }                                                                                           \
+                const int ti_ = kSplitLut ? 2 * (s_ & 3) : 2 * s_;                                          \
                 ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                               \
-                    __builtin_bit_cast(f16x8, u32x4{tl[2 * s_].x, tl[2 * s_].y, tl[2 * s_ + 1].x, tl[2 * s_ + 1].y}), \
+                    __builtin_bit_cast(f16x8, u32x4{tl[ti_].x, tl[ti_].y, tl[ti_ + 1].x, tl[ti_ + 1].y}),   \
                     __builtin_bit_cast(f16x8, qb[s_]), ACC, 0, 0, 0);                                       \
+            }                                                                                               \
         }                                                                                                   \
     }
 #define CLB_STAGE_E(ACC, INVB, PM, TAG)                                                                     \

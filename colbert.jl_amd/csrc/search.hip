@@ -564,7 +564,11 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr)
 #ifdef CLB_ABLATIONS
             if (CLB_KNOB("CLB_DEBUG_APPROX_PIPE", 0)) {     // round-3 experiment: epilogue of step i-1 under step i's MFMAs (slower: profiles/r03_experiments.md)
+#if CLB_APPROX_WAVES <= 12
                 auto kern = s->gather_lds ? score_approx32_kernel<false, 0, 1, 1> : score_approx32_kernel<false, 0, 0, 1>;
+#else
+                auto kern = score_approx32_kernel<false, 0, 0, 1>;
+#endif
                 hipLaunchKernelGGL(kern, approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                                    s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                                    w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
@@ -583,7 +587,11 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
             }
 #else
             {
+#if CLB_APPROX_WAVES <= 12
                 auto kern = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
+#else
+                auto kern = score_approx32_kernel<false, 0, 0, 0>;
+#endif
                 hipLaunchKernelGGL(kern, approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                                    s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                                    w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
@@ -1103,7 +1111,11 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
     CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
+#if CLB_APPROX_WAVES <= 12
     auto dbg_kernel = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
+#else
+    auto dbg_kernel = score_approx32_kernel<false, 0, 0, 0>;
+#endif
     hipLaunchKernelGGL(dbg_kernel, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                        w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
