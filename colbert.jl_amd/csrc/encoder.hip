@@ -415,6 +415,17 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
     return CLB_OK;
 }
 
+int clb_encoder_check_last_ids(clb_encoder* e) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (!e->err.p) return CLB_OK;                     // nothing has been encoded yet
+    CLB_TRY(use_device(e->device));
+    int herr = 0;
+    CLB_HIP(hipDeviceSynchronize());                  // the asynchronous encode may run on any of the caller's streams
+    CLB_HIP(hipMemcpy(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    return CLB_OK;
+}
+
 int clb_encoder_profile_enable(clb_encoder* e, int on) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     e->prof_on = on != 0;

@@ -153,6 +153,11 @@ class BertEncoder:
                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
         return d_out
 
+    def check_last_ids(self):
+        """Raise BoundsError if the last (asynchronous, device-resident) encode saw a token id outside the vocabulary --
+        query_embeddings_device clamps such ids because it cannot report them when it is enqueued."""
+        check(lib().clb_encoder_check_last_ids(self._h))
+
     # -- profiling (bench.py) -----------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         """HIP events around every stage of the forward, on the launching stream (not for timed regions)."""

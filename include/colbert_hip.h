@@ -301,6 +301,10 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
  * cannot be reported from an asynchronous call: it is clamped (use clb_encode_queries to validate inputs). */
 int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
                               const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream);
+/* The asynchronous device path cannot report an id outside the vocabulary when it is enqueued (it clamps): this call
+ * waits for the device and returns the BoundsError of the last encode, if it had one (the host-buffer entry points
+ * report it themselves). */
+int clb_encoder_check_last_ids(clb_encoder* e);
 /* Per-stage HIP-event timing of the encoder forward (bench.py's encoder roofline; the stages are the Linear layers of
  * `doc`, src/modelling/checkpoint.jl:21-25, by role).  enable, run encodes, then read: names[i] (static strings), total
  * milliseconds and stage executions since the last read.  Returns the number of entries written (<= cap), -1 on error. */

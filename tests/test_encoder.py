@@ -157,6 +157,16 @@ def test_bert_forward_matches_fp32_reference(gemm):
     assert np.array_equal(Q.view(np.uint32), orc.query_epilogue(got, (ids0.T + 1).astype(np.int32), skip).view(np.uint32))
     with pytest.raises(clb.BoundsError):
         enc.doc(np.full((4, 1), cfg.vocab_size + 1, np.int32), np.ones((4, 1), bool))
+    # the asynchronous device path clamps such an id when it is enqueued and reports it on request
+    d_ids = torch.full((1, 4), cfg.vocab_size + 1, dtype=torch.int32, device="cuda")
+    d_mask = torch.ones((1, 4), dtype=torch.uint8, device="cuda")
+    d_skip = torch.tensor([1], dtype=torch.int64, device="cuda")
+    d_out = torch.empty((1, 4, 32), dtype=torch.float32, device="cuda")
+    enc.query_embeddings_device(d_ids, d_mask, d_skip, d_out)
+    with pytest.raises(clb.BoundsError):
+        enc.check_last_ids()
+    enc.query_embeddings_device(torch.ones_like(d_ids), d_mask, d_skip, d_out)
+    enc.check_last_ids()
     enc.close()
 
 
