@@ -410,6 +410,43 @@ static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, in
     }
 }
 
+// _query_embeddings' epilogue (checkpoint.jl:61-69) for the device-resident query path, mask and normalisation in ONE
+// kernel with four lanes per token: lane g owns the dims = g mod 4, i.e. exactly one of the four interleaved partial sums
+// of the canonical sum of squares (each still summed in ascending order), combined as (p0 + p1) + (p2 + p3) by two
+// shuffles -- bit-identical to epilogue_mask_kernel + epilogue_normalize_kernel (one thread per token: 32 us per 32
+// queries for 1 024 rows of 128 floats), which the host-buffer entry points keep.  dim % 4 == 0.
+static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const float* __restrict__ D, int dim, int64_t n_tok,
+                                                                         const int32_t* __restrict__ ids,
+                                                                         const int64_t* __restrict__ skip, int nskip,
+                                                                         float* __restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = gid >> 2;
+    const int g = (int)(gid & 3);
+    const bool live = j < n_tok;
+    const int64_t jj = live ? j : n_tok - 1;
+    const int32_t id = ids[jj];
+    bool keep = true;
+    for (int s = 0; s < nskip; ++s) keep = keep && ((int64_t)id != skip[s]);
+    const float* x = D + jj * dim + g;
+    float p = 0.f;
+    for (int d = 0; d < dim; d += 4) {
+        const float a = x[d];
+        const float sq = a * a;
+        p = p + sq;
+    }
+    const float q = p + __shfl_xor(p, 1, 64);          // lanes 0,1: p0 + p1; lanes 2,3: p2 + p3 (commutative: same bits)
+    const float n2 = __shfl(q, (threadIdx.x & 60), 64) + __shfl(q, (threadIdx.x & 60) + 2, 64);   // (p0 + p1) + (p2 + p3)
+    if (!live) return;
+    float* o = out + jj * dim + g;
+    if (!keep) {
+        // D .* mask zeroes the column (-0.0 for negative entries); 0/(0+eps) keeps it
+        for (int d = 0; d < dim; d += 4) o[d] = (x[d] * 0.0f) / FLT_EPSILON;
+        return;
+    }
+    const float den = sqrtf(n2) + FLT_EPSILON;
+    for (int d = 0; d < dim; d += 4) o[d] = x[d] / den;
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // Index build: exact nearest centroid of every point from the group lists centroid_top_bf16x3_mq_kernel<false, BIAS>
 // wrote with gx = 1 (partial: [ceil(n/32)][32 points][2 halves][kTopPartial]).  MODE 0: argmax of the canonical dot

@@ -406,10 +406,15 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
     CLB_TRY(forward(e, L, N, st, d_integer_ids, d_bitmask, /*sync=*/false));
     {
         EncTimed tm(e, ES_EPILOGUE, st);
-        hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
-                           d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
-        hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
-                           (int)L, (int)N, e->qmask.as<uint8_t>(), (const int64_t*)nullptr, d_out);
+        if (e->dim % 4 == 0)
+            hipLaunchKernelGGL(epilogue_query_fused_kernel, dim3(blocks_for(L * N * 4, 256)), dim3(256), 0, st, e->out.as<float>(),
+                               (int)e->dim, (int64_t)(L * N), d_integer_ids, d_skiplist, (int)n_skip, d_out);
+        else {
+            hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
+                               d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
+            hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                               (int)L, (int)N, e->qmask.as<uint8_t>(), (const int64_t*)nullptr, d_out);
+        }
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;

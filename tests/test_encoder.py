@@ -157,6 +157,14 @@ def test_bert_forward_matches_fp32_reference(gemm):
     assert np.array_equal(Q.view(np.uint32), orc.query_epilogue(got, (ids0.T + 1).astype(np.int32), skip).view(np.uint32))
     with pytest.raises(clb.BoundsError):
         enc.doc(np.full((4, 1), cfg.vocab_size + 1, np.int32), np.ones((4, 1), bool))
+    # the device-resident query path (fused epilogue kernel, four lanes per token) == the host-buffer path, bit for bit
+    d_ids0 = torch.from_numpy((ids0 + 1).astype(np.int32)).cuda()                # (N, L) row-major = Julia (L, N)
+    d_mask0 = torch.from_numpy(mask.astype(np.uint8)).cuda()
+    d_skip0 = torch.tensor(skip, dtype=torch.int64, device="cuda")
+    d_q = torch.empty((N, L, 32), dtype=torch.float32, device="cuda")
+    enc.query_embeddings_device(d_ids0, d_mask0, d_skip0, d_q)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.ascontiguousarray(Q.transpose(2, 1, 0)).view(np.uint32), d_q.cpu().numpy().view(np.uint32))
     # the asynchronous device path clamps such an id when it is enqueued and reports it on request
     d_ids = torch.full((1, 4), cfg.vocab_size + 1, dtype=torch.int32, device="cuda")
     d_mask = torch.ones((1, 4), dtype=torch.uint8, device="cuda")
