@@ -3,6 +3,7 @@
 // (`_doc_embeddings_and_doclens` :27-52, `_query_embeddings` :54-71).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -112,6 +113,9 @@ void gemm(hipStream_t st, const float* A, const float* B, float* C, const float*
 // activations (T x K, fp32) x Linear weight (N x K, fp32) on the split-bf16 kernels (both operands are split into
 // bf16 planes while they are staged).  Falls back to the fp32 MFMA GEMM for shapes the kernel does not take.
 struct LnArgs { const float* gamma; const float* beta; float eps; };
+// small tiles (query batches): two LDS tile buffers, one barrier per step (COLBERT_ENCODER_DOUBLE_BUFFER=0: the
+// single-buffer loop, for comparison)
+static const bool g_double_buffer = [] { const char* v = getenv("COLBERT_ENCODER_DOUBLE_BUFFER"); return !v || atoi(v) != 0; }();
 
 // ln != null: the caller applies a LayerNorm to the output next; returns true when it was applied here (split-K path:
 // fused into the reduction pass)
@@ -125,7 +129,19 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
     if (wgs(128, 128) >= 384) {
         hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 2, 2, NS>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), lds(128, 128), st, g);
     } else if (wgs(64, 128) >= 384 && N >= 128) {
-        hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 2, NS>), dim3((N + 127) / 128, (M + 63) / 64, 1), dim3(256), lds(64, 128), st, g);
+        if (g_double_buffer) {
+            // 72 KB of dynamic LDS: above the 64-KB default limit of a launch
+            static const bool raised = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16split_kernel<2, 2, 1, 2, NS, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NS * (64 + 128) * 64);
+                (void)hipGetLastError();
+                return true;
+            }();
+            (void)raised;
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 2, NS, true>), dim3((N + 127) / 128, (M + 63) / 64, 1), dim3(256), 2 * lds(64, 128), st, g);
+        }
+        else
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 2, NS>), dim3((N + 127) / 128, (M + 63) / 64, 1), dim3(256), lds(64, 128), st, g);
     } else {
         int ks = 1;
         if (part) {
@@ -135,7 +151,10 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
         }
         float* C = g.C;
         if (ks > 1) { g.ksplit = ks; g.C = part; }
-        hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), lds(64, 64), st, g);
+        if (g_double_buffer)
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS, true>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 2 * lds(64, 64), st, g);
+        else
+            hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 1, NS>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), lds(64, 64), st, g);
         if (ks > 1) {
             if (ln && N <= 1024) {
                 if (N <= 768)

@@ -257,7 +257,13 @@ __device__ __forceinline__ void split_store4(const f32x4 v, unsigned char* d, in
     }
 }
 
-template <int WGM, int WGN, int WM, int WN, int NS>
+// DB = true (round 3, the small tiles of query batches): TWO LDS tile buffers.  A query batch gives these GEMMs 1-2
+// work-groups per CU (384 x 4 waves on 1 024 SIMDs), so nothing covered the two barriers per step of the single-buffer
+// loop: a wave spent 39 % of its cycles waiting and its 224 VALU instructions of operand splitting and its 24 MFMAs
+// took turns (PMC: MFMA busy 20 % of the wave cycles).  Here the split of tile k+1 (registers -> the other buffer) and
+// the MFMAs of tile k (this buffer) sit in one basic block with one barrier per step, so the vector work issues in the
+// shadow of the matrix pipe, and tile k+2 is requested as soon as the registers are free.
+template <int WGM, int WGN, int WM, int WN, int NS, bool DB = false>
 static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(Gemm3Args g) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
@@ -280,8 +286,10 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
     // loader: thread t moves float4 (t & 7) of rows (t >> 3) + RPP p of A and of B
     const int lrow = tid >> 3, lq = tid & 7;
     f32x4 pa[BM / RPP], pb[BN / RPP];
+    constexpr int BUFB = NS * (PA + PB);                                   // bytes of one tile buffer
 #define CLB_G3_LOAD(K0) CLB_G3_LOAD_(K0, pa, pb)
-#define CLB_G3_STORE() CLB_G3_STORE_(pa, pb)
+#define CLB_G3_STORE() CLB_G3_STORE_(pa, pb, 0)
+#define CLB_G3_STORE_AT(OFF) CLB_G3_STORE_(pa, pb, OFF)
 #define CLB_G3_LOAD_(K0, pa, pb)                                                                                      \
     {                                                                                                        \
         _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
@@ -295,15 +303,15 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
             pb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldb_ + (K0) + 4 * lq);                 \
         }                                                                                                    \
     }
-#define CLB_G3_STORE_(pa, pb)                                                                                \
+#define CLB_G3_STORE_(pa, pb, OFF)                                                                           \
     {                                                                                                        \
         _Pragma("unroll") for (int p = 0; p < BM / RPP; ++p) {                                               \
             const int row_ = lrow + RPP * p;                                                                 \
-            split_store4<NS>(pa[p], g3lds + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PA); \
+            split_store4<NS>(pa[p], g3lds + (OFF) + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PA); \
         }                                                                                                    \
         _Pragma("unroll") for (int p = 0; p < BN / RPP; ++p) {                                               \
             const int row_ = lrow + RPP * p;                                                                 \
-            split_store4<NS>(pb[p], g3lds + NS * PA + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PB); \
+            split_store4<NS>(pb[p], g3lds + (OFF) + NS * PA + row_ * 64 + (((lq >> 1) ^ ((row_ >> 2) & 3)) << 4) + ((lq & 1) << 3), PB); \
         }                                                                                                    \
     }
     f32x16 acc[WM][WN];
@@ -319,10 +327,10 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
     const int sw = (i >> 2) & 3;                  // the swizzle of this lane's rows (tile bases are multiples of 32)
     const unsigned char* As = g3lds + (wr * 32 * WM + i) * 64;
     const unsigned char* Bs = g3lds + NS * PA + (wc * 32 * WN + i) * 64;
-    auto compute_step = [&]() {
+    auto compute_step = [&](int boff = 0) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int off = ((2 * s + h) ^ sw) << 4;
+            const int off = (((2 * s + h) ^ sw) << 4) + boff;
             bf16x8 av[NS][WM], bv[NS][WN];
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -348,16 +356,64 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
                 }
         }
     };
-    for (int k0 = 0; k0 < K_; k0 += 32) {
-        const bool more = k0 + 32 < K_;
-        if (more) CLB_G3_LOAD(k0 + 32)
-        compute_step();
-        __syncthreads();              // every wave has read the tile
-        if (more) CLB_G3_STORE()
-        __syncthreads();
+    if (!DB) {
+        for (int k0 = 0; k0 < K_; k0 += 32) {
+            const bool more = k0 + 32 < K_;
+            if (more) CLB_G3_LOAD(k0 + 32)
+            compute_step();
+            __syncthreads();              // every wave has read the tile
+            if (more) CLB_G3_STORE()
+            __syncthreads();
+        }
+    } else {
+        if (K_ > 32) CLB_G3_LOAD(32)                  // tile 1 waits in registers
+        int cur = 0;
+        // One step: all fragments of tile k leave this buffer FIRST (the compiler will not move an LDS read above an LDS
+        // write it cannot tell apart), then tile k+1 goes registers -> the other buffer (every wave left it at the barrier
+        // below) and tile k+2 is requested as soon as the registers are free; the MFMAs depend on registers only and
+        // interleave with that vector work.  STORE / LOAD are compile-time flags: a branch inside the step would split
+        // the basic block and the MFMAs would queue up behind the split again (the last two steps are peeled instead).
+#define CLB_G3_DB_STEP(K0, DO_STORE, DO_LOAD)                                                                \
+        {                                                                                                    \
+            bf16x8 av[2][NS][WM], bv[2][NS][WN];                                                             \
+            const int boff = cur * BUFB;                                                                     \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                  \
+                const int off = (((2 * s + h) ^ sw) << 4) + boff;                                            \
+                _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                             \
+                    _Pragma("unroll") for (int a = 0; a < WM; ++a)                                           \
+                        av[s][q][a] = *reinterpret_cast<const bf16x8*>(As + q * PA + a * 32 * 64 + off);     \
+                    _Pragma("unroll") for (int b = 0; b < WN; ++b)                                           \
+                        bv[s][q][b] = *reinterpret_cast<const bf16x8*>(Bs + q * PB + b * 32 * 64 + off);     \
+                }                                                                                            \
+            }                                                                                                \
+            if (DO_STORE) CLB_G3_STORE_AT((cur ^ 1) * BUFB)                                                  \
+            if (DO_LOAD) CLB_G3_LOAD((K0) + 64)                                                              \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
+                _Pragma("unroll") for (int a = 0; a < WM; ++a)                                               \
+                    _Pragma("unroll") for (int b = 0; b < WN; ++b) {                                         \
+                        f32x16 c = acc[a][b];                                                                \
+                        if (NS == 3) {                                                                       \
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][2][a], bv[s][0][b], c, 0, 0, 0); \
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][a], bv[s][2][b], c, 0, 0, 0); \
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][1][a], bv[s][1][b], c, 0, 0, 0); \
+                        }                                                                                    \
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][1][a], bv[s][0][b], c, 0, 0, 0);   \
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][a], bv[s][1][b], c, 0, 0, 0);   \
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][a], bv[s][0][b], c, 0, 0, 0);   \
+                        acc[a][b] = c;                                                                       \
+                    }                                                                                        \
+            __syncthreads();                                                                                 \
+            cur ^= 1;                                                                                        \
+        }
+        int k0 = 0;
+        for (; k0 + 64 < K_; k0 += 32) CLB_G3_DB_STEP(k0, true, true)
+        if (k0 + 32 < K_) { CLB_G3_DB_STEP(k0, true, false) k0 += 32; }
+        CLB_G3_DB_STEP(k0, false, false)
+#undef CLB_G3_DB_STEP
     }
 #undef CLB_G3_LOAD
 #undef CLB_G3_STORE
+#undef CLB_G3_STORE_AT
 #undef CLB_G3_LOAD_
 #undef CLB_G3_STORE_
     // C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
