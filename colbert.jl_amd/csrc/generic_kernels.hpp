@@ -96,21 +96,110 @@ static __global__ __launch_bounds__(256) void generic_score_kernel(
     }
 }
 
+// The same on the fp32 MFMA (round 3), for every shape with T <= 16 * kGenericMaxTokenGroups: one WAVE per passage,
+// 16 embeddings x 16 tokens per v_mfma_f32_16x16x4_f32 with k walked in ascending order -- exactly the canonical fmaf
+// chain of dot_canonical -- in the lane layout of score_exact_kernel: lane (r = lane & 15, g = lane >> 4) owns the dims
+// = g mod 4 of embedding r, i.e. one of the four interleaved partial sums of the canonical sum of squares.  Any
+// dim % 4 == 0 (the reference requires dim % 8 == 0) and nbits in {1, 2, 4, 8}: the decompressed value of a dim is
+// recomputed from the packed residual and the centroid row for every token group instead of being kept (no register
+// array sized by dim).  Rows past the end of a passage duplicate its last row (a duplicate cannot change a maximum).
+// grid = any, block = 256 (4 waves); dynamic LDS = (1 << nbits) floats (the bucket weights).
+constexpr int kGenericMaxTokenGroups = 32;
+static __global__ __launch_bounds__(256) void generic_score_mfma_kernel(
+    const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
+    const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand,
+    const float* __restrict__ Q, int dim, int nbits, int T, float* __restrict__ scores) {
+    extern __shared__ float gw[];
+    for (int i = threadIdx.x; i < (1 << nbits); i += blockDim.x) gw[i] = weights[i];
+    __syncthreads();
+    const int n = *ncand;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int rows = dim / 8 * nbits;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const int ks = dim >> 2;                             // MFMA k-steps: dims 4s .. 4s+3
+    const int ngroups = (T + 15) >> 4;
+    for (int j = (int)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (int)gridDim.x * 4) {
+        const uint2 hd = cand_hdr[j];
+        const uint32_t off = hd.x, len = hd.y;
+        float mt[kGenericMaxTokenGroups];                // running maximum of token 16 tg + (lane & 15), per token group
+#pragma unroll
+        for (int tg = 0; tg < kGenericMaxTokenGroups; ++tg) mt[tg] = kNegInf;
+        for (uint32_t e0 = 0; e0 < len; e0 += 16) {
+            const uint32_t e = off + (e0 + r < len ? e0 + r : len - 1);
+            const uint8_t* rp = residuals + (size_t)e * rows;
+            const float* cent = C + (size_t)codes0[e] * dim;
+            // canonical sum of squares: lane (r, g) sums dims = g mod 4 in ascending order, then (p0 + p1) + (p2 + p3)
+            float p = 0.f;
+            for (int s = 0; s < ks; ++s) {
+                const int d = 4 * s + g, bit = d * nbits;
+                const uint32_t idx = ((uint32_t)rp[bit >> 3] >> (bit & 7)) & mask;
+                const float v = cent[d] + gw[idx];
+                const float sq = v * v;
+                p = p + sq;
+            }
+            const float a2 = p + __shfl_xor(p, 16, 64);
+            const float n2 = a2 + __shfl_xor(a2, 32, 64);
+            const float den = sqrtf(n2) + FLT_EPSILON;
+#pragma unroll
+            for (int tg = 0; tg < kGenericMaxTokenGroups; ++tg) {
+                if (tg >= ngroups) break;
+                const int t = 16 * tg + r;               // B operand: lane (col = r, k = g) supplies Q[t][4s + g]
+                const float* qrow = Q + (size_t)(t < T ? t : T - 1) * dim + g;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < ks; ++s) {
+                    const int d = 4 * s + g, bit = d * nbits;
+                    const uint32_t idx = ((uint32_t)rp[bit >> 3] >> (bit & 7)) & mask;
+                    const float x = (cent[d] + gw[idx]) / den;
+                    const float q = t < T ? qrow[4 * s] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, q, acc, 0, 0, 0);
+                }
+                // accumulator: lane (col = token r, g) holds embeddings 4 g + i, i = 0..3
+                float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                mt[tg] = fmaxf(mt[tg], m);
+            }
+        }
+        float total = 0.f;                               // sequential sum over the tokens (ranking.jl:83)
+#pragma unroll
+        for (int tg = 0; tg < kGenericMaxTokenGroups; ++tg) {
+            if (tg >= ngroups) break;
+            for (int c = 0; c < 16; ++c) {
+                const float v = __shfl(mt[tg], c, 64);
+                if (16 * tg + c < T) total = total + v;
+            }
+        }
+        if (lane == 0) scores[j] = total;
+    }
+}
+
 // Top-k by a full sort (searching.jl:125-127: sortperm(scores, rev = true), stable): key = ~order(score) << 32 | position
 // ascending == score descending, lower candidate position (= lower pid) first.  `list` (two-pass mode) maps positions
 // to candidate slots.
-static __global__ void generic_topk_keys_kernel(const float* __restrict__ scores, const int* __restrict__ list, int n,
+// `n_ptr` (device) = the number of valid entries: positions past it get the largest key and sort to the end, so the host
+// launches the sort over the slot's capacity without reading the count back (no synchronisation per query).
+static __global__ void generic_topk_keys_kernel(const float* __restrict__ scores, const int* __restrict__ list,
+                                                const int* __restrict__ n_ptr, int cap,
                                                 unsigned long long* __restrict__ keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= cap) return;
+    const int n = *n_ptr;
+    if (i >= n) { keys[i] = ~0ull; return; }
     const int slot = list ? list[i] : i;
     keys[i] = ((unsigned long long)(~f32_order_key(scores[slot])) << 32) | (unsigned long long)(uint32_t)i;
 }
 static __global__ void generic_topk_emit_kernel(const unsigned long long* __restrict__ keys_sorted,
                                                 const float* __restrict__ scores, const uint32_t* __restrict__ cand,
-                                                const int* __restrict__ list, int n, int k, int64_t pid_offset,
-                                                int64_t* __restrict__ out_pids, float* __restrict__ out_scores) {
+                                                const int* __restrict__ list, const int* __restrict__ n_ptr,
+                                                const int* __restrict__ ncand_ptr, int k, int64_t pid_offset,
+                                                int64_t* __restrict__ out_pids, float* __restrict__ out_scores,
+                                                int* __restrict__ short_flag, int64_t* __restrict__ n_cand_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_ptr;
+    if (i == 0) {
+        *short_flag = n < k ? 1 : 0;
+        if (n_cand_out) *n_cand_out = *ncand_ptr;
+    }
     if (i >= k) return;
     if (i < n) {
         const int pos = (int)(uint32_t)keys_sorted[i];

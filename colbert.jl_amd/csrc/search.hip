@@ -397,33 +397,24 @@ int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* c
     return CLB_OK;
 }
 
-// top-k of ONE query by a full stable sort (k above the single-work-group sort of topk_kernel); synchronises
+// top-k of ONE query by a full stable sort (k above the single-work-group sort of topk_kernel).  The count stays on the
+// device: the sort runs over the slot's candidate capacity with the positions past the count keyed to the end, the
+// emit kernel writes the short-result flag and the candidate count -- no host synchronisation per query.
 int topk_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, int b, const int* list, const int* nlist, int k,
                  int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand) {
-    int n = 0, nc = 0;
-    CLB_HIP(hipMemcpyAsync(&nc, w.ncand.as<int>() + b, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (list) CLB_HIP(hipMemcpyAsync(&n, nlist + b, sizeof(int), hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipStreamSynchronize(st));
-    if (!list) n = nc;
+    const int cap = (int)w.cand_cap;
     const float* sc = w.scores.as<float>() + (size_t)b * w.cand_cap;
     const int* lst = list ? list + (size_t)b * w.cand_cap : nullptr;
-    CLB_TRY(w.g_keys.ensure(sizeof(uint64_t) * std::max(n, 1)));
-    CLB_TRY(w.g_keys2.ensure(sizeof(uint64_t) * std::max(n, 1)));
-    if (n > 0) {
-        hipLaunchKernelGGL(generic_topk_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sc, lst, n,
-                           w.g_keys.as<unsigned long long>());
-        CLB_TRY(sort_keys_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), (size_t)n, st));
-    }
-    hipLaunchKernelGGL(generic_topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, st,
-                       w.g_keys2.as<unsigned long long>(), sc, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, lst, n, k,
-                       s->pid_offset, d_out_pids + (size_t)b * k, d_out_scores + (size_t)b * k);
-    const int flag = n < k ? 1 : 0;
-    CLB_HIP(hipMemcpyAsync(w.flags.as<int>() + b, &flag, sizeof(int), hipMemcpyHostToDevice, st));
-    if (d_n_cand) {
-        const int64_t nc64 = nc;
-        CLB_HIP(hipMemcpyAsync(d_n_cand + b, &nc64, sizeof(int64_t), hipMemcpyHostToDevice, st));
-    }
-    CLB_HIP(hipStreamSynchronize(st));        // the two host words above must stay alive until copied
+    const int* n_ptr = list ? nlist + b : w.ncand.as<int>() + b;
+    CLB_TRY(w.g_keys.ensure(sizeof(uint64_t) * std::max(cap, 1)));
+    CLB_TRY(w.g_keys2.ensure(sizeof(uint64_t) * std::max(cap, 1)));
+    hipLaunchKernelGGL(generic_topk_keys_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, sc, lst, n_ptr, cap,
+                       w.g_keys.as<unsigned long long>());
+    CLB_TRY(sort_keys_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), (size_t)cap, st));
+    hipLaunchKernelGGL(generic_topk_emit_kernel, dim3((std::max(k, 1) + 255) / 256), dim3(256), 0, st,
+                       w.g_keys2.as<unsigned long long>(), sc, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, lst, n_ptr,
+                       w.ncand.as<int>() + b, k, s->pid_offset, d_out_pids + (size_t)b * k, d_out_scores + (size_t)b * k,
+                       w.flags.as<int>() + b, d_n_cand ? d_n_cand + b : nullptr);
     CLB_HIP(hipGetLastError());
     return CLB_OK;
 }
@@ -457,6 +448,14 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
     CLB_TRY(w.g_scratch.ensure(sizeof(float) * grid * max_len * s->dim));
     for (int b = 0; b < B; ++b) {
         CLB_TRY(run_retrieve_general(s, w, st, dQ, b, T, nprobe));
+        if (T <= 16 * kGenericMaxTokenGroups && s->dim % 4 == 0 && !CLB_KNOB("CLB_DEBUG_GENERIC_SCALAR", 0))
+            // fp32 MFMA, one wave per passage (the canonical arithmetic of the scalar kernel, bit for bit)
+            hipLaunchKernelGGL(generic_score_mfma_kernel, dim3(grid), dim3(256), sizeof(float) * ((size_t)1 << s->nbits), st,
+                               s->centroids.as<float>(), s->weights.as<float>(), s->codes0.as<uint32_t>(),
+                               s->residuals.as<uint8_t>(), w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap,
+                               w.ncand.as<int>() + b, dQ + (size_t)b * T * s->dim, (int)s->dim, s->nbits, T,
+                               w.scores.as<float>() + (size_t)b * w.cand_cap);
+        else
         hipLaunchKernelGGL(generic_score_kernel, dim3(grid), dim3(256), sizeof(float) * T, st, s->centroids.as<float>(),
                            s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(),
                            w.cand_hdr.as<uint2>() + (size_t)b * w.cand_cap, w.ncand.as<int>() + b,
