@@ -71,6 +71,26 @@ def test_argument_contracts_without_gpu():
         clb.codec.compress(np.zeros((7, 2), np.float32), np.zeros(1, np.float32), 7, 1, np.zeros((7, 3), np.float32))
 
 
+def test_round3_entry_points_check_their_arguments_first():
+    """The entry points added in round 3 refuse null handles / bad values before touching a device (error 4 =
+    ArgumentError), like every other export."""
+    import ctypes as C
+    l = clb.lib()
+    null = C.c_void_p()
+    assert l.clb_searcher_set_pass1_gather(null, 0) == 4
+    assert l.clb_searcher_get_pass1_gather(null, None) == -1
+    assert l.clb_searcher_sync_bound_consts(null, null) == 4
+    assert l.clb_kmeans_shard_block_bytes(null) == 0
+    assert l.clb_kmeans_shard_set_centroids(null, None) == 4
+    assert l.clb_kmeans_shard_get_centroids(null, None) == 4
+    assert l.clb_kmeans_shard_pass_device(null, None, None) == 4
+    assert l.clb_kmeans_shard_update_device(null, None, C.c_int64(1), C.c_float(1e-4), None, None, None) == 4
+    assert l.clb_encoder_check_last_ids(null) == 4
+    assert l.clb_encoder_profile_enable(null, 1) == 4
+    assert l.clb_encoder_profile_read(null, None, None, None, 0) == -1
+    assert b"null" in l.clb_last_error()
+
+
 def test_host_planning_helpers_match_oracle(oracle):
     for n in (1, 10, 1000, 141431, 10 ** 6):
         assert clb.codec.num_sampled_pids(n) == oracle.num_sampled_pids(n)
