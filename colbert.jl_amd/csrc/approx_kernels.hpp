@@ -53,7 +53,8 @@ typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr float kEpsSafety = 1.25f;
 
 inline bool approx_supported(int dim, int nbits) { return dim == kDim && nbits == 2; }
-inline size_t approx_cells_bytes(int64_t B, int64_t K, int64_t /*Tpad*/) { return (size_t)B * K * 16 * 4; }
+// (+ 2 KB: the spill block the batched centroid kernel sends its out-of-range stores to)
+inline size_t approx_cells_bytes(int64_t B, int64_t K, int64_t /*Tpad*/) { return (size_t)B * K * 16 * 4 + 2048; }
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -61,6 +62,17 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
+}
+// Two fp32 values -> the two operand words of the split-bf16 products: hi = RNE(x), lo = RNE(x - hi), value 0 in the low
+// half of each word.  gfx950 converts a pair in one instruction (v_cvt_pk_bf16_f32, round to nearest even: the same
+// results as f32_to_bf16_rne for finite inputs); the integer form above costs ~12 VALU operations per value, and every
+// wave of the centroid kernels splits 256 query values before its first tile -- ~7 us of a 0.11-ms launch
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32pair{x0, x1}, bf16x2));
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32pair{r0, r1}, bf16x2));
 }
 // fp16 (round to nearest even, subnormals kept: v_cvt_f16_f32) -- the operand format of pass 1's Q.r MFMAs since round 3:
 // 11 significant bits where bf16 has 8, so the measured rounding terms of the error bound (dq, dw_rn) are 8x smaller;
@@ -244,15 +256,14 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
             const float4 a = *reinterpret_cast<const float4*>(qrow + 8 * s);
             const float4 c = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-            uint32_t hh[8], ll[8];
+            uint32_t hh[4], ll[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = i < T ? v[j] : 0.f;
-                hh[j] = f32_to_bf16_rne(x);
-                ll[j] = f32_to_bf16_rne(x - __uint_as_float(hh[j] << 16));
+            for (int j = 0; j < 4; ++j) {
+                split_bf16_pair(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+                if (i >= T) { hh[j] = 0u; ll[j] = 0u; }      // tokens past T: zero operand rows
             }
-            qh[s] = u32x4{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-            ql[s] = u32x4{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+            qh[s] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            ql[s] = u32x4{ll[0], ll[1], ll[2], ll[3]};
         }
     }
     float bv[kTopPartial];
@@ -360,15 +371,14 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
             const float4 a = *reinterpret_cast<const float4*>(qrow + 8 * s);
             const float4 c = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-            uint32_t hh[8], ll[8];
+            uint32_t hh[4], ll[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = i < T ? v[j] : 0.f;
-                hh[j] = f32_to_bf16_rne(x);
-                ll[j] = f32_to_bf16_rne(x - __uint_as_float(hh[j] << 16));
+            for (int j = 0; j < 4; ++j) {
+                split_bf16_pair(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+                if (i >= T) { hh[j] = 0u; ll[j] = 0u; }      // tokens past T: zero operand rows
             }
-            qh[q][s] = u32x4{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-            ql[q][s] = u32x4{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+            qh[q][s] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            ql[q][s] = u32x4{ll[0], ll[1], ll[2], ll[3]};
         }
     }
     float bv0[kTopPartial], bv1[kTopPartial];
@@ -377,26 +387,41 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int p = 0; p < kTopPartial; ++p) { bv0[p] = bv1[p] = kNegInf; bi0[p] = bi1[p] = 0x7fffffff; }
     // loader: thread tid moves 16-B chunk (tid & 15) of rows (tid >> 4) and 16 + (tid >> 4), hi and lo
     const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
-    uint4 ph0, ph1, pl0, pl1;
+    u32x4 ph0, ph1, pl0, pl1;
 #define CLB_MQ_LOAD(TL)                                                                                   \
     {                                                                                                     \
         int c0_ = (TL) * 32 + prow, c1_ = c0_ + 16;                                                       \
         c0_ = c0_ < K ? c0_ : K - 1;                                                                      \
         c1_ = c1_ < K ? c1_ : K - 1;                                                                      \
-        ph0 = *reinterpret_cast<const uint4*>(Chi + (size_t)c0_ * kDim + 8 * pchunk);                      \
-        pl0 = *reinterpret_cast<const uint4*>(Clo + (size_t)c0_ * kDim + 8 * pchunk);                      \
-        ph1 = *reinterpret_cast<const uint4*>(Chi + (size_t)c1_ * kDim + 8 * pchunk);                      \
-        pl1 = *reinterpret_cast<const uint4*>(Clo + (size_t)c1_ * kDim + 8 * pchunk);                      \
+        const uint16_t* a0_ = Chi + (size_t)c0_ * kDim + 8 * pchunk;                                       \
+        const uint16_t* a1_ = Clo + (size_t)c0_ * kDim + 8 * pchunk;                                       \
+        const uint16_t* a2_ = Chi + (size_t)c1_ * kDim + 8 * pchunk;                                       \
+        const uint16_t* a3_ = Clo + (size_t)c1_ * kDim + 8 * pchunk;                                       \
+        if (WRITE_HALF) {   /* hand-issued and hand-waited (CLB_MQ_WAIT): see the stores at the end of the loop */ \
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"           \
+                         "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"                \
+                         : "=&v"(ph0), "=&v"(pl0), "=&v"(ph1), "=&v"(pl1)                                   \
+                         : "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_) : "memory");                             \
+        } else {                                                                                          \
+            ph0 = *reinterpret_cast<const u32x4*>(a0_);                                                   \
+            pl0 = *reinterpret_cast<const u32x4*>(a1_);                                                   \
+            ph1 = *reinterpret_cast<const u32x4*>(a2_);                                                   \
+            pl1 = *reinterpret_cast<const u32x4*>(a3_);                                                   \
+        }                                                                                                 \
     }
+    // the four tile loads have landed once at most N younger vector-memory operations are outstanding
+#define CLB_MQ_WAIT(N)                                                                                    \
+    if (WRITE_HALF) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph0), "+v"(pl0), "+v"(ph1), "+v"(pl1) :: "memory");
     int tile = blockIdx.x;
     CLB_MQ_LOAD(tile < n_tiles ? tile : n_tiles - 1)
+    CLB_MQ_WAIT(0)
     int buf = 0;
     while (tile < n_tiles) {            // uniform over the work-group: tile depends on blockIdx only
         unsigned char* my = lds16 + buf * (2 * 32 * kRowBytes16);
-        *reinterpret_cast<uint4*>(my + prow * kRowBytes16 + 16 * pchunk) = ph0;
-        *reinterpret_cast<uint4*>(my + (16 + prow) * kRowBytes16 + 16 * pchunk) = ph1;
-        *reinterpret_cast<uint4*>(my + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl0;
-        *reinterpret_cast<uint4*>(my + (48 + prow) * kRowBytes16 + 16 * pchunk) = pl1;
+        *reinterpret_cast<u32x4*>(my + prow * kRowBytes16 + 16 * pchunk) = ph0;
+        *reinterpret_cast<u32x4*>(my + (16 + prow) * kRowBytes16 + 16 * pchunk) = ph1;
+        *reinterpret_cast<u32x4*>(my + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl0;
+        *reinterpret_cast<u32x4*>(my + (48 + prow) * kRowBytes16 + 16 * pchunk) = pl1;
         const int next = tile + gridDim.x;
         CLB_MQ_LOAD(next < n_tiles ? next : n_tiles - 1)
         // one barrier per tile: the buffer written now was last read two iterations ago, before the previous barrier
@@ -443,21 +468,209 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int b = bq0 + q;
-                if (b < B) {
-                    unsigned char* dst = reinterpret_cast<unsigned char*>(cells16 + ((size_t)b * K + c0) * 16);
+                unsigned char* dst = reinterpret_cast<unsigned char*>(cells16 + ((size_t)b * K + c0) * 16);
+                // UNCONDITIONAL stores: rows past K and queries past B go to the 2-KB spill block behind the table
+                // (approx_cells_bytes) instead of being branched around, so that every iteration issues exactly four
+                // stores behind the next tile's four loads.  Left to hipcc, the loop waits with vmcnt(0) at its top
+                // -- for the write acknowledgements of the tile just stored, not only for the prefetched loads (it
+                // cannot count stores inside branches, and merges the loop entry, where nothing is younger than the
+                // loads).  The loads are therefore issued by hand (CLB_MQ_LOAD) and waited for with vmcnt(4) at the
+                // bottom of the loop: the stores drain under the next tile's MFMAs (0.1205 -> 0.112 ms per batch of 32)
+                unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * 16);
 #pragma unroll
-                    for (int part = 0; part < 2; ++part) {
-                        const int off = part * 1024 + lane * 16;   // centroid c0 + off / 64
-                        if (c0 + (off >> 6) < K)
-                            *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(patch + off);
-                    }
+                for (int part = 0; part < 2; ++part) {
+                    const int off = part * 1024 + lane * 16;   // centroid c0 + off / 64
+                    unsigned char* to = (b < B && c0 + (off >> 6) < K) ? dst + off : spill + off;
+                    *reinterpret_cast<uint4*>(to) = *reinterpret_cast<const uint4*>(patch + off);
                 }
             }
         }
+        CLB_MQ_WAIT(4)
         tile = next;
         buf ^= 1;
     }
 #undef CLB_MQ_LOAD
+#undef CLB_MQ_WAIT
+    const int slot = blockIdx.x * 2 + h;
+    const int nslots = gridDim.x * 2;
+    if (bq0 < B) {
+        ValIdx* out = partial + (((size_t)bq0 * 32 + i) * nslots + slot) * kTopPartial;   // [query][token][slot][entry]
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv0[p], bi0[p]};
+    }
+    if (bq0 + 1 < B) {
+        ValIdx* out = partial + (((size_t)(bq0 + 1) * 32 + i) * nslots + slot) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv1[p], bi1[p]};
+    }
+}
+
+// "Two teams" variant for batches of 16+ queries (round 3).  In the kernel above every wave alternates an MFMA phase
+// (48 MFMAs: 1 536 cycles of the matrix pipe) with an epilogue (group maxima, fp16 conversion, LDS transposition, table
+// stores), and the work-group barrier per tile keeps the two waves that share a SIMD in step: both want the matrix
+// pipe, then both leave it idle -- the pipe was 41 % busy.  s_memtime stamps around the phases (profiles/
+// r03_experiments.md) put a wave's tile at ~1 830 cycles of MFMA phase, ~2 500 of epilogue -- 1 220 of them waiting to
+// ISSUE its four table stores behind those of the other waves (the CU's texture-address unit takes ~70 cycles per store
+// instruction whatever its width) -- and ~500 at the staging barrier.  Three changes:
+//   * a work-group has EIGHT waves = two teams of four; wave w and wave w + 4 share a SIMD.  Both teams run
+//     MFMA(tile) -> epilogue(tile), but team 1 meets the barrier between the two and team 0 after them: between two
+//     barriers team 0 runs MFMA(k), epilogue(k) while team 1 runs epilogue(k-1), MFMA(k), so on every SIMD one wave
+//     multiplies while the other converts and transposes.  Still one barrier per tile;
+//   * the four table stores of a tile are issued one every twelve MFMAs of the wave's NEXT MFMA phase (data and
+//     addresses wait in registers), so a team's sixteen stores no longer arrive at the texture-address unit together;
+//   * sixteen queries per staged tile instead of eight: half the L2 reads of the split table.
+// The arithmetic per (query, tile) is unchanged, so are the error bound and the partial-list layout.
+// 0.1205 -> 0.106 ms per 32 queries x 131 072 centroids together with the hand-counted waits (both kernels) and the
+// hardware bf16 split of the query operands.
+// grid = (gx, ceil(B / 16)), block = 512, LDS = 2 buffers * 2 arrays * 32 rows * 272 B + 8 waves * 4 KB (66 KB).
+constexpr int kTeamQueries = 16;
+
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_teams_kernel(
+    const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
+    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int team = wave >> 2;
+    const int i = lane & 31, h = lane >> 5;
+    const int bq0 = blockIdx.y * kTeamQueries + wave * 2;   // this wave's queries: bq0, bq0 + 1
+    u32x4 qh[2][8], ql[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = bq0 + q < B ? bq0 + q : B - 1;      // past the batch: a duplicate whose results are dropped
+        const float* qrow = Q + ((size_t)b * T + (i < T ? i : T - 1)) * kDim + 64 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 8 * s);
+            const float4 c = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            uint32_t hh[4], ll[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                split_bf16_pair(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+                if (i >= T) { hh[j] = 0u; ll[j] = 0u; }      // tokens past T: zero operand rows
+            }
+            qh[q][s] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            ql[q][s] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        }
+    }
+    float bv0[kTopPartial], bv1[kTopPartial];
+    int bi0[kTopPartial], bi1[kTopPartial];
+#pragma unroll
+    for (int p = 0; p < kTopPartial; ++p) { bv0[p] = bv1[p] = kNegInf; bi0[p] = bi1[p] = 0x7fffffff; }
+    // loader: thread tid moves 16-B chunk (tid & 15) of row (tid >> 4), hi and lo.  Hand-issued and hand-waited, as in
+    // the kernel above: every epilogue issues exactly four stores, so the two loads of a tile have landed once at most
+    // four younger vector-memory operations are outstanding
+    const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
+    u32x4 ph, pl;
+#define CLB_TM_LOAD(TL)                                                                                   \
+    {                                                                                                     \
+        int c_ = (TL) * 32 + prow;                                                                        \
+        c_ = c_ < K ? c_ : K - 1;                                                                         \
+        const uint16_t* a0_ = Chi + (size_t)c_ * kDim + 8 * pchunk;                                       \
+        const uint16_t* a1_ = Clo + (size_t)c_ * kDim + 8 * pchunk;                                       \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"                 \
+                     : "=&v"(ph), "=&v"(pl) : "v"(a0_), "v"(a1_) : "memory");                             \
+    }
+#define CLB_TM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph), "+v"(pl) :: "memory");
+    // 48 MFMAs: the staged tile against this wave's two queries
+#define CLB_TM_STORE(DATA, ADDR) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ADDR), "v"(DATA));
+#define CLB_TM_MFMA(MY)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                  \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                   \
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + i * kRowBytes16 + 16 * (8 * h + s)));        \
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + (32 + i) * kRowBytes16 + 16 * (8 * h + s))); \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][s]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][s]), acc1, 0, 0, 0); \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
+            /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue) */            \
+            if (s == 0) CLB_TM_STORE(o0, a0)                                                              \
+            if (s == 2) CLB_TM_STORE(o1, a1)                                                              \
+            if (s == 4) CLB_TM_STORE(o2, a2)                                                              \
+            if (s == 6) CLB_TM_STORE(o3, a3)                                                              \
+        }                                                                                                 \
+    }
+    // epilogue of tile TL: group lists, then the 32 x 32 scores of each query become one 2-KB block of fp16 rows
+    // [centroid][token] (transposed through the wave's LDS patches) in o0..o3, with the addresses of its four 16-B-per-lane
+    // stores in a0..a3 (rows past K and queries past B: the spill block)
+#define CLB_TM_EPI(TL)                                                                                    \
+    {                                                                                                     \
+        const int c0 = (TL) * 32;                                                                         \
+        topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * (TL) + h);               \
+        topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * (TL) + h);               \
+        __builtin_amdgcn_wave_barrier();                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;                                                \
+            *reinterpret_cast<__half*>(patch + cl * 64 + i * 2) = __float2half_rn(acc0[r]);               \
+            *reinterpret_cast<__half*>(patch + 2048 + cl * 64 + i * 2) = __float2half_rn(acc1[r]);        \
+        }                                                                                                 \
+        __builtin_amdgcn_wave_barrier();                                                                  \
+        o0 = *reinterpret_cast<const u32x4*>(patch + lane * 16);                                          \
+        o1 = *reinterpret_cast<const u32x4*>(patch + 1024 + lane * 16);                                   \
+        o2 = *reinterpret_cast<const u32x4*>(patch + 2048 + lane * 16);                                   \
+        o3 = *reinterpret_cast<const u32x4*>(patch + 3072 + lane * 16);                                   \
+        unsigned char* d0_ = reinterpret_cast<unsigned char*>(cells16 + ((size_t)bq0 * K + c0) * 16) + lane * 16;  \
+        unsigned char* d1_ = d0_ + (size_t)K * 64;                                                        \
+        unsigned char* sp_ = spill + lane * 16;                                                           \
+        const bool in0_ = c0 + (lane >> 2) < K, in1_ = c0 + 16 + (lane >> 2) < K;   /* centroid of the 16-B piece */ \
+        a0 = bq0 < B && in0_ ? d0_ : sp_;                                                                 \
+        a1 = bq0 < B && in1_ ? d0_ + 1024 : sp_ + 1024;                                                   \
+        a2 = bq0 + 1 < B && in0_ ? d1_ : sp_;                                                             \
+        a3 = bq0 + 1 < B && in1_ ? d1_ + 1024 : sp_ + 1024;                                               \
+    }
+    unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 4096;      // one 2-KB patch per query
+    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * 16);
+    f32x16 acc0, acc1;
+    // the table stores of a tile are issued during the NEXT tile's MFMA phase (data in o0..o3, addresses in a0..a3; the
+    // first phase stores zeros to the spill block, the last tile's stores follow the loop)
+    u32x4 o0 = {0u, 0u, 0u, 0u}, o1 = o0, o2 = o0, o3 = o0;
+    unsigned char *a0 = spill + lane * 16, *a1 = a0 + 1024, *a2 = a0, *a3 = a1;
+    // Both teams run  MFMA(tile) -> epilogue(tile)  per iteration; what differs is WHERE in the iteration a team stages
+    // the next tile and meets the other at the barrier: team 0 after its epilogue, team 1 between its MFMAs and its
+    // epilogue.  Between two barriers team 0 therefore runs MFMA(k), epilogue(k) and team 1 epilogue(k-1), MFMA(k).
+    // The buffer written before barrier k+1 held tile k-1, whose last reads (MFMA(k-1), either team) precede barrier k.
+    // stage: the registers hold the tile after the staged one (requested one stage ago); behind those two loads are
+    // exactly the four stores of one MFMA phase, hence vmcnt(4)
+#define CLB_TM_STAGE()                                                                                    \
+    {                                                                                                     \
+        CLB_TM_WAIT(4)                                                                                    \
+        unsigned char* nb_ = lds16 + (buf ^ 1) * (2 * 32 * kRowBytes16);                                  \
+        *reinterpret_cast<u32x4*>(nb_ + prow * kRowBytes16 + 16 * pchunk) = ph;                           \
+        *reinterpret_cast<u32x4*>(nb_ + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;                    \
+        const int after_ = tile + 2 * (int)gridDim.x;                                                     \
+        CLB_TM_LOAD(after_ < n_tiles ? after_ : n_tiles - 1)                                              \
+        __syncthreads();                                                                                  \
+    }
+    int tile = blockIdx.x, buf = 0;
+    if (tile < n_tiles) {
+        CLB_TM_LOAD(tile)
+        CLB_TM_WAIT(0)
+        *reinterpret_cast<u32x4*>(lds16 + prow * kRowBytes16 + 16 * pchunk) = ph;
+        *reinterpret_cast<u32x4*>(lds16 + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;
+        const int second = tile + (int)gridDim.x;
+        CLB_TM_LOAD(second < n_tiles ? second : n_tiles - 1)
+        __syncthreads();
+    }
+    while (tile < n_tiles) {            // uniform over the work-group: tile depends on blockIdx only
+        const unsigned char* my = lds16 + buf * (2 * 32 * kRowBytes16);
+        CLB_TM_MFMA(my)
+        if (team == 1) CLB_TM_STAGE()
+        CLB_TM_EPI(tile)
+        if (team == 0) CLB_TM_STAGE()
+        tile += gridDim.x;
+        buf ^= 1;
+    }
+    CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1) CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3)    // the last tile's
+#undef CLB_TM_STAGE
+#undef CLB_TM_LOAD
+#undef CLB_TM_WAIT
+#undef CLB_TM_MFMA
+#undef CLB_TM_STORE
+#undef CLB_TM_EPI
     const int slot = blockIdx.x * 2 + h;
     const int nslots = gridDim.x * 2;
     if (bq0 < B) {
@@ -722,7 +935,7 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // ABL != 0: ablation variants for the roofline analysis (instantiated only in -DCLB_ABLATIONS builds; results are
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
 // stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
-// access in the loop at all.
+// access in the loop at all; 8 no result stores (what the passage-end stores and the waits they widen cost).
 // GL = 1 ("LDS-DMA gather", round 3): the score rows reach the wave through LDS instead of VGPRs.  Four ADJACENT lanes
 // fetch the 64 bytes of one row with global_load_lds_dwordx4 (16 rows per instruction, 2 instructions per step) -- one
 // L1 tag look-up per row where the VGPR form (lane (r, h) fetching 2 x 16 B of row r, the lanes of a row 32 apart)
@@ -1006,8 +1219,11 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             if (TAG.last) {                                                                                 \
                 mx = max_lane_halves(mx);                                                                   \
                 const float sum = sum_lanes_0_31(r < T ? mx : 0.f);     /* valid in lanes 16..31 */         \
+                if (ABL == 8) { if (sum == 12345.678f) out[0] = mx; }    /* ablation: no result stores */     \
+                else {                                                                                      \
                 if (lane == 16 && TAG.j >= 0) out[TAG.j] = sum;                                             \
                 if (h == 0 && TAG.j >= 0) tmax[(size_t)TAG.j * 32] = (uint16_t)f32_to_f16_floor(mx);       \
+                }                                                                                           \
                 mx = kNegInf;                                                                               \
             }                                                                                               \
         }                                                                                                   \

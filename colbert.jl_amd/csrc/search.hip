@@ -252,6 +252,11 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
                           : std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
         const int gx_dbg = CLB_KNOB("CLB_DEBUG_S1_GX", 0);
         if (gx_dbg > 0 && !mq) gx = std::min(gx_dbg, n_tiles / 2 + 1);
+        // 16+ queries and a score table to write: two teams of four waves per work-group, 16 queries per staged tile
+        // (centroid_top_bf16x3_teams_kernel); one 8-wave work-group per CU
+        const bool teams = mq && want_half && B >= kTeamQueries && CLB_KNOB("CLB_DEBUG_S1_TEAMS", 1);
+        const int team_groups = (B + kTeamQueries - 1) / kTeamQueries;
+        if (teams) gx = std::max(1, std::min(n_tiles, std::min(256, std::max(256 / team_groups, 16))));
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
@@ -263,7 +268,19 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
-                if (mq && want_half)
+                if (teams) {
+                    // 66 KB of dynamic LDS: above the 64-KB default limit of a launch
+                    static const bool raised = [] {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * kRowBytes16 + 8 * 4096);
+                        (void)hipGetLastError();
+                        return true;
+                    }();
+                    (void)raised;
+                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
+                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
+                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
+                } else if (mq && want_half)
                     hipLaunchKernelGGL(centroid_top_bf16x3_mq_kernel<true>, dim3(gx, groups), dim3(256), lds_b16 + 4 * 2048, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
@@ -582,6 +599,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 case 5: CLB_LAUNCH_APPROX(5); break;
                 case 6: CLB_LAUNCH_APPROX(6); break;
                 case 7: CLB_LAUNCH_APPROX(7); break;
+                case 8: CLB_LAUNCH_APPROX(8); break;
                 default: CLB_LAUNCH_APPROX(0);
             }
 #else
