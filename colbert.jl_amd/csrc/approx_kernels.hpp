@@ -533,6 +533,24 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     const int team = wave >> 2;
     const int i = lane & 31, h = lane >> 5;
     const int bq0 = blockIdx.y * kTeamQueries + wave * 2;   // this wave's queries: bq0, bq0 + 1
+    // loader: thread tid moves 16-B chunk (tid & 15) of row (tid >> 4), hi and lo.  Hand-issued and hand-waited, as in
+    // the kernel above: every epilogue issues exactly four stores, so the two loads of a tile have landed once at most
+    // four younger vector-memory operations are outstanding
+    const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
+    u32x4 ph, pl;
+#define CLB_TM_LOAD(TL)                                                                                   \
+    {                                                                                                     \
+        int c_ = (TL) * 32 + prow;                                                                        \
+        c_ = c_ < K ? c_ : K - 1;                                                                         \
+        const uint16_t* a0_ = Chi + (size_t)c_ * kDim + 8 * pchunk;                                       \
+        const uint16_t* a1_ = Clo + (size_t)c_ * kDim + 8 * pchunk;                                       \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"                 \
+                     : "=&v"(ph), "=&v"(pl) : "v"(a0_), "v"(a1_) : "memory");                             \
+    }
+#define CLB_TM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph), "+v"(pl) :: "memory");
+    // the first tile is requested before the query operands are split
+    int tile = blockIdx.x, buf = 0;
+    CLB_TM_LOAD(tile < n_tiles ? tile : n_tiles - 1)
     u32x4 qh[2][8], ql[2][8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -558,21 +576,6 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     int bi0[kTopPartial], bi1[kTopPartial];
 #pragma unroll
     for (int p = 0; p < kTopPartial; ++p) { bv0[p] = bv1[p] = kNegInf; bi0[p] = bi1[p] = 0x7fffffff; }
-    // loader: thread tid moves 16-B chunk (tid & 15) of row (tid >> 4), hi and lo.  Hand-issued and hand-waited, as in
-    // the kernel above: every epilogue issues exactly four stores, so the two loads of a tile have landed once at most
-    // four younger vector-memory operations are outstanding
-    const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
-    u32x4 ph, pl;
-#define CLB_TM_LOAD(TL)                                                                                   \
-    {                                                                                                     \
-        int c_ = (TL) * 32 + prow;                                                                        \
-        c_ = c_ < K ? c_ : K - 1;                                                                         \
-        const uint16_t* a0_ = Chi + (size_t)c_ * kDim + 8 * pchunk;                                       \
-        const uint16_t* a1_ = Clo + (size_t)c_ * kDim + 8 * pchunk;                                       \
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"                 \
-                     : "=&v"(ph), "=&v"(pl) : "v"(a0_), "v"(a1_) : "memory");                             \
-    }
-#define CLB_TM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph), "+v"(pl) :: "memory");
     // 48 MFMAs: the staged tile against this wave's two queries
 #define CLB_TM_STORE(DATA, ADDR) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ADDR), "v"(DATA));
 #define CLB_TM_MFMA(MY)                                                                                   \
@@ -645,10 +648,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         CLB_TM_LOAD(after_ < n_tiles ? after_ : n_tiles - 1)                                              \
         __syncthreads();                                                                                  \
     }
-    int tile = blockIdx.x, buf = 0;
     if (tile < n_tiles) {
-        CLB_TM_LOAD(tile)
-        CLB_TM_WAIT(0)
+        // (tied to the last operand words, or hipcc moves the wait in front of the operand split)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ph), "+v"(pl), "+v"(ql[0][7]), "+v"(ql[1][7]) :: "memory");
         *reinterpret_cast<u32x4*>(lds16 + prow * kRowBytes16 + 16 * pchunk) = ph;
         *reinterpret_cast<u32x4*>(lds16 + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;
         const int second = tile + (int)gridDim.x;

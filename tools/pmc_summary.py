@@ -24,7 +24,8 @@ def bench_id(name: str):
     if base == "score_approx32_kernel":
         return "rescore_rows" if name.startswith("score_approx32_kernel<true") else "score_approx"
     return {"score_exact_flat_kernel": "score_exact", "score_exact_kernel": "score_exact",
-            "centroid_top_bf16x3_mq_kernel": "centroid_scores"}.get(base)
+            "centroid_top_bf16x3_mq_kernel": "centroid_scores",
+            "centroid_top_bf16x3_teams_kernel": "centroid_scores"}.get(base)
 
 
 def csrc_hash() -> str:
