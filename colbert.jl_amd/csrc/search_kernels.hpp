@@ -987,10 +987,13 @@ static __global__ __launch_bounds__(256, 3) void score_exact_flat_kernel(
             m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));                                                            \
             m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));                                                            \
             m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));                                                            \
-            float total = 0.f;           /* sequential sum over tokens (ranking.jl:83) */                     \
+            /* sequential sum over tokens (ranking.jl:83).  The maxima reach the adder through v_readlane (a scalar  */ \
+            /* operand, no LDS round trip as with ds_bpermute: 32 of those per passage were a quarter of the wave's  */ \
+            /* non-MFMA time); tokens past T add +0.0, which leaves a sum that started from +0.0 unchanged            */ \
+            float total = 0.f;                                                                                 \
             _Pragma("unroll") for (int t = 0; t < 32; ++t) {                                                   \
-                const float v = __shfl(t < 16 ? m0 : m1, t & 15, 64);                                          \
-                if (t < T) total = total + v;                                                                  \
+                const uint32_t sv = __builtin_amdgcn_readlane(__float_as_uint(t < 16 ? m0 : m1), t & 15);      \
+                total = total + __uint_as_float(t < T ? sv : 0u);                                              \
             }                                                                                                  \
             if (lane == 0 && TAG.slot >= 0) out[TAG.slot] = total;                                             \
             m0 = kNegInf;                                                                                      \

@@ -286,16 +286,17 @@ def test_search_query_lengths(oracle, T):
 
 @pytest.mark.parametrize("T", [32, 20])
 def test_search_batch_sizes(oracle, T):
-    """Batches of 8+ queries take the shared-tile centroid kernel (8 queries per work-group, ragged last group);
-    smaller ones the per-query kernel.  Both must give the oracle's result in both modes."""
+    """Batches of 8-15 queries take the shared-tile centroid kernel (8 queries per work-group, ragged last group), 16+
+    the two-team kernel when it also writes the score table (mode 1: 16 queries per work-group, ragged last group and
+    whole duplicate waves), smaller ones the per-query kernel.  All must give the oracle's result in both modes."""
     idx = synthetic.make_index(seed=19, n_docs=4000, K=1024)
-    Qs = synthetic.make_queries(idx, 20, 19, T=T)
+    Qs = synthetic.make_queries(idx, 20, 35, T=T)
     ref = [oracle.search(idx, Qs[:, :, j], nprobe=2, k=50) for j in range(Qs.shape[2])]
     s = clb.Searcher(index=idx)
     try:
         for mode in (0, 1):
             s.set_mode(mode)
-            for B in (7, 8, 11, 16, 19):
+            for B in (7, 8, 11, 16, 19, 33, 35):
                 bp, bs, bn = s.search_batch(np.asfortranarray(Qs[:, :, :B]), 50, nprobe=2)
                 for j in range(B):
                     rp, rs, rn = ref[j]
