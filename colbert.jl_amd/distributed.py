@@ -253,6 +253,27 @@ class DeviceSearch:
                                             C.c_void_p(st)))
         return self.out_p, self.out_s
 
+    def capture(self, Qstatic):
+        """A HIP graph of one search over the STATIC query buffer `Qstatic` (B, T, dim): the library enqueues nothing but
+        kernels and memsets on the stream it is handed, so the nine launches of a search can be captured once and
+        replayed -- write the next queries into `Qstatic` (e.g. let the encoder write there), `graph.replay()`, read
+        `out_p` / `out_s`.  Measured (one query, 1 M passages; bench.py `p50_latency_graph_replay_ms`, tools/graph_probe.py):
+        no faster than the stream launches (0.176-0.184 against 0.176-0.179 ms with a new query per replay) -- the host
+        enqueues the nine launches ahead of the device either way; offered for callers that replay graphs anyway.  The
+        search runs once on a side stream first, so that the workspace is sized outside the capture."""
+        import torch
+        self._check_queries(Qstatic)
+        cur = torch.cuda.current_stream(self.dev)
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self(Qstatic)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self(Qstatic)
+        return graph
+
     def __call__(self, Qdev):
         """Qdev: torch float32 tensor holding B queries laid out (B, T, dim) contiguous == Julia (dim, T, B)."""
         import torch

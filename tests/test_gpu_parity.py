@@ -635,6 +635,34 @@ def test_candidate_bitmap_slice_boundaries(oracle, n_docs):
     s.close()
 
 
+def test_captured_graph_replays_the_search(oracle):
+    """DeviceSearch.capture: the launches of one search captured as a HIP graph over a static query buffer; every
+    replay (new queries written into the buffer) gives the oracle's result."""
+    import torch
+    from colbert_jl_amd.distributed import DeviceSearch
+    idx = synthetic.make_index(seed=23, n_docs=6000, K=1024)
+    k = 60
+    s = clb.Searcher(index=idx)
+    try:
+        for B in (1, 17):
+            Qs = synthetic.make_queries(idx, 31, 3 * B)
+            Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
+            run = DeviceSearch(s, 32, B, k, 2)
+            q_static = Qdev[:B].clone()
+            graph = run.capture(q_static)
+            for it in range(3):
+                q_static.copy_(Qdev[it * B:(it + 1) * B])
+                graph.replay()
+                torch.cuda.synchronize()
+                for j in range(B):
+                    rp, rs, rn = oracle.search(idx, Qs[:, :, it * B + j], nprobe=2, k=k)
+                    assert np.array_equal(run.out_p[j].cpu().numpy(), rp), (B, it, j)
+                    assert_same_f32(run.out_s[j].cpu().numpy(), rs, f"graph B={B} it={it} q={j}")
+            del graph
+    finally:
+        s.close()
+
+
 def test_batches_in_flight_equal_serial_results():
     """Forty batches through two workspace slots on two streams (what bench.py times) give exactly the results the same
     batches give one after the other on one stream."""
