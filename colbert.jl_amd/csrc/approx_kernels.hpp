@@ -235,7 +235,7 @@ __device__ __forceinline__ float group_max16(const f32x16& acc, int c0, int h, i
     return fmaxf(m, acc[15]);
 }
 
-// grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * 2 arrays * 32 rows * 272 B.
+// grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * (2 arrays * 32 rows * 272 B + a 2-KB patch with WRITE_HALF).
 // partial: [B][32 tokens][nslots][kTopPartial], nslots = waves * 2 halves.
 template <bool WRITE_HALF>
 static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_kernel(
@@ -274,22 +274,41 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
     int tile = blockIdx.x * 2 + wave;
     const int prow = lane >> 4, pchunk = lane & 15;   // loader: instruction m covers rows 4m..4m+3, 16 chunks each
 #define CLB_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define CLB_PF_DECL(m) uint4 ph##m, pl##m;
+    // WRITE_HALF: the sixteen tile loads are issued and waited for by hand, as in the batched kernels below -- behind them
+    // are exactly the two table stores of a tile, so the next tile is waited for with vmcnt(2) (at the loop bottom: the
+    // last, clamped request has then landed too, before its destination registers die) instead of the vmcnt(0) hipcc
+    // places at the loop top when stores sit in branches, which also waits for the write acknowledgements
+#define CLB_PF_DECL(m) u32x4 ph##m, pl##m;
 #define CLB_PF_LOAD(m)                                                                        \
     {                                                                                         \
         int c = tl * 32 + 4 * m + prow;                                                       \
         c = c < K ? c : K - 1;                                                                \
-        ph##m = *reinterpret_cast<const uint4*>(Chi + (size_t)c * kDim + 8 * pchunk);          \
-        pl##m = *reinterpret_cast<const uint4*>(Clo + (size_t)c * kDim + 8 * pchunk);          \
+        const uint16_t* a0_ = Chi + (size_t)c * kDim + 8 * pchunk;                            \
+        const uint16_t* a1_ = Clo + (size_t)c * kDim + 8 * pchunk;                            \
+        if (WRITE_HALF) {                                                                     \
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"  \
+                         : "=&v"(ph##m), "=&v"(pl##m) : "v"(a0_), "v"(a1_) : "memory");       \
+        } else {                                                                              \
+            ph##m = *reinterpret_cast<const u32x4*>(a0_);                                     \
+            pl##m = *reinterpret_cast<const u32x4*>(a1_);                                     \
+        }                                                                                     \
     }
+#define CLB_PF_TIE(m) , "+v"(ph##m), "+v"(pl##m)
+#define CLB_PF_WAIT(N)                                                                        \
+    if (WRITE_HALF) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph0), "+v"(pl0) CLB_PF_TIE(1) CLB_PF_TIE(2) CLB_PF_TIE(3) \
+                                 CLB_PF_TIE(4) CLB_PF_TIE(5) CLB_PF_TIE(6) CLB_PF_TIE(7) :: "memory");
 #define CLB_PF_STORE(m)                                                                                          \
-    *reinterpret_cast<uint4*>(my + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = ph##m;                          \
-    *reinterpret_cast<uint4*>(my + 32 * kRowBytes16 + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = pl##m;
+    *reinterpret_cast<u32x4*>(my + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = ph##m;                          \
+    *reinterpret_cast<u32x4*>(my + 32 * kRowBytes16 + (4 * m + prow) * kRowBytes16 + 16 * pchunk) = pl##m;
     CLB_REP8(CLB_PF_DECL)
     {
         const int tl = tile < n_tiles ? tile : n_tiles - 1;
         CLB_REP8(CLB_PF_LOAD)
     }
+    CLB_PF_WAIT(0)
+    // the wave's 2-KB transposition patch (behind the two waves' tile buffers) and the spill block behind the table
+    unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 2048;
+    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)gridDim.y * K * 16);
     while (tile < n_tiles) {
         const int c0 = tile * 32;
         CLB_REP8(CLB_PF_STORE)
@@ -312,22 +331,33 @@ static __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         __builtin_amdgcn_wave_barrier();
         topn_insert_lazy<kTopPartial>(bv, bi, group_max16(acc, c0, h, K), 2 * tile + h);
+        if (WRITE_HALF) {
+            // the tile's 32 x 32 scores leave as one 2-KB block of fp16 rows [centroid][token], transposed through the
+            // wave's LDS patch: two full-width stores (rows past K to the spill block) instead of sixteen dword stores
+            // in branches -- a store instruction costs the CU's texture-address unit ~70 cycles whatever its width
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (WRITE_HALF) {
-                const float other = __shfl_xor(acc[r], 1, 64);     // token i ^ 1, same centroid row
-                if ((i & 1) == 0 && c < K) {                       // row of 32 fp16 in token order: pairs {i, i+1}
-                    const __half2 hv = __floats2half2_rn(acc[r], other);
-                    cells16[((size_t)b * K + c) * 16 + (i >> 1)] = *reinterpret_cast<const uint32_t*>(&hv);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                *reinterpret_cast<__half*>(patch + cl * 64 + i * 2) = __float2half_rn(acc[r]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            unsigned char* dst = reinterpret_cast<unsigned char*>(cells16 + ((size_t)b * K + c0) * 16);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int off = part * 1024 + lane * 16;   // centroid c0 + off / 64
+                unsigned char* to = c0 + (off >> 6) < K ? dst + off : spill + off;
+                *reinterpret_cast<uint4*>(to) = *reinterpret_cast<const uint4*>(patch + off);
             }
         }
+        CLB_PF_WAIT(2)
         tile = next;
     }
 #undef CLB_REP8
 #undef CLB_PF_DECL
 #undef CLB_PF_LOAD
+#undef CLB_PF_TIE
+#undef CLB_PF_WAIT
 #undef CLB_PF_STORE
     const int slot = (blockIdx.x * 2 + wave) * 2 + h;
     const int nslots = gridDim.x * 4;
@@ -666,6 +696,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         tile += gridDim.x;
         buf ^= 1;
     }
+    // the last stage requested one more (clamped) tile: its two loads must have landed before their destination
+    // registers die -- hipcc does not know they are in flight and would hand the registers to the code below
+    CLB_TM_WAIT(0)
     CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1) CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3)    // the last tile's
 #undef CLB_TM_STAGE
 #undef CLB_TM_LOAD

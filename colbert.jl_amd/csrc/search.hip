@@ -246,7 +246,9 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
     if (nprobe <= 2 && T <= 32) {
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
         // batches of 8+ queries share each staged centroid tile between 8 queries (centroid_top_bf16x3_mq_kernel)
-        const bool mq = s->s1_mode == 1 && s->cent_hi.p && B >= kMqQueries;
+        // (from 6 queries: the shared-tile kernel with two idle query slots, 0.047 ms, beats six or seven per-query passes
+        // over the table, 0.06-0.07 ms)
+        const bool mq = s->s1_mode == 1 && s->cent_hi.p && B >= 6;
         const int groups = (B + kMqQueries - 1) / kMqQueries;
         int gx = mq ? std::max(1, std::min(n_tiles, std::min(256, std::max(512 / groups, 16))))
                           : std::max(1, std::min(n_tiles / 2 + 1, std::min(256, std::max(1024 / std::max(1, B), 16))));
@@ -289,7 +291,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), (uint32_t*)nullptr, (int)s->K, T, B, n_tiles);
                 else if (want_half)
-                    hipLaunchKernelGGL(centroid_top_bf16x3_kernel<true>, dim3(gx, B), dim3(128), lds_b16, st,
+                    hipLaunchKernelGGL(centroid_top_bf16x3_kernel<true>, dim3(gx, B), dim3(128), lds_b16 + 2 * 2048, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, n_tiles);
                 else
