@@ -1421,7 +1421,8 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    int* __restrict__ list, int* __restrict__ nlist,
                                                                    float* __restrict__ thresh,
                                                                    float* __restrict__ eps_pair,
-                                                                   const float* __restrict__ tau_in = nullptr) {
+                                                                   const float* __restrict__ tau_in = nullptr,
+                                                                   int coarse_tau = 0) {
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ int sh_scan[16];
     __shared__ int sh_big[2][8][16];
@@ -1473,7 +1474,11 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         tau_f = tau_in[b];
         thr = tau_f == kNegInf ? kNegInf : tau_f - 2.f * eps;
     } else if (n > k) {
-        CLB_RADIX_SELECT()
+        // coarse_tau (the unsharded search): two digit passes instead of four.  Any LOWER bound of the k-th approximate
+        // score keeps the proof of the two-pass mode (it only lists more); the lower edge of the k-th key's 16-bit bin
+        // is below it by at most 2^-16 of the score range (~5e-4 here against 2 eps ~ 0.09), and six block-wide
+        // barriers of the 32-us kernel go away.  The sharded protocol publishes EXACT local thresholds and keeps all passes
+        if (coarse_tau) { CLB_RADIX_SELECT_N(2) } else { CLB_RADIX_SELECT() }
         eps = qb.eps_sum;
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;

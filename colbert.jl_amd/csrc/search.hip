@@ -506,12 +506,13 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
 // up to 32 768 candidates in registers; shards whose queries can have several times that (candidate capacity >= 131 072:
 // roughly 3 M passages and up) take the wide selection -- kWideBlocks work-groups per query, one launch per radix pass.
 constexpr size_t kWideSelectCap = 131072;
-int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int k, const float* tau_in) {
+int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int k, const float* tau_in,
+                  bool coarse_tau = false) {
     const bool wide = s->wide_select == 1 || (s->wide_select < 0 && w.cand_cap >= kWideSelectCap);
     if (!wide) {
         hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
                            w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
-                           w.eps_pair.as<float>(), tau_in);
+                           w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0);
         return CLB_OK;
     }
     CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
@@ -622,7 +623,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         }
         {
             Timed t(s, KID_SELECT, st);
-            CLB_TRY(launch_select(s, w, st, dQ, B, T, k, nullptr));
+            CLB_TRY(launch_select(s, w, st, dQ, B, T, k, nullptr, /*coarse_tau=*/phase == 0));
         }
         list = w.list.as<int>();
         nlist = w.nlist.as<int>();

@@ -1081,7 +1081,11 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
 // the (up to) eight bits below the highest differing bit -- well spread -- and later passes only touch the keys of
 // the selected bin.  Leaves tau in *s_prefix and the rank inside the == tau group in *s_remaining.
 // Needs: __shared__ hist[256] (16-byte aligned), s_prefix, s_remaining (= rem on entry), s_kmin, s_kmax.
-#define CLB_RADIX_SELECT()                                                                                  \
+// CLB_RADIX_SELECT_N(LIMIT): stop after LIMIT digit passes -- *s_prefix is then the LOWER EDGE of the bin the rem-th
+// largest key lies in (its unresolved low bits zero), a lower bound of that key to 2^-8 (one pass) / 2^-16 (two passes)
+// of the key range; the rank in *s_remaining is then the rank inside that bin.
+#define CLB_RADIX_SELECT() CLB_RADIX_SELECT_N(99)
+#define CLB_RADIX_SELECT_N(LIMIT)                                                                           \
     {                                                                                                       \
         uint32_t kmin_ = 0xffffffffu, kmax_ = 0u;                                                           \
         CLB_SEL_FOR_EACH(if (valid) { kmin_ = key < kmin_ ? key : kmin_; kmax_ = key > kmax_ ? key : kmax_; }) \
@@ -1103,6 +1107,7 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
             int shift_ = top_ > 7 ? top_ - 7 : 0;                                                           \
             int width_ = top_ - shift_ + 1;                                                                 \
             if (tid == 0) s_prefix = top_ == 31 ? 0u : (s_kmax & (0xffffffffu << (top_ + 1)));              \
+            int passes_ = 0;                                                                                \
             for (;;) {                                                                                      \
                 if (tid < 256) hist[tid] = 0;                                                               \
                 __syncthreads();                                                                            \
@@ -1114,7 +1119,7 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, uint32_t bin, boo
                 __syncthreads();                                                                            \
                 if (tid < 64) radix_pick(hist, s_remaining, prefix_, shift_, &s_prefix, &s_remaining);      \
                 __syncthreads();                                                                            \
-                if (shift_ == 0) break;                                                                     \
+                if (shift_ == 0 || ++passes_ >= (LIMIT)) break;                                             \
                 const int ns_ = shift_ > 8 ? shift_ - 8 : 0;                                                \
                 width_ = shift_ - ns_;                                                                      \
                 shift_ = ns_;                                                                               \
