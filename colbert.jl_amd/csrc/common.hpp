@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/colbert_hip.h"
@@ -91,6 +94,19 @@ inline int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st = nu
 }
 
 constexpr float kNegInf = -__builtin_huge_valf();
+
+// A launch may use more than 64 KB of dynamic LDS only after the limit of that kernel has been raised -- per DEVICE
+// (a process may hold handles on several GPUs, one host thread each), so the raise is remembered per (kernel, device).
+inline void allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.insert({kernel, dev}).second) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipGetLastError();
+}
 
 // Launch-geometry knobs used while tuning: the shipped library compiles them to their defaults; a build with
 // -DCLB_ABLATIONS reads CLB_DEBUG_* from the environment instead (make ABLATIONS=1).

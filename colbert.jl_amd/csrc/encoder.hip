@@ -131,13 +131,8 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
     } else if (wgs(64, 128) >= 384 && N >= 128) {
         if (g_double_buffer) {
             // 72 KB of dynamic LDS: above the 64-KB default limit of a launch
-            static const bool raised = [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16split_kernel<2, 2, 1, 2, NS, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NS * (64 + 128) * 64);
-                (void)hipGetLastError();
-                return true;
-            }();
-            (void)raised;
+            allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16split_kernel<2, 2, 1, 2, NS, true>),
+                              2 * NS * (64 + 128) * 64);
             hipLaunchKernelGGL((gemm_bf16split_kernel<2, 2, 1, 2, NS, true>), dim3((N + 127) / 128, (M + 63) / 64, 1), dim3(256), 2 * lds(64, 128), st, g);
         }
         else

@@ -142,12 +142,7 @@ inline int token_tiles(int64_t T) { return T <= 32 ? 1 : T <= 64 ? 2 : 4; }
 
 // the top-k kernel sorts up to kMaxTopK 8-byte keys in LDS: beyond 64 KB the attribute has to be raised
 void allow_large_topk_lds() {
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(unsigned long long) * kMaxTopK));
-    (void)hipGetLastError();
-    done = true;
+    allow_dynamic_lds(reinterpret_cast<const void*>(topk_kernel), (int)(sizeof(unsigned long long) * kMaxTopK));
 }
 
 int next_pow2(int x) {
@@ -272,13 +267,8 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
                 if (teams) {
                     // 66 KB of dynamic LDS: above the 64-KB default limit of a launch
-                    static const bool raised = [] {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * kRowBytes16 + 8 * 4096);
-                        (void)hipGetLastError();
-                        return true;
-                    }();
-                    (void)raised;
+                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel),
+                                      2 * 2 * 32 * kRowBytes16 + 8 * 4096);
                     hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
