@@ -258,8 +258,9 @@ class DeviceSearch:
         kernels and memsets on the stream it is handed, so the nine launches of a search can be captured once and
         replayed -- write the next queries into `Qstatic` (e.g. let the encoder write there), `graph.replay()`, read
         `out_p` / `out_s`.  Measured (one query, 1 M passages; bench.py `p50_latency_graph_replay_ms`, tools/graph_probe.py):
-        no faster than the stream launches (0.176-0.184 against 0.176-0.179 ms with a new query per replay) -- the host
-        enqueues the nine launches ahead of the device either way; offered for callers that replay graphs anyway.  The
+        no faster than the stream launches (0.171-0.184 against 0.171-0.179 ms with a new query per replay) -- the host
+        enqueues the eleven launches ahead of the device either way; on a 10 M-passage index, where a search is ~20
+        launches, the replay is faster (0.259 against 0.318 ms).  The
         search runs once on a side stream first, so that the workspace is sized outside the capture."""
         import torch
         self._check_queries(Qstatic)
