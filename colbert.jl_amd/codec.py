@@ -78,14 +78,45 @@ def kmeans(data, init_centroids, max_iters: int = 10, tol: float = 1e-4, point_b
     return c, assign, iters.value
 
 
+def _is_tensor(a) -> bool:
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
+def _dev_rows(t, dtype=None):
+    """A torch CUDA tensor as the device array the ABI takes: (n, dim) row-major IS the reference's (dim, n) column-major
+    matrix.  Returns the (contiguous) tensor; the caller keeps it alive across the call."""
+    import torch
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError("device arrays must be contiguous CUDA tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _stream_of(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
 class KMeansShard:
-    """One rank's points of a sharded k-means (clb_kmeans_shard_*): uploaded once, one `pass_` per iteration."""
+    """One rank's points of a sharded k-means (clb_kmeans_shard_*): uploaded once, one `pass_` per iteration.
+    `data`: a (dim, n) numpy array (uploaded) or an (n, dim) float32 CUDA tensor (borrowed in place:
+    clb_kmeans_shard_create_device -- the tensor is kept alive by this object)."""
 
     def __init__(self, data, K: int, point_bsize: int = 1000, device: int = 0):
+        self._h = C.c_void_p()
+        if _is_tensor(data):
+            import torch
+            x = _dev_rows(data, torch.float32)
+            self._points = x                                    # borrowed by the handle
+            self.n, self.dim = x.shape
+            self.K, self.device = int(K), x.device.index
+            check(lib().clb_kmeans_shard_create_device(self.device, C.c_void_p(x.data_ptr()), i64(self.dim), i64(self.n),
+                                                       i64(K), i64(point_bsize), C.byref(self._h)))
+            return
         x = colmajor(data, np.float32)
         self.dim, self.n = x.shape
         self.K, self.device = int(K), device
-        self._h = C.c_void_p()
         check(lib().clb_kmeans_shard_create(device, fptr(x), i64(self.dim), i64(self.n), i64(K), i64(point_bsize),
                                             C.byref(self._h)))
 
@@ -104,14 +135,36 @@ class KMeansShard:
         return int(lib().clb_kmeans_shard_block_bytes(self._h))
 
     def set_centroids(self, centroids):
+        """(dim, K) numpy array or (K, dim) float32 CUDA tensor"""
+        if _is_tensor(centroids):
+            import torch
+            c = _dev_rows(centroids, torch.float32)
+            assert tuple(c.shape) == (self.K, self.dim)
+            torch.cuda.current_stream(c.device).synchronize()
+            check(lib().clb_kmeans_shard_set_centroids(self._h, C.c_void_p(c.data_ptr())))
+            return
         c = colmajor(centroids, np.float32)
         assert c.shape == (self.dim, self.K)
         check(lib().clb_kmeans_shard_set_centroids(self._h, fptr(c)))
 
-    def get_centroids(self):
+    def get_centroids(self, out=None):
+        """-> (dim, K) numpy array, or into `out`, a (K, dim) float32 CUDA tensor"""
+        if out is not None:
+            import torch
+            c = _dev_rows(out, torch.float32)
+            assert tuple(c.shape) == (self.K, self.dim)
+            torch.cuda.current_stream(c.device).synchronize()
+            check(lib().clb_kmeans_shard_get_centroids(self._h, C.c_void_p(c.data_ptr())))
+            return out
         c = np.zeros((self.dim, self.K), dtype=np.float32, order="F")
         check(lib().clb_kmeans_shard_get_centroids(self._h, fptr(c)))
         return c
+
+    def get_assignments(self):
+        """Int32[n], 1-based: the assignments of the last pass"""
+        a = np.zeros(self.n, dtype=np.int32)
+        check(lib().clb_kmeans_shard_get_assignments(self._h, fptr(a)))
+        return a
 
     def pass_device(self, d_block):
         """this rank's [sums | counts] block into the uint8 CUDA tensor `d_block` (block_bytes long)"""
@@ -141,6 +194,88 @@ class KMeansShard:
             self.close()
         except Exception:
             pass
+
+
+def kmeans_device(points, init_centroids, max_iters: int = 10, tol: float = 1e-4, point_bsize: int = 1000):
+    """kmeans_gpu_onehot!  (src/utils.jl:253-318) on points that are already in HBM: `points` (n, dim) and
+    `init_centroids` (K, dim) float32 CUDA tensors.  One shard, no exchange -- bit-identical to `kmeans` (the shard
+    handle documents that).  Returns (centroids (K, dim) CUDA tensor, iterations executed, shard handle -- open, for
+    `get_assignments`; close it)."""
+    import torch
+    sh = KMeansShard(points, init_centroids.shape[0], point_bsize)
+    sh.set_centroids(init_centroids)
+    blk = torch.empty(sh.block_bytes, dtype=torch.uint8, device=points.device)
+    it = 0
+    with torch.cuda.device(points.device):
+        for it in range(1, max_iters + 1):
+            sh.pass_device(blk)
+            _delta, conv = sh.update_device(blk, 1, tol)
+            if conv:
+                break
+    out = torch.empty_like(init_centroids)
+    sh.get_centroids(out)
+    return out, (it if max_iters > 0 else 0), sh
+
+
+class Codec:
+    """The chunk loop's resident codec (clb_codec_*): centroids and cutoffs uploaded once, `compress_device` per chunk
+    of device-resident embeddings (compress, residual.jl:586-604)."""
+
+    def __init__(self, centroids, bucket_cutoffs, dim: int, nbits: int, device: int = 0):
+        self._h = C.c_void_p()
+        self.dim, self.nbits = int(dim), int(nbits)
+        cu = np.ascontiguousarray(bucket_cutoffs, dtype=np.float32)
+        if _is_tensor(centroids):
+            import torch
+            c = _dev_rows(centroids, torch.float32)
+            self.K, self.device = int(c.shape[0]), c.device.index
+            torch.cuda.current_stream(c.device).synchronize()
+            cptr = C.c_void_p(c.data_ptr())
+        else:
+            c = colmajor(centroids, np.float32)
+            self.K, self.device = int(c.shape[1]), device
+            cptr = fptr(c)
+        check(lib().clb_codec_create(self.device, i64(dim), C.c_int(nbits), i64(self.K), cptr, fptr(cu), i64(cu.size),
+                                     C.byref(self._h)))
+
+    def compress_device(self, embs, out_codes=None, out_residuals=None):
+        """embs (n, dim) float32 CUDA tensor -> (codes uint32-as-int32 [n] 1-based, residuals uint8 (n, dim/8*nbits)),
+        enqueued on torch's current stream."""
+        import torch
+        x = _dev_rows(embs, torch.float32)
+        n = x.shape[0]
+        rows = self.dim // 8 * self.nbits
+        codes = out_codes if out_codes is not None else torch.empty(n, dtype=torch.int32, device=x.device)
+        res = out_residuals if out_residuals is not None else torch.empty((n, rows), dtype=torch.uint8, device=x.device)
+        assert codes.is_contiguous() and res.is_contiguous() and codes.numel() == n and res.numel() == n * rows
+        check(lib().clb_codec_compress_device(self._h, C.c_void_p(x.data_ptr()), i64(n), C.c_void_p(codes.data_ptr()),
+                                              C.c_void_p(res.data_ptr()), _stream_of(x)))
+        return codes, res
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().clb_codec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_ivf_device(codes, num_partitions: int):
+    """_build_ivf  (collection_indexer.jl:349-353) over a device array: codes int32/uint32 CUDA tensor [n] (1-based) ->
+    (ivf int64 CUDA tensor [n] 1-based, ivf_lengths int64 CUDA tensor [K])."""
+    import torch
+    co = _dev_rows(codes)
+    assert co.element_size() == 4
+    n = co.numel()
+    ivf = torch.empty(n, dtype=torch.int64, device=co.device)
+    lens = torch.empty(num_partitions, dtype=torch.int64, device=co.device)
+    check(lib().clb_build_ivf_device(co.device.index, C.c_void_p(co.data_ptr()), i64(n), i64(num_partitions),
+                                     C.c_void_p(ivf.data_ptr()), C.c_void_p(lens.data_ptr()), _stream_of(co)))
+    return ivf, lens
 
 
 def kmeans_reduce_update(centroids, gathered_sums, gathered_counts, tol: float = 1e-4, device: int = 0):

@@ -235,6 +235,67 @@ int clb_compress(int device, const float* centroids, int64_t K, const float* buc
     return CLB_OK;
 }
 
+// ---- codec handle: centroids, cutoffs and the nearest-centroid scratch stay on the device across chunks -----------
+struct clb_codec {
+    int device = 0;
+    int64_t dim = 0, K = 0, n_cutoffs = 0;
+    int nbits = 0;
+    DevBuf dC, dCut;
+    NearestScratch nscratch;
+    bool split_done = false;
+};
+
+int clb_codec_create(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
+                     const float* bucket_cutoffs, int64_t n_cutoffs, clb_codec** out) {
+    if (!out) return fail(CLB_EARGUMENT, "out is null");
+    *out = nullptr;
+    if (!centroids || (!bucket_cutoffs && n_cutoffs > 0)) return fail(CLB_EARGUMENT, "null argument");
+    if (dim < 8 || dim % 8 != 0) return fail(CLB_EDOMAIN, "dims should be a multiple of 8!");                // residual.jl:523-525
+    if (nbits < 1 || nbits > 16 || n_cutoffs != ((int64_t)1 << nbits) - 1)
+        return fail(CLB_EDOMAIN, "length(bucket_cutoffs) should be 2^nbits - 1!");
+    if (K < 1) return fail(CLB_EARGUMENT, "no centroids");
+    CLB_TRY(use_device(device));
+    auto* c = new clb_codec();
+    c->device = device; c->dim = dim; c->K = K; c->nbits = nbits; c->n_cutoffs = n_cutoffs;
+    int rc;
+    if ((rc = c->dC.alloc(sizeof(float) * dim * K)) || (rc = c->dCut.alloc(sizeof(float) * std::max<int64_t>(n_cutoffs, 1)))) {
+        delete c;
+        return rc;
+    }
+    // hipMemcpyDefault: host or device pointers (the centroids of a device-resident k-means never visit the host)
+    if (hipMemcpy(c->dC.p, centroids, sizeof(float) * dim * K, hipMemcpyDefault) != hipSuccess ||
+        (n_cutoffs > 0 && hipMemcpy(c->dCut.p, bucket_cutoffs, sizeof(float) * n_cutoffs, hipMemcpyDefault) != hipSuccess)) {
+        delete c;
+        return fail(CLB_EHIP, "codec upload failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *out = c;
+    return CLB_OK;
+}
+
+int clb_codec_destroy(clb_codec* c) {
+    if (!c) return CLB_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    delete c;
+    return CLB_OK;
+}
+
+int clb_codec_compress_device(clb_codec* c, const float* d_embs, int64_t n, uint32_t* d_codes, uint8_t* d_residuals,
+                              void* hip_stream) {
+    if (!c) return fail(CLB_EARGUMENT, "codec is null");
+    if (n < 0) return fail(CLB_EARGUMENT, "negative size");
+    if (n == 0) return CLB_OK;
+    if (!d_embs || !d_codes || !d_residuals) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(c->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int64_t rows = c->dim / 8 * c->nbits;
+    CLB_TRY(nearest_centroids<0>(st, c->dC.as<float>(), nullptr, (int)c->dim, (int)c->K, d_embs, n, d_codes, &c->nscratch));
+    hipLaunchKernelGGL(pack_residuals_kernel, dim3(blocks_for(n * rows)), dim3(256), 0, st, c->dC.as<float>(),
+                       c->dCut.as<float>(), (int)c->n_cutoffs, (int)c->dim, c->nbits, d_embs, d_codes, n, d_residuals);
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
 int clb_kmeans(int device, const float* data, int64_t dim, int64_t n, float* centroids, int64_t K,
                int64_t max_iters, float tol, int64_t point_bsize, int32_t* assignments, int64_t* iters_done) {
     if (K < 1 || dim < 1 || point_bsize < 1) return fail(CLB_EDIMENSION, "size(centroids, 2) must be k!");
@@ -304,12 +365,30 @@ struct clb_kmeans_shard {
     int64_t dim = 0, n = 0, K = 0, point_bsize = 0;
     int end_bit = 1;
     Stream s;
+    const float* X = nullptr;      // the shard's points: dX (uploaded copy) or the caller's device array (create_device)
     DevBuf dX, dC, dNew, dC2, dAssign, dOrder, dIota, dKeys, dCounts, dStart, dErr, dCnt32, dCnt64;
+    DevBuf sort_tmp, scan_tmp;     // rocPRIM temporaries (kept: the per-iteration sort and scan are only enqueued)
+    DevBuf dNext, dDelta;          // update_device: next centroids and max-abs delta (allocated once: a hipFree per
+                                   // iteration would be a device-wide synchronisation under the exchange)
     NearestScratch nscratch;
 };
 
+// shared by create (host points, uploaded) and create_device (device points, borrowed)
+static int kmeans_shard_create_impl(int device, const float* data, bool on_device, int64_t dim, int64_t n, int64_t K,
+                                    int64_t point_bsize, clb_kmeans_shard** out);
+
 int clb_kmeans_shard_create(int device, const float* data, int64_t dim, int64_t n, int64_t K, int64_t point_bsize,
                             clb_kmeans_shard** out) {
+    return kmeans_shard_create_impl(device, data, false, dim, n, K, point_bsize, out);
+}
+
+int clb_kmeans_shard_create_device(int device, const float* d_data, int64_t dim, int64_t n, int64_t K,
+                                   int64_t point_bsize, clb_kmeans_shard** out) {
+    return kmeans_shard_create_impl(device, d_data, true, dim, n, K, point_bsize, out);
+}
+
+static int kmeans_shard_create_impl(int device, const float* data, bool on_device, int64_t dim, int64_t n, int64_t K,
+                                    int64_t point_bsize, clb_kmeans_shard** out) {
     if (!out) return fail(CLB_EARGUMENT, "out is null");
     *out = nullptr;
     if (K < 1 || dim < 1 || point_bsize < 1 || n < 0) return fail(CLB_EDIMENSION, "size(centroids, 2) must be k!");
@@ -323,17 +402,20 @@ int clb_kmeans_shard_create(int device, const float* data, int64_t dim, int64_t 
     const int64_t n1 = std::max<int64_t>(n, 1);
     if (n > 0) {
         if (!data) return bail(fail(CLB_EARGUMENT, "data is null"));
-        if ((rc = upload(h->dX, data, sizeof(float) * dim * n, h->s.st))) return bail(rc);
+        if (on_device) h->X = data;
+        else if ((rc = upload(h->dX, data, sizeof(float) * dim * n, h->s.st))) return bail(rc);
     } else {      // a rank whose part of the clustering sample is empty: nothing to read from the host
         if ((rc = h->dX.alloc(sizeof(float) * dim))) return bail(rc);
         if (hipMemsetAsync(h->dX.p, 0, sizeof(float) * dim, h->s.st) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
     }
+    if (!h->X) h->X = h->dX.as<float>();
     if ((rc = h->dC.alloc(sizeof(float) * dim * K)) || (rc = h->dNew.alloc(sizeof(float) * dim * K)) ||
         (rc = h->dC2.alloc(sizeof(float) * K)) || (rc = h->dAssign.alloc(sizeof(uint32_t) * n1)) ||
         (rc = h->dOrder.alloc(sizeof(uint32_t) * n1)) || (rc = h->dIota.alloc(sizeof(uint32_t) * n1)) ||
         (rc = h->dKeys.alloc(sizeof(uint32_t) * n1)) || (rc = h->dCounts.alloc(sizeof(uint32_t) * (K + 1))) ||
         (rc = h->dStart.alloc(sizeof(uint32_t) * (K + 2))) || (rc = h->dCnt32.alloc(sizeof(int) * K)) ||
-        (rc = h->dCnt64.alloc(sizeof(long long) * K)) || (rc = h->dErr.alloc(sizeof(int))))
+        (rc = h->dCnt64.alloc(sizeof(long long) * K)) || (rc = h->dErr.alloc(sizeof(int))) ||
+        (rc = h->dNext.alloc(sizeof(float) * dim * K)) || (rc = h->dDelta.alloc(sizeof(unsigned int))))
         return bail(rc);
     if (n > 0) hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, h->s.st, h->dIota.as<uint32_t>(), n);
     while (((int64_t)1 << h->end_bit) <= K) ++h->end_bit;
@@ -373,7 +455,7 @@ static int kmeans_shard_pass_core(clb_kmeans_shard* h, hipStream_t st) {
     const int64_t n = h->n, K = h->K, dim = h->dim;
     hipLaunchKernelGGL(centroid_sumsq_kernel, dim3(blocks_for(K, 64)), dim3(64), 0, st, h->dC.as<float>(), (int)dim,
                        (int)K, h->dC2.as<float>());
-    CLB_TRY(nearest_centroids<1>(st, h->dC.as<float>(), h->dC2.as<float>(), (int)dim, (int)K, h->dX.as<float>(), n,
+    CLB_TRY(nearest_centroids<1>(st, h->dC.as<float>(), h->dC2.as<float>(), (int)dim, (int)K, h->X, n,
                                  h->dAssign.as<uint32_t>(), &h->nscratch));
     CLB_HIP(hipMemsetAsync(h->dCounts.p, 0, sizeof(uint32_t) * (K + 1), st));
     CLB_HIP(hipMemsetAsync(h->dErr.p, 0, sizeof(int), st));
@@ -381,10 +463,10 @@ static int kmeans_shard_pass_core(clb_kmeans_shard* h, hipStream_t st) {
         hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, st, h->dAssign.as<uint32_t>(), n,
                            (uint32_t)K, h->dCounts.as<unsigned int>(), h->dErr.as<int>());
         CLB_TRY(sort_pairs_u32(h->dAssign.as<uint32_t>(), h->dKeys.as<uint32_t>(), h->dIota.as<uint32_t>(),
-                               h->dOrder.as<uint32_t>(), (size_t)n, h->end_bit, st));
+                               h->dOrder.as<uint32_t>(), (size_t)n, h->end_bit, st, &h->sort_tmp));
     }
-    CLB_TRY(exclusive_scan_u32(h->dCounts.as<uint32_t>(), h->dStart.as<uint32_t>(), (size_t)K, st));
-    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, st, h->dX.as<float>(),
+    CLB_TRY(exclusive_scan_u32(h->dCounts.as<uint32_t>(), h->dStart.as<uint32_t>(), (size_t)K, st, &h->scan_tmp));
+    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, st, h->X,
                        (int)dim, h->dOrder.as<uint32_t>(), h->dStart.as<uint32_t>(), (int)K, (int)h->point_bsize,
                        h->dNew.as<float>(), h->dCnt32.as<int>());
     hipLaunchKernelGGL(widen_counts_kernel, dim3(blocks_for(K)), dim3(256), 0, st, h->dCnt32.as<int>(),
@@ -406,7 +488,8 @@ int64_t clb_kmeans_shard_block_bytes(const clb_kmeans_shard* h) {
 int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids) {
     if (!h || !centroids) return fail(CLB_EARGUMENT, "null argument");
     CLB_TRY(use_device(h->device));
-    CLB_HIP(hipMemcpyAsync(h->dC.p, centroids, sizeof(float) * h->dim * h->K, hipMemcpyHostToDevice, h->s.st));
+    // hipMemcpyDefault: `centroids` may be a host or a device pointer (unified addressing tells them apart)
+    CLB_HIP(hipMemcpyAsync(h->dC.p, centroids, sizeof(float) * h->dim * h->K, hipMemcpyDefault, h->s.st));
     CLB_HIP(hipStreamSynchronize(h->s.st));
     return CLB_OK;
 }
@@ -414,7 +497,15 @@ int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids) 
 int clb_kmeans_shard_get_centroids(clb_kmeans_shard* h, float* centroids) {
     if (!h || !centroids) return fail(CLB_EARGUMENT, "null argument");
     CLB_TRY(use_device(h->device));
-    CLB_HIP(hipMemcpy(centroids, h->dC.p, sizeof(float) * h->dim * h->K, hipMemcpyDeviceToHost));
+    CLB_HIP(hipMemcpy(centroids, h->dC.p, sizeof(float) * h->dim * h->K, hipMemcpyDefault));
+    return CLB_OK;
+}
+
+int clb_kmeans_shard_get_assignments(clb_kmeans_shard* h, int32_t* assignments) {
+    if (!h || (!assignments && h->n > 0)) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(h->device));
+    CLB_HIP(hipStreamSynchronize(h->s.st));
+    if (h->n > 0) CLB_HIP(hipMemcpy(assignments, h->dAssign.p, sizeof(int32_t) * h->n, hipMemcpyDefault));
     return CLB_OK;
 }
 
@@ -448,9 +539,8 @@ int clb_kmeans_shard_update_device(clb_kmeans_shard* h, const void* d_gathered, 
     hipStream_t st = (hipStream_t)hip_stream;
     const int64_t K = h->K, dim = h->dim;
     const size_t blk = (size_t)clb_kmeans_shard_block_bytes(h);
-    DevBuf dDelta, dNext;
-    CLB_TRY(dDelta.alloc(sizeof(unsigned int)));
-    CLB_TRY(dNext.alloc(sizeof(float) * dim * K));
+    DevBuf& dDelta = h->dDelta;
+    DevBuf& dNext = h->dNext;
     CLB_HIP(hipMemsetAsync(dDelta.p, 0, sizeof(unsigned int), st));
     const char* g = static_cast<const char*>(d_gathered);
     hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3(blocks_for(K * dim)), dim3(256), 0, st,
@@ -466,9 +556,9 @@ int clb_kmeans_shard_update_device(clb_kmeans_shard* h, const void* d_gathered, 
     if (delta_out) *delta_out = delta;
     const int conv = delta < tol;      // utils.jl:308-311: the previous centroids stay
     if (converged) *converged = conv;
-    if (!conv) {
-        CLB_HIP(hipMemcpyAsync(h->dC.p, dNext.p, sizeof(float) * dim * K, hipMemcpyDeviceToDevice, st));
-        CLB_HIP(hipStreamSynchronize(st));
+    if (!conv) {   // the stream is idle (synchronised above): the new centroids become the handle's by a pointer swap
+        std::swap(h->dC.p, dNext.p);
+        std::swap(h->dC.bytes, dNext.bytes);
     }
     return CLB_OK;
 }
@@ -539,42 +629,61 @@ int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int
     return CLB_OK;
 }
 
+// _build_ivf on device arrays: stable LSD radix sort of (code, embedding id) + histogram; d_ivf / d_lens are device
+// pointers (Int64, 1-based ids).  Synchronises `st` (the code range check must be read back: counts(values, K) throws).
+static int build_ivf_core(hipStream_t st, const uint32_t* d_codes, int64_t n, int64_t K, int64_t* d_ivf, int64_t* d_lens) {
+    DevBuf dKeys, dIota, dOrder, dCounts, dErr;
+    CLB_TRY(dKeys.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dIota.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dOrder.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
+    CLB_TRY(dCounts.alloc(sizeof(uint32_t) * std::max<int64_t>(K, 1)));
+    CLB_TRY(dErr.alloc(sizeof(int)));
+    CLB_HIP(hipMemsetAsync(dCounts.p, 0, dCounts.bytes, st));
+    CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), st));
+    if (n > 0) {
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dIota.as<uint32_t>(), n);
+        hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d_codes, n, (uint32_t)K,
+                           dCounts.as<unsigned int>(), dErr.as<int>());
+        int herr = 0;
+        CLB_HIP(hipMemcpyAsync(&herr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        CLB_HIP(hipStreamSynchronize(st));
+        if (herr) return fail(CLB_EBOUNDS, "codes outside 1..num_partitions");  // counts(values, K) would throw
+        int end_bit = 1;
+        while (((int64_t)1 << end_bit) <= K) ++end_bit;
+        CLB_TRY(sort_pairs_u32(d_codes, dKeys.as<uint32_t>(), dIota.as<uint32_t>(), dOrder.as<uint32_t>(), (size_t)n,
+                               end_bit, st));
+        hipLaunchKernelGGL(ivf_widen_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dOrder.as<uint32_t>(), n, d_ivf);
+    }
+    if (K > 0)
+        hipLaunchKernelGGL(widen_u32_i64_kernel, dim3(blocks_for(K)), dim3(256), 0, st, dCounts.as<uint32_t>(), K, d_lens);
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipStreamSynchronize(st));      // the scratch above is freed on return
+    return CLB_OK;
+}
+
 int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64_t* ivf, int64_t* ivf_lengths) {
     if (K < 0 || n < 0) return fail(CLB_EARGUMENT, "negative size");
     if (n >= (int64_t)0xffffffffll) return fail(CLB_EUNSUPPORTED, "n too large");
     CLB_TRY(use_device(device));
     Stream s; CLB_TRY(s.init());
-    DevBuf dCodes, dKeys, dIota, dOrder, dCounts, dErr, dIvf;
+    DevBuf dCodes, dIvf, dLens;
     CLB_TRY(upload(dCodes, codes, sizeof(uint32_t) * std::max<int64_t>(n, 1), s.st));
-    CLB_TRY(dKeys.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
-    CLB_TRY(dIota.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
-    CLB_TRY(dOrder.alloc(sizeof(uint32_t) * std::max<int64_t>(n, 1)));
-    CLB_TRY(dCounts.alloc(sizeof(uint32_t) * std::max<int64_t>(K, 1)));
     CLB_TRY(dIvf.alloc(sizeof(int64_t) * std::max<int64_t>(n, 1)));
-    CLB_TRY(dErr.alloc(sizeof(int)));
-    CLB_HIP(hipMemsetAsync(dCounts.p, 0, dCounts.bytes, s.st));
-    CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), s.st));
-    if (n > 0) {
-        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dIota.as<uint32_t>(), n);
-        hipLaunchKernelGGL(code_histogram_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dCodes.as<uint32_t>(), n,
-                           (uint32_t)K, dCounts.as<unsigned int>(), dErr.as<int>());
-        int herr = 0;
-        CLB_HIP(hipMemcpyAsync(&herr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, s.st));
-        CLB_HIP(hipStreamSynchronize(s.st));
-        if (herr) return fail(CLB_EBOUNDS, "codes outside 1..num_partitions");  // counts(values, K) would throw
-        int end_bit = 1;
-        while (((int64_t)1 << end_bit) <= K) ++end_bit;
-        CLB_TRY(sort_pairs_u32(dCodes.as<uint32_t>(), dKeys.as<uint32_t>(), dIota.as<uint32_t>(), dOrder.as<uint32_t>(),
-                               (size_t)n, end_bit, s.st));
-        hipLaunchKernelGGL(ivf_widen_kernel, dim3(blocks_for(n)), dim3(256), 0, s.st, dOrder.as<uint32_t>(), n,
-                           dIvf.as<int64_t>());
-        CLB_HIP(hipMemcpyAsync(ivf, dIvf.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, s.st));
-    }
-    std::vector<uint32_t> cnt((size_t)std::max<int64_t>(K, 1));
-    CLB_HIP(hipMemcpyAsync(cnt.data(), dCounts.p, sizeof(uint32_t) * std::max<int64_t>(K, 1), hipMemcpyDeviceToHost, s.st));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * std::max<int64_t>(K, 1)));
+    CLB_TRY(build_ivf_core(s.st, dCodes.as<uint32_t>(), n, K, dIvf.as<int64_t>(), dLens.as<int64_t>()));
+    if (n > 0) CLB_HIP(hipMemcpyAsync(ivf, dIvf.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, s.st));
+    if (K > 0) CLB_HIP(hipMemcpyAsync(ivf_lengths, dLens.p, sizeof(int64_t) * K, hipMemcpyDeviceToHost, s.st));
     CLB_HIP(hipStreamSynchronize(s.st));
-    for (int64_t c = 0; c < K; ++c) ivf_lengths[c] = cnt[c];
     return CLB_OK;
+}
+
+int clb_build_ivf_device(int device, const uint32_t* d_codes, int64_t n, int64_t K, int64_t* d_ivf,
+                         int64_t* d_ivf_lengths, void* hip_stream) {
+    if (K < 0 || n < 0) return fail(CLB_EARGUMENT, "negative size");
+    if (n >= (int64_t)0xffffffffll) return fail(CLB_EUNSUPPORTED, "n too large");
+    if ((n > 0 && (!d_codes || !d_ivf)) || (K > 0 && !d_ivf_lengths)) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(device));
+    return build_ivf_core((hipStream_t)hip_stream, d_codes, n, K, d_ivf, d_ivf_lengths);
 }
 
 int clb_doc_epilogue(int device, const float* D, int64_t dim, int64_t L, int64_t N, const int32_t* integer_ids,

@@ -348,6 +348,11 @@ static __global__ void widen_counts_kernel(const int* __restrict__ c32, long lon
     if (i < K) c64[i] = c32[i];
 }
 
+static __global__ void widen_u32_i64_kernel(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
 static __global__ void iota_kernel(uint32_t* __restrict__ v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;

@@ -66,7 +66,7 @@ struct Workspace {
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
         outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds;
-    DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch;   // general-shape path (generic_kernels.hpp)
+    DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch, g_sort_tmp;   // general-shape path (generic_kernels.hpp)
 };
 
 constexpr int kWorkspaceSlots = 4;
@@ -399,7 +399,7 @@ int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* c
     hipLaunchKernelGGL(generic_sel_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cells, stride_t,
                        stride_c, (int)s->K, T, w.g_keys.as<unsigned long long>(), w.g_vals.as<uint32_t>());
     CLB_TRY(sort_pairs_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), w.g_vals.as<uint32_t>(),
-                           w.g_vals2.as<uint32_t>(), n, st));
+                           w.g_vals2.as<uint32_t>(), n, st, &w.g_sort_tmp));
     hipLaunchKernelGGL(generic_sel_extract_kernel, dim3((unsigned)((T * nprobe + 255) / 256)), dim3(256), 0, st,
                        w.g_vals2.as<uint32_t>(), (int)s->K, T, nprobe, NP, sel_b);
     CLB_HIP(hipGetLastError());
@@ -408,7 +408,9 @@ int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* c
 
 // top-k of ONE query by a full stable sort (k above the single-work-group sort of topk_kernel).  The count stays on the
 // device: the sort runs over the slot's candidate capacity with the positions past the count keyed to the end, the
-// emit kernel writes the short-result flag and the candidate count -- no host synchronisation per query.
+// emit kernel writes the short-result flag and the candidate count; rocPRIM's temporary storage lives in the workspace
+// slot (g_sort_tmp, sized on first use), so the sort is only enqueued -- no allocation and no host synchronisation per
+// query.  The price of keeping the count on the device: the sort covers cand_cap keys, not the query's own count.
 int topk_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, int b, const int* list, const int* nlist, int k,
                  int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand) {
     const int cap = (int)w.cand_cap;
@@ -419,7 +421,7 @@ int topk_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, int b, const int
     CLB_TRY(w.g_keys2.ensure(sizeof(uint64_t) * std::max(cap, 1)));
     hipLaunchKernelGGL(generic_topk_keys_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, sc, lst, n_ptr, cap,
                        w.g_keys.as<unsigned long long>());
-    CLB_TRY(sort_keys_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), (size_t)cap, st));
+    CLB_TRY(sort_keys_u64(w.g_keys.as<uint64_t>(), w.g_keys2.as<uint64_t>(), (size_t)cap, st, &w.g_sort_tmp));
     hipLaunchKernelGGL(generic_topk_emit_kernel, dim3((std::max(k, 1) + 255) / 256), dim3(256), 0, st,
                        w.g_keys2.as<unsigned long long>(), sc, w.cand.as<uint32_t>() + (size_t)b * w.cand_cap, lst, n_ptr,
                        w.ncand.as<int>() + b, k, s->pid_offset, d_out_pids + (size_t)b * k, d_out_scores + (size_t)b * k,
@@ -696,10 +698,34 @@ int clb_device_count(void) {
     return n;
 }
 
+// `big_on_device`: centroids, codes, residuals and ivf are device pointers on `device` (an index that was built there:
+// clb_codec_compress_device / clb_build_ivf_device); the per-passage and per-centroid lengths are host arrays either way
+static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
+                                const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                                const uint32_t* codes, const uint8_t* residuals, const int64_t* ivf,
+                                const int64_t* ivf_lengths, int64_t pid_offset, bool big_on_device, clb_searcher** out);
+
 int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
                         const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
                         const uint32_t* codes, const uint8_t* residuals, const int64_t* ivf,
                         const int64_t* ivf_lengths, int64_t pid_offset, clb_searcher** out) {
+    return searcher_create_impl(device, dim, nbits, K, centroids, bucket_weights, n_docs, doclens, n_emb, codes, residuals,
+                                ivf, ivf_lengths, pid_offset, false, out);
+}
+
+int clb_searcher_create_device(int device, int64_t dim, int nbits, int64_t K, const float* d_centroids,
+                               const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                               const uint32_t* d_codes, const uint8_t* d_residuals, const int64_t* d_ivf,
+                               const int64_t* ivf_lengths, int64_t pid_offset, clb_searcher** out) {
+    return searcher_create_impl(device, dim, nbits, K, d_centroids, bucket_weights, n_docs, doclens, n_emb, d_codes,
+                                d_residuals, d_ivf, ivf_lengths, pid_offset, true, out);
+}
+
+static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
+                                const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                                const uint32_t* codes, const uint8_t* residuals, const int64_t* ivf,
+                                const int64_t* ivf_lengths, int64_t pid_offset, bool big_on_device, clb_searcher** out) {
+    const hipMemcpyKind big_kind = big_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (!out) return fail(CLB_EARGUMENT, "out is null");
     *out = nullptr;
     if (dim < 8 || dim % 8 != 0) return fail(CLB_EDOMAIN, "dim should be a multiple of 8!");          // residual.jl:763-768
@@ -743,7 +769,9 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
 
     const size_t rows = (size_t)(dim / 8 * nbits);
     int rc;
-    if ((rc = upload(s->centroids, centroids, sizeof(float) * dim * K, s->stream))) return bail(rc);
+    if ((rc = s->centroids.alloc(sizeof(float) * dim * K))) return bail(rc);
+    if (hipMemcpyAsync(s->centroids.p, centroids, sizeof(float) * dim * K, big_kind, s->stream) != hipSuccess)
+        return bail(fail(CLB_EHIP, "index upload failed"));
     if ((rc = upload(s->weights, bucket_weights, sizeof(float) * ((size_t)1 << nbits), s->stream))) return bail(rc);
     // pad the per-embedding arrays by one step (dummy steps read embeddings 0 .. kStepRows-1 even of a tiny index)
     constexpr int64_t kPad = kStepRows;
@@ -751,14 +779,16 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K, const flo
     if ((rc = s->residuals.alloc(rows * (n_emb + kPad)))) return bail(rc);
     if (hipMemsetAsync(s->codes0.p, 0, s->codes0.bytes, s->stream) != hipSuccess ||
         hipMemsetAsync(s->residuals.p, 0, s->residuals.bytes, s->stream) != hipSuccess ||
-        hipMemcpyAsync(s->codes0.p, codes, sizeof(uint32_t) * n_emb, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
-        hipMemcpyAsync(s->residuals.p, residuals, rows * n_emb, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+        hipMemcpyAsync(s->codes0.p, codes, sizeof(uint32_t) * n_emb, big_kind, s->stream) != hipSuccess ||
+        hipMemcpyAsync(s->residuals.p, residuals, rows * n_emb, big_kind, s->stream) != hipSuccess)
         return bail(fail(CLB_EHIP, "index upload failed"));
     if ((rc = upload(s->doc_off, doc_off.data(), sizeof(uint32_t) * doc_off.size(), s->stream))) return bail(rc);
     if ((rc = upload(s->ivf_off, ivf_off.data(), sizeof(uint32_t) * ivf_off.size(), s->stream))) return bail(rc);
     if ((rc = s->ivf_pid.alloc(sizeof(uint32_t) * n_emb))) return bail(rc);
     DevBuf ivf_raw, err;
-    if ((rc = upload(ivf_raw, ivf, sizeof(int64_t) * n_emb, s->stream))) return bail(rc);
+    if ((rc = ivf_raw.alloc(sizeof(int64_t) * n_emb))) return bail(rc);
+    if (n_emb > 0 && hipMemcpyAsync(ivf_raw.p, ivf, sizeof(int64_t) * n_emb, big_kind, s->stream) != hipSuccess)
+        return bail(fail(CLB_EHIP, "index upload failed"));
     if ((rc = err.alloc(sizeof(int)))) return bail(rc);
     if (hipMemsetAsync(err.p, 0, sizeof(int), s->stream) != hipSuccess) return bail(fail(CLB_EHIP, "memset failed"));
     if (n_emb > 0) {

@@ -100,3 +100,138 @@ def index(indexer: Indexer) -> Optional[str]:
     storage._save(os.path.join(path, "ivf"), ivf); storage._save(os.path.join(path, "ivf_lengths"), ivf_lengths)
     assert storage.check_all_files_are_saved(path)
     return path
+
+
+# ---- the same build with every large array resident in HBM ----------------------------------------------------------
+class DeviceEmbeddingSource:
+    """Stands in for the BERT checkpoint when the collection's fp32 embeddings do not fit host memory (1 M passages:
+    80 M x 128 fp32 = 41 GB): `doclens` (Int64[n_docs], host) and `chunk(start, end)` -> the (n_emb, dim) float32 CUDA
+    tensor of passages start..end-1 (0-based, end exclusive), i.e. what `encode_passages` returns, left on the device.
+    `chunk` must be reproducible: index_device() reads every passage twice (sample, then compress), as the reference
+    encodes its sample and then every chunk (collection_indexer.jl:56-79, 271-297)."""
+
+    dim = 128
+    doclens: np.ndarray
+
+    def chunk(self, start: int, end: int):
+        raise NotImplementedError
+
+
+def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: int = 20, chunksize=None, seed: int = 0,
+                 num_partitions=None, log=None):
+    """The array stages of index() (src/indexing.jl:63-147) with the sample, the codes, the residuals and the IVF kept in
+    HBM: sample pids -> gather their embeddings -> shuffle, held-out split -> setup -> k-means (the device-resident shard
+    handle) -> codec statistics -> per chunk: compress (resident codec) -> _build_ivf.  Returns (index, record): `index`
+    holds CUDA tensors (centroids (K, dim), codes int32 [n] 1-based, residuals uint8 (n, dim/8*nbits), ivf int64 [n]) and
+    host arrays (doclens, ivf_lengths, bucket_cutoffs, bucket_weights) -- what Searcher(index=...) takes; `record` the
+    seconds per stage.  RNG-dependent draws use numpy's generator (module docstring)."""
+    import time
+
+    import torch
+    doclens = np.ascontiguousarray(source.doclens, dtype=np.int64)
+    n_docs = doclens.size
+    dim = source.dim
+    dev = source.device
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    n_emb = int(off[-1])
+    rec = {"passages": int(n_docs), "embeddings": n_emb}
+    sync = lambda: torch.cuda.synchronize(dev)
+
+    def tick(name, t0):
+        sync()
+        rec[name] = round(time.time() - t0, 3)
+        if log:
+            log(f"index_device: {name} {rec[name]} s")
+
+    # sample (collection_indexer.jl:17-24, 56-79): the embeddings of the sampled passages, chunk by chunk
+    t0 = time.time()
+    n_s = codec.num_sampled_pids(n_docs)
+    sampled = np.unique(rng.integers(0, n_docs, size=n_s))
+    plan_chunk = int(chunksize or min(25000, 1 + n_docs))
+    n_sample = int(doclens[sampled].sum())
+    sample = torch.empty((n_sample, dim), dtype=torch.float32, device=dev)
+    fill = 0
+    for start in range(0, n_docs, plan_chunk):
+        end = min(n_docs, start + plan_chunk)
+        mine = sampled[(sampled >= start) & (sampled < end)]
+        if mine.size == 0:
+            continue
+        x = source.chunk(start, end)
+        rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in mine])
+        sample[fill:fill + rows.size] = x[torch.from_numpy(rows).to(dev)]
+        fill += rows.size
+        del x
+    assert fill == n_sample
+    avg_doclen_est = float(np.float32(doclens[sampled].sum() / max(sampled.size, 1)))
+    # held-out split (collection_indexer.jl:81-91): shuffle the columns, the last heldout_size go to the held-out set
+    perm = torch.from_numpy(rng.permutation(n_sample)).to(dev)
+    sample = sample[perm]
+    del perm
+    h = codec.heldout_size(n_sample)
+    heldout = sample[n_sample - h:]
+    sample = sample[:n_sample - h]
+    plan = codec.setup(n_docs, avg_doclen_est, sample.shape[0], chunksize, 1)
+    K = int(num_partitions or plan["num_partitions"])
+    init = sample[torch.from_numpy(rng.permutation(sample.shape[0])[:K]).to(dev)].contiguous()
+    rec.update({"sample_points": int(sample.shape[0]), "heldout": int(h), "K": K, "chunksize": plan["chunksize"]})
+    tick("sample_and_split_s", t0)
+
+    # train (collection_indexer.jl:219-237)
+    t0 = time.time()
+    sample = sample.contiguous()
+    centroids, iters, shard = codec.kmeans_device(sample, init, max_iters=kmeans_niters)
+    shard.close()
+    tick("kmeans_s", t0)
+    rec["kmeans_iters"] = int(iters)
+    rec["kmeans_s_per_iter"] = round(rec["kmeans_s"] / max(iters, 1), 4)
+    t0 = time.time()
+    cent_host = np.asfortranarray(centroids.cpu().numpy().T)
+    cut, w, avg, _ = codec.compute_avg_residuals(nbits, cent_host, np.asfortranarray(heldout.cpu().numpy().T), device=dev.index)
+    tick("codec_stats_s", t0)
+    del sample, heldout, init
+
+    # chunk loop (collection_indexer.jl:271-297)
+    t0 = time.time()
+    rows = dim // 8 * nbits
+    codes = torch.empty(n_emb, dtype=torch.int32, device=dev)
+    residuals = torch.empty((n_emb, rows), dtype=torch.uint8, device=dev)
+    cdc = codec.Codec(centroids, cut, dim, nbits)
+    t_src = 0.0
+    for start in range(0, n_docs, plan["chunksize"]):
+        end = min(n_docs, start + plan["chunksize"])
+        t1 = time.time()
+        x = source.chunk(start, end)
+        sync()
+        t_src += time.time() - t1
+        a, b = int(off[start]), int(off[end])
+        assert x.shape[0] == b - a
+        cdc.compress_device(x, codes[a:b], residuals[a:b])
+        sync()
+        del x
+    cdc.close()
+    tick("chunks_s", t0)
+    rec["generate_chunks_s"] = round(t_src, 3)
+    rec["compress_s"] = round(rec["chunks_s"] - t_src, 3)
+    rec["compress_Membeddings_per_s"] = round(n_emb / max(rec["compress_s"], 1e-9) / 1e6, 2)
+    t0 = time.time()
+    ivf, ivf_lengths = codec.build_ivf_device(codes, K)
+    tick("build_ivf_s", t0)
+    rec["total_build_s"] = round(rec["sample_and_split_s"] + rec["kmeans_s"] + rec["codec_stats_s"] + rec["chunks_s"] + rec["build_ivf_s"], 2)
+    index = {"dim": dim, "nbits": nbits, "centroids": centroids, "bucket_cutoffs": cut, "bucket_weights": w,
+             "avg_residual": avg, "doclens": doclens, "codes": codes, "residuals": residuals, "ivf": ivf,
+             "ivf_lengths": ivf_lengths.cpu().numpy(), "pid_offset": 0}
+    return index, rec
+
+
+def index_to_host(index: dict) -> dict:
+    """A device-resident index (index_device) as the numpy arrays of the reference's layout (what the oracle and
+    storage.save_* take): centroids (dim, K), codes UInt32, residuals (rows, n) column-major, ivf Int64."""
+    out = dict(index)
+    t = lambda a: a.cpu().numpy() if hasattr(a, "data_ptr") else np.asarray(a)
+    out["centroids"] = np.asfortranarray(t(index["centroids"]).T)
+    out["codes"] = t(index["codes"]).view(np.uint32)
+    out["residuals"] = np.asfortranarray(t(index["residuals"]).T)
+    out["ivf"] = t(index["ivf"])
+    out["ivf_lengths"] = t(index["ivf_lengths"])
+    return out

@@ -31,6 +31,9 @@ class Searcher:
         self.device = device
         self.encoder = encoder
         self.dim = int(index["dim"]); self.nbits = int(index["nbits"])
+        if hasattr(index["codes"], "data_ptr"):
+            self._create_from_device_arrays(index, pid_offset)
+            return
         c = colmajor(index["centroids"], np.float32)
         w = np.ascontiguousarray(index["bucket_weights"], dtype=np.float32)
         dl = np.ascontiguousarray(index["doclens"], dtype=np.int64)
@@ -49,6 +52,34 @@ class Searcher:
         check(lib().clb_searcher_create(device, i64(self.dim), C.c_int(self.nbits), i64(c.shape[1]), fptr(c), fptr(w),
                                         i64(dl.size), fptr(dl), i64(co.size), fptr(co), fptr(r), fptr(iv), fptr(il),
                                         i64(pid_offset), C.byref(self._h)))
+
+    def _create_from_device_arrays(self, index: dict, pid_offset: int):
+        """An index that was built in HBM (indexer.index_device): centroids (K, dim) float32, codes int32/uint32 [n],
+        residuals uint8 (n, dim/8*nbits), ivf int64 [n] as CUDA tensors; doclens / ivf_lengths / bucket_weights on the
+        host (numpy or tensors) -- clb_searcher_create_device."""
+        import torch
+        c, co, r, iv = index["centroids"], index["codes"], index["residuals"], index["ivf"]
+        for t in (c, co, r, iv):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ColBERTError("device index arrays must be contiguous CUDA tensors")
+        host = lambda a, dt: np.ascontiguousarray(a.cpu().numpy() if hasattr(a, "data_ptr") else a, dtype=dt)
+        w, dl, il = host(index["bucket_weights"], np.float32), host(index["doclens"], np.int64), host(index["ivf_lengths"], np.int64)
+        if c.dtype != torch.float32 or c.shape[1] != self.dim:
+            raise ColBERTError("centroids must be a (K, dim) float32 tensor")
+        if co.element_size() != 4 or r.dtype != torch.uint8 or iv.dtype != torch.int64:
+            raise ColBERTError("codes must be 32-bit, residuals uint8, ivf int64")
+        if tuple(r.shape) != (co.numel(), self.dim // 8 * self.nbits):
+            raise ColBERTError("residuals must be (n_emb, dim/8*nbits)")
+        if il.size != c.shape[0]:
+            raise ColBERTError("ivf_lengths must have one entry per centroid")
+        self.device = c.device.index
+        self.num_centroids = int(c.shape[0]); self.num_docs = dl.size; self.num_embeddings = co.numel()
+        torch.cuda.synchronize(c.device)
+        self._h = C.c_void_p()
+        check(lib().clb_searcher_create_device(self.device, i64(self.dim), C.c_int(self.nbits), i64(c.shape[0]),
+                                               C.c_void_p(c.data_ptr()), fptr(w), i64(dl.size), fptr(dl), i64(co.numel()),
+                                               C.c_void_p(co.data_ptr()), C.c_void_p(r.data_ptr()), C.c_void_p(iv.data_ptr()),
+                                               fptr(il), i64(pid_offset), C.byref(self._h)))
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):

@@ -158,3 +158,46 @@ def make_embeddings(seed: int, n_docs: int, dim: int = 128, doclen_mean: float =
     x = centres[comp] + 0.25 * rng.standard_normal((n_emb, dim), dtype=np.float32) / np.float32(math.sqrt(dim)) * np.float32(math.sqrt(dim) / 4)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     return np.asfortranarray(x.T.astype(np.float32)), doclens
+
+
+class DeviceMixtureSource:
+    """`make_embeddings` for collections whose fp32 embeddings do not fit host memory: the same 4096-component mixture
+    (centre + 0.25 * Gaussian, normalised), generated ON THE DEVICE in fixed blocks of `block` passages, each from its
+    own counter-based stream -- any passage range can be regenerated bit for bit (indexer.DeviceEmbeddingSource).
+    torch is used as the random-number generator of the synthetic INPUT only."""
+
+    def __init__(self, seed: int, n_docs: int, device, dim: int = 128, doclen_mean: float = 80.0, doclen_std: float = 16.0,
+                 n_components: int = 4096, block: int = 25000):
+        import torch
+        self.seed, self.n_docs, self.dim, self.block = seed, n_docs, dim, block
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        rng = np.random.default_rng(seed)
+        self.doclens = np.clip(np.rint(doclen_mean + doclen_std * rng.standard_normal(n_docs)), 8, 220).astype(np.int64)
+        self.off = np.concatenate([[0], np.cumsum(self.doclens)])
+        centres = rng.standard_normal((n_components, dim), dtype=np.float32)
+        centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+        self.centres = torch.from_numpy(centres).to(self.device)
+
+    def _block(self, b: int):
+        import torch
+        lo, hi = b * self.block, min(self.n_docs, (b + 1) * self.block)
+        n = int(self.off[hi] - self.off[lo])
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed * 1_000_003 + b)
+        comp = torch.randint(0, self.centres.shape[0], (n,), generator=g, device=self.device)
+        x = torch.randn((n, self.dim), generator=g, device=self.device, dtype=torch.float32)
+        x.mul_(0.25).add_(self.centres[comp])
+        x.div_(torch.linalg.vector_norm(x, dim=1, keepdim=True))
+        return x
+
+    def chunk(self, start: int, end: int):
+        """(n_emb, dim) float32 CUDA tensor of passages start..end-1"""
+        import torch
+        parts = []
+        for b in range(start // self.block, (max(end, start + 1) - 1) // self.block + 1):
+            lo = b * self.block
+            x = self._block(b)
+            a = int(self.off[max(start, lo)] - self.off[lo])
+            z = int(self.off[min(end, lo + self.block, self.n_docs)] - self.off[lo])
+            parts.append(x[a:z])
+        return parts[0].contiguous() if len(parts) == 1 else torch.cat(parts)

@@ -55,6 +55,14 @@ int clb_searcher_create(int device, int64_t dim, int nbits, int64_t K,
                         const int64_t* ivf /* n_emb, 1-based embedding ids */,
                         const int64_t* ivf_lengths /* K */, int64_t pid_offset,
                         clb_searcher** out);
+/* The same Searcher from an index that is already in HBM (built there by clb_codec_compress_device /
+ * clb_build_ivf_device: Searcher(index_path) loads exactly these arrays, src/searching.jl:41-59): d_centroids, d_codes,
+ * d_residuals and d_ivf are device pointers on `device`, copied into the handle (the caller may free them on return);
+ * bucket_weights, doclens and ivf_lengths are host arrays as above. */
+int clb_searcher_create_device(int device, int64_t dim, int nbits, int64_t K, const float* d_centroids,
+                               const float* bucket_weights, int64_t n_docs, const int64_t* doclens, int64_t n_emb,
+                               const uint32_t* d_codes, const uint8_t* d_residuals, const int64_t* d_ivf,
+                               const int64_t* ivf_lengths, int64_t pid_offset, clb_searcher** out);
 int clb_searcher_destroy(clb_searcher* s);
 /* bytes of HBM held by the handle (index + workspace) */
 int64_t clb_searcher_device_bytes(const clb_searcher* s);
@@ -215,8 +223,17 @@ int clb_kmeans_shard_pass(clb_kmeans_shard* h, const float* centroids /* (dim,K)
  * the n_ranks gathered blocks in rank order and applies utils.jl:302-314 to the handle's centroids (one 4-byte
  * read-back per iteration: delta).  Bit-identical to clb_kmeans_shard_pass + clb_kmeans_reduce_update. */
 int64_t clb_kmeans_shard_block_bytes(const clb_kmeans_shard* h);
-int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids /* (dim,K) host */);
-int clb_kmeans_shard_get_centroids(clb_kmeans_shard* h, float* centroids /* (dim,K) host */);
+/* `centroids` may be a host or a device pointer in both calls (the runtime tells them apart) */
+int clb_kmeans_shard_set_centroids(clb_kmeans_shard* h, const float* centroids /* (dim,K) */);
+int clb_kmeans_shard_get_centroids(clb_kmeans_shard* h, float* centroids /* (dim,K) */);
+/* A shard whose points are ALREADY in HBM (the clustering sample of a collection too large to stage through host
+ * memory: 14 M x 128 fp32 at 1 M passages): d_data (dim, n) is borrowed, not copied -- the caller keeps it alive and
+ * unchanged until clb_kmeans_shard_destroy. */
+int clb_kmeans_shard_create_device(int device, const float* d_data /* (dim, n) device */, int64_t dim, int64_t n,
+                                   int64_t K, int64_t point_bsize, clb_kmeans_shard** out);
+/* the assignments of the last pass (Int32, 1-based: `assignments` of kmeans_gpu_onehot!, utils.jl:253); host or
+ * device pointer, n entries */
+int clb_kmeans_shard_get_assignments(clb_kmeans_shard* h, int32_t* assignments);
 int clb_kmeans_shard_pass_device(clb_kmeans_shard* h, void* d_block, void* hip_stream);
 int clb_kmeans_shard_update_device(clb_kmeans_shard* h, const void* d_gathered /* n_ranks blocks */, int64_t n_ranks,
                                    float tol, float* delta_out, int* converged, void* hip_stream);
@@ -231,6 +248,25 @@ int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int
 /* _build_ivf  (collection_indexer.jl:349-353) */
 int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64_t* ivf,
                   int64_t* ivf_lengths);
+/* The same over device arrays (80 M codes at 1 M passages never visit the host): d_codes UInt32[n] 1-based,
+ * d_ivf Int64[n], d_ivf_lengths Int64[K], all on `device`; runs on `hip_stream` and waits for it (the range check of
+ * counts(values, K) has to be read back: CLB_EBOUNDS). */
+int clb_build_ivf_device(int device, const uint32_t* d_codes, int64_t n, int64_t K, int64_t* d_ivf,
+                         int64_t* d_ivf_lengths, void* hip_stream);
+
+/* The chunk loop of index()  (src/indexing.jl:102-118, collection_indexer.jl:271-297: encode a chunk of passages ->
+ * compress -> save) with the codec resident: the centroids (64 MB at K = 131 072), their bf16 split and the
+ * nearest-centroid scratch are uploaded / allocated once instead of once per chunk, and a chunk's embeddings, codes and
+ * residuals are device arrays -- the encoder's output (clb_encode_docs on the device) or a generator's.
+ * clb_codec_create: `centroids` (dim,K) and `bucket_cutoffs` (2^nbits - 1) may be host or device pointers.
+ * clb_codec_compress_device = compress (residual.jl:586-604) for n embeddings d_embs (dim, n): d_codes UInt32[n] 1-based,
+ * d_residuals UInt8 (dim/8*nbits, n); enqueued on hip_stream, not waited for.  Bit-identical to clb_compress. */
+typedef struct clb_codec clb_codec;
+int clb_codec_create(int device, int64_t dim, int nbits, int64_t K, const float* centroids,
+                     const float* bucket_cutoffs, int64_t n_cutoffs, clb_codec** out);
+int clb_codec_destroy(clb_codec* c);
+int clb_codec_compress_device(clb_codec* c, const float* d_embs, int64_t n, uint32_t* d_codes, uint8_t* d_residuals,
+                              void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Exchange step of the sharded search / index build on RCCL  (the reference is single-GPU)
