@@ -239,6 +239,58 @@ def build_config2_index(clb, docs, kmeans_iters, device):
     return index, rec
 
 
+def build_device_index(torch, docs, kmeans_iters, dev):
+    """`docs` passages of mixture embeddings through this repo's index build with every large array resident in HBM
+    (indexer.index_device: the fp32 embeddings of 1 M passages are 41 GB and exist only chunk by chunk, generated on the
+    device): sample -> k-means -> codec statistics -> per chunk compress -> IVF, seconds per stage."""
+    from colbert_jl_amd import indexer, synthetic
+    src = synthetic.DeviceMixtureSource(seed=61, n_docs=docs, device=dev)
+    index, rec = indexer.index_device(src, nbits=2, kmeans_niters=kmeans_iters, seed=62)
+    for stage, n_pts, secs in (("kmeans", rec["sample_points"] * rec["kmeans_iters"], rec["kmeans_s"]),
+                               ("compress", rec["embeddings"], rec["compress_s"])):
+        tf = 3 * 2.0 * 128 * n_pts * rec["K"] / max(secs, 1e-9) / 1e12
+        rec[stage + "_roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF,
+                                    "unit": "TFLOP/s (bf16, 3 products per fp32 product; " +
+                                            ("the centroid update inside the time)" if stage == "kmeans" else "residual packing inside the time)"),
+                                    "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
+    rec["input"] = "generated on the device chunk by chunk (synthetic.DeviceMixtureSource); no host copy of the embeddings exists"
+    return index, rec
+
+
+def sharded_index_build(torch, dist, rank, world, docs, kmeans_iters, dev):
+    """BASELINE config 5's build half on the N ranks of this job: the passages sharded in contiguous ranges, one rank's
+    range generated on its own GPU, sample / k-means / statistics / compress / IVF through
+    distributed_index.index_device_sharded over the process group (RCCL: one all-gather of the [sums | counts] blocks
+    per k-means iteration).  Seconds per stage = MAX over ranks; the centroids must agree on every rank."""
+    from colbert_jl_amd import synthetic
+    from colbert_jl_amd.distributed_index import index_device_sharded
+    n_local = docs // world
+    src = synthetic.DeviceMixtureSource(seed=610 + rank, n_docs=n_local, device=dev)
+    index, rec = index_device_sharded(src, rank * n_local, n_local * world, nbits=2, kmeans_niters=kmeans_iters, seed=62)
+    staged = dist.get_backend() != "nccl"
+    cdev = torch.device("cpu") if staged else dev
+    keys = ["sample_and_split_s", "kmeans_s", "codec_stats_s", "chunks_s", "build_ivf_s", "total_build_s"]
+    t = torch.tensor([rec[kk] for kk in keys], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # identical centroids on every rank: min and max over the ranks of a checksum agree
+    ck = index["centroids"].view(torch.int32).to(torch.int64).sum().reshape(1).to(cdev)
+    lo, hi = ck.clone(), ck.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    out = {kk: round(float(v), 3) for kk, v in zip(keys, t.tolist())}
+    out.update({"ranks": world, "passages_total": rec["passages_total"], "passages_per_rank": n_local, "K": rec["K"],
+                "sample_points_total": rec["sample_points_total"], "kmeans_iters": rec["kmeans_iters"],
+                "kmeans_s_per_iter": round(out["kmeans_s"] / max(rec["kmeans_iters"], 1), 4),
+                "kmeans_exchange_bytes_per_rank_per_iter": rec["kmeans_exchange_bytes_per_rank_per_iter"],
+                "centroids_identical_on_all_ranks": bool(lo.item() == hi.item()),
+                "exchange": "staged through host memory (gloo rehearsal)" if staged else "RCCL all_gather_into_tensor",
+                "note": "seconds per stage are the MAX over the ranks; every rank builds and keeps its own shard"})
+    tf = 3 * 2.0 * 128 * rec["sample_points_total"] * rec["K"] * rec["kmeans_iters"] / max(out["kmeans_s"], 1e-9) / 1e12
+    out["kmeans_roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF * world,
+                              "unit": "TFLOP/s over all ranks (bf16, 3 products per fp32 product; exchange and update inside the time)",
+                              "frac": round(tf / (BF16_MFMA_PEAK_TF * world), 4)}
+    return out
+
+
 def encoder_l2_operand_bytes(M, N, Kd):
     """fp32 operand bytes the work-groups of one Linear layer pull through L2, mirroring linear_split's tile choice
     (csrc/encoder.hip): every work-group streams its A rows and B rows of the K range it owns."""
@@ -286,6 +338,11 @@ def main():
                     help="make the config-2 built index (100k passages through this repo's own index build) the HEADLINE workload")
     ap.add_argument("--built-docs", type=int, default=100_000, help="passages of the built_index workload (BASELINE config 2)")
     ap.add_argument("--built-kmeans-iters", type=int, default=20, help="k-means iterations of the built index (reference default)")
+    ap.add_argument("--no-built-1m", action="store_true",
+                    help="skip built_index_1M (the headline corpus size through this repo's own device-resident index build, ~40 s)")
+    ap.add_argument("--built-1m-docs", type=int, default=0,
+                    help="passages of the built_index_1M workload (0: 1 000 000 when --docs is at least that, else skipped; tests pass a small value)")
+    ap.add_argument("--no-index-build", action="store_true", help="N > 1: skip the sharded index build over the process group")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -348,7 +405,13 @@ def main():
     t0 = time.time()
     if args.built_index:
         assert world == 1, "--built-index is a single-GPU workload (BASELINE config 2)"
-        shard, index_build = build_config2_index(clb, args.built_docs, args.built_kmeans_iters, local_rank)
+        if args.built_docs > 200_000:      # the fp32 embeddings no longer fit a host buffer comfortably: device-resident build
+            from colbert_jl_amd.indexer import index_to_host
+            didx, index_build = build_device_index(torch, args.built_docs, args.built_kmeans_iters, dev)
+            shard = index_to_host(didx)
+            del didx
+        else:
+            shard, index_build = build_config2_index(clb, args.built_docs, args.built_kmeans_iters, local_rank)
         K = int(shard["centroids"].shape[1])
         n_docs_total = args.built_docs
     else:
@@ -739,8 +802,13 @@ def main():
                "gpu_matches_cpu_top_k": ok}
 
     # ---- N = 1 sub-records: the batch sizes the N-GPU runs use, the worst-case code distribution, and BASELINE config 2
-    batch_sweep = worst = built = None
+    batch_sweep = worst = built = built_1m = None
     device_bytes = s.device_bytes
+    if world > 1 and not args.no_index_build and not args.built_index:
+        try:
+            index_build = sharded_index_build(torch, dist, rank, world, args.docs, args.built_kmeans_iters, dev)
+        except Exception as e:      # the search figures of the line stand on their own
+            index_build = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_sub and not args.force_gather:
         batch_sweep = {}
         for Bs in (64, 128, 256):
@@ -783,6 +851,30 @@ def main():
             built["index_build"] = brec
             sb.close()
             del bidx
+        n_built_1m = args.built_1m_docs or (1_000_000 if args.docs >= 1_000_000 else 0)
+        if not args.built_index and not args.no_built_1m and n_built_1m > 0:
+            # the headline corpus SIZE through this repo's own build: K = 131 072 k-means on the reference-sized sample,
+            # 80 M embeddings compressed, IVF over 80 M codes -- all in HBM -- then searched like the other workloads
+            from colbert_jl_amd.indexer import index_to_host
+            didx, drec = build_device_index(torch, n_built_1m, args.built_kmeans_iters, dev)
+            t0 = time.time()
+            sd = clb.Searcher(index=didx)
+            torch.cuda.synchronize()
+            drec["searcher_from_device_arrays_s"] = round(time.time() - t0, 2)
+            hidx = index_to_host(didx)
+            del didx
+            if args.mode >= 0:
+                sd.set_mode(args.mode)
+            Qd = synthetic.make_queries(hidx, seed=79, n_queries=256, T=T)
+            built_1m = measure_sub(torch, clb, sd, hidx, Qd, 32, k, args.nprobe, args.steps, 0.4,
+                                   0 if args.no_cpu else 8, dev, in_flight=NF, T=T)
+            built_1m["workload"] = (f"synthetic {n_built_1m} passages of 4096-component mixture embeddings (dim 128, doclen~80) indexed by "
+                                    f"this repo's own device-resident build (k-means K={drec['K']} on {drec['sample_points']} sample points, "
+                                    f"nbits 2), top-{k}, nprobe {args.nprobe}, batch 32; queries = noisy decompressed passage tokens")
+            built_1m["pass1_gather"] = {"form": ["vgpr", "lds-dma"][sd.pass1_gather[0]], "code_adjacency": round(sd.pass1_gather[1], 4)}
+            built_1m["index_build"] = drec
+            sd.close()
+            del hidx
 
     if rank == 0:
         out = {"metric": "queries/sec, top-1000 on 1M-passage corpus", "value": round(qps, 2), "unit": "queries/s",
@@ -808,7 +900,7 @@ def main():
                "end_to_end_with_query_encoder": e2e,
                "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4),
                "p50_latency_graph_replay_ms": None if p50_graph_ms is None else round(p50_graph_ms, 4), "roofline": roof, "cpu_baseline": cpu,
-               "worst_case_uniform_codes": worst, "built_index": built, "batch_sweep": batch_sweep,
+               "worst_case_uniform_codes": worst, "built_index": built, "built_index_1M": built_1m, "batch_sweep": batch_sweep,
                "fixed_batch_32": fixed32, "single_exchange": single_exchange, "index_build": index_build,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
                "hbm_bytes": device_bytes}

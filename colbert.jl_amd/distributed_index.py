@@ -138,3 +138,155 @@ def build_index_sharded(local_embs, local_doclens, local_sample, heldout, init_c
     return {"dim": dim, "nbits": nbits, "centroids": centroids, "bucket_cutoffs": cutoffs, "bucket_weights": weights,
             "avg_residual": avg, "doclens": np.asarray(local_doclens, dtype=np.int64), "codes": codes,
             "residuals": residuals, "ivf": ivf, "ivf_lengths": ivf_lengths, "kmeans_iters": iters}
+
+
+def index_device_sharded(source, pid_lo: int, n_docs_total: int, backend=None, nbits: int = 2, kmeans_niters: int = 20,
+                         seed: int = 0, group=None, all_gather=None, chunksize=None, log=None, keep=None):
+    """One rank's part of index() (src/indexing.jl:63-147) for a collection sharded by contiguous passage ranges, with
+    every large array resident in HBM (BASELINE config 5: the fp32 embeddings of a 1.25 M-passage shard are 51 GB and
+    exist only chunk by chunk).  `source` (indexer.DeviceEmbeddingSource) yields THIS rank's passages -- local ids
+    0..n_local-1 are the global passages pid_lo..pid_lo+n_local-1 of `n_docs_total`.
+
+      sample   the reference's rule over the WHOLE collection (collection_indexer.jl:17-24), drawn identically on every
+               rank; a rank gathers the sampled passages of its own range.  Shuffled per rank; the held-out set
+               (collection_indexer.jl:81-91: min(5 %, 50 000) of all sample embeddings) is the tail of rank 0's part.
+      setup    K from the global estimate (all-reduce of the sample counts), collection_indexer.jl:115-139.
+      init     every rank contributes ceil(K / world) of its sample points, all-gathered in rank order (utils.jl:261
+               draws K random points of the sample).
+      k-means  kmeans_sharded: shard handle over the rank's device points, one all-gather per iteration.
+      stats    rank 0, broadcast.   compress + IVF: per shard (resident codec, device IVF), no exchange.
+
+    Returns (index, record): `index` is what Searcher(index=..., pid_offset=pid_lo) takes (CUDA tensors + host lengths).
+    `keep` (a dict, tests only) receives this rank's clustering sample and the initial centroids."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from . import codec
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = backend or HipBackend(source.device.index)
+    dev = source.device
+    doclens = np.ascontiguousarray(source.doclens, dtype=np.int64)
+    n_local, dim = doclens.size, source.dim
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    n_emb = int(off[-1])
+    rec = {"rank": rank, "world": world, "passages_total": int(n_docs_total), "passages_local": int(n_local),
+           "embeddings_local": n_emb}
+
+    def tick(name, t0):
+        torch.cuda.synchronize(dev)
+        rec[name] = round(time.time() - t0, 3)
+        if log:
+            log(f"index_device_sharded[{rank}]: {name} {rec[name]} s")
+
+    # RCCL moves device tensors; under gloo (tests: several ranks on one GPU, CPU rehearsals) the same exchanges are
+    # staged through host memory
+    staged = dist.get_backend(group) != "nccl"
+    cdev = torch.device("cpu") if staged else dev
+
+    def all_sum(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return [int(v) for v in t.tolist()]
+
+    def gather_rows(t):
+        """contiguous (n, ...) device tensor -> (world, n, ...) device tensor, rank order"""
+        src_t = t.contiguous().to(cdev)
+        out = torch.empty((world,) + tuple(src_t.shape), dtype=src_t.dtype, device=cdev)
+        dist.all_gather_into_tensor(out.view(-1), src_t.view(-1), group=group)
+        return out.to(dev)
+
+    if all_gather is None and staged:
+        all_gather = gather_rows
+
+    # sample
+    t0 = time.time()
+    rng = np.random.default_rng(seed)
+    sampled = np.unique(rng.integers(0, n_docs_total, size=codec.num_sampled_pids(n_docs_total)))
+    mine = sampled[(sampled >= pid_lo) & (sampled < pid_lo + n_local)] - pid_lo
+    n_sample = int(doclens[mine].sum())
+    step = int(chunksize or min(25000, 1 + n_docs_total // world))
+    sample = torch.empty((n_sample, dim), dtype=torch.float32, device=dev)
+    fill = 0
+    for start in range(0, n_local, step):
+        end = min(n_local, start + step)
+        m = mine[(mine >= start) & (mine < end)]
+        if m.size == 0:
+            continue
+        x = source.chunk(start, end)
+        rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in m])
+        sample[fill:fill + rows.size] = x[torch.from_numpy(rows).to(dev)]
+        fill += rows.size
+        del x
+    assert fill == n_sample
+    lrng = np.random.default_rng([seed, rank + 1])
+    sample = sample[torch.from_numpy(lrng.permutation(n_sample)).to(dev)]
+    tot_sample, tot_sampled_docs = all_sum([n_sample, int(mine.size)])
+    h = codec.heldout_size(tot_sample)
+    heldout = None
+    if rank == 0:
+        assert n_sample > h, "rank 0 holds fewer sample embeddings than the held-out set"
+        heldout = sample[n_sample - h:]
+        sample = sample[:n_sample - h]
+    avg_doclen_est = float(np.float32(tot_sample / max(tot_sampled_docs, 1)))
+    plan = codec.setup(n_docs_total, avg_doclen_est, tot_sample - h, chunksize, world)
+    K = plan["num_partitions"]
+    per = -(-K // world)
+    assert sample.shape[0] >= per, "a rank holds fewer sample points than its share of the initial centroids"
+    mine_init = sample[:per].contiguous()
+    allinit = gather_rows(mine_init).view(world * per, dim) if world > 1 else mine_init
+    init = np.asfortranarray(allinit[:K].cpu().numpy().T)
+    sample = sample.contiguous()
+    rec.update({"sample_points_local": int(sample.shape[0]), "sample_points_total": int(tot_sample - h), "heldout": int(h),
+                "K": int(K), "chunksize": plan["chunksize"]})
+    tick("sample_and_split_s", t0)
+    if keep is not None:
+        keep["sample"], keep["init"], keep["heldout"] = sample, init, heldout
+
+    # k-means over the process group
+    t0 = time.time()
+    centroids, iters = kmeans_sharded(sample, init, backend, max_iters=kmeans_niters, group=group, comm_device=dev,
+                                      all_gather=all_gather)
+    tick("kmeans_s", t0)
+    rec["kmeans_iters"] = int(iters)
+    rec["kmeans_s_per_iter"] = round(rec["kmeans_s"] / max(iters, 1), 4)
+    rec["kmeans_exchange_bytes_per_rank_per_iter"] = int(dim * K * 4 + K * 8)
+    t0 = time.time()
+    nopt = 1 << nbits
+    stats = np.zeros(2 * nopt, dtype=np.float32)
+    if rank == 0:
+        cut, w, avg = backend.compute_avg_residuals(nbits, centroids, np.asfortranarray(heldout.cpu().numpy().T))
+        stats[:nopt - 1] = cut; stats[nopt - 1:2 * nopt - 1] = w; stats[2 * nopt - 1] = avg
+    t = torch.from_numpy(stats).to(cdev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    stats = t.cpu().numpy()
+    cutoffs, weights, avg = stats[:nopt - 1].copy(), stats[nopt - 1:2 * nopt - 1].copy(), np.float32(stats[2 * nopt - 1])
+    tick("codec_stats_s", t0)
+    del sample, heldout
+
+    # this shard's chunks
+    t0 = time.time()
+    rows_b = dim // 8 * nbits
+    codes = torch.empty(n_emb, dtype=torch.int32, device=dev)
+    residuals = torch.empty((n_emb, rows_b), dtype=torch.uint8, device=dev)
+    cdc = codec.Codec(centroids, cutoffs, dim, nbits, device=dev.index)
+    for start in range(0, n_local, plan["chunksize"]):
+        end = min(n_local, start + plan["chunksize"])
+        x = source.chunk(start, end)
+        a, b = int(off[start]), int(off[end])
+        cdc.compress_device(x, codes[a:b], residuals[a:b])
+        torch.cuda.synchronize(dev)
+        del x
+    cdc.close()
+    tick("chunks_s", t0)
+    rec["compress_Membeddings_per_s"] = round(n_emb / max(rec["chunks_s"], 1e-9) / 1e6, 2)
+    t0 = time.time()
+    ivf, ivf_lengths = codec.build_ivf_device(codes, K)
+    tick("build_ivf_s", t0)
+    rec["total_build_s"] = round(sum(rec[k] for k in ("sample_and_split_s", "kmeans_s", "codec_stats_s", "chunks_s", "build_ivf_s")), 2)
+    cent_dev = torch.from_numpy(np.ascontiguousarray(centroids.T)).to(dev)
+    index = {"dim": dim, "nbits": nbits, "centroids": cent_dev, "bucket_cutoffs": cutoffs, "bucket_weights": weights,
+             "avg_residual": avg, "doclens": doclens, "codes": codes, "residuals": residuals, "ivf": ivf,
+             "ivf_lengths": ivf_lengths.cpu().numpy(), "pid_offset": int(pid_lo), "kmeans_iters": int(iters)}
+    return index, rec

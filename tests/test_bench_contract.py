@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "40000", "--steps", "3", "--warmup", "1",
                           "--no-encoder", "--cpu-seconds", "1", "--min-seconds", "0.05", "--k", "100", "--built-docs", "3000",
-                          "--built-kmeans-iters", "3"],
+                          "--built-kmeans-iters", "3", "--built-1m-docs", "4000"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -45,4 +45,10 @@ def test_bench_line_has_the_contract_fields():
     for key in ("kmeans_s", "kmeans_iters", "codec_stats_s", "compress_s", "build_ivf_s", "kmeans_roofline", "K"):
         assert key in ib, key
     assert b["candidates_per_query"]["passages"] > 0
+    # ... and the device-resident build (at a test size here; 1 M passages in the default run)
+    m = d["built_index_1M"]
+    assert m["value"] > 0 and m["gpu_matches_cpu_top_k"] is True and "frac" in m["roofline"]
+    for key in ("kmeans_s", "kmeans_iters", "codec_stats_s", "compress_s", "build_ivf_s", "kmeans_roofline", "compress_roofline", "K",
+                "sample_points", "total_build_s"):
+        assert key in m["index_build"], key
     assert set(d["batch_sweep"]) == {"64", "128", "256"}

@@ -151,3 +151,60 @@ def test_hip_backend_two_rank_processes_one_gpu(oracle):
         assert np.array_equal(res[r]["codes"], codes) and np.array_equal(res[r]["residuals"], rr)
         ivf, lens = oracle.build_ivf(codes, init.shape[1])
         assert np.array_equal(res[r]["ivf"], ivf) and np.array_equal(res[r]["ivf_lengths"], lens)
+
+
+# ---- the same with every large array resident in HBM (index_device_sharded): the path bench.py --gpus N times ----------
+def _device_worker(rank, world, store, q):
+    import torch
+    import torch.distributed as dist
+    from colbert_jl_amd.distributed_index import index_device_sharded
+    from colbert_jl_amd.indexer import index_to_host
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    n_total, n_local = 2400, 1200
+    src = synthetic.DeviceMixtureSource(seed=90 + rank, n_docs=n_local, device=dev, block=500, n_components=64)
+    keep = {}
+    index, rec = index_device_sharded(src, rank * n_local, n_total, HipBackend(0), nbits=2, kmeans_niters=3, seed=91,
+                                      chunksize=700, keep=keep)
+    host = index_to_host(index)
+    out = {k: host[k] for k in ("centroids", "bucket_cutoffs", "bucket_weights", "codes", "residuals", "ivf", "ivf_lengths",
+                                "kmeans_iters", "pid_offset")}
+    out["sample"] = np.asfortranarray(keep["sample"].cpu().numpy().T)
+    out["init"] = keep["init"]
+    out["heldout"] = None if keep["heldout"] is None else np.asfortranarray(keep["heldout"].cpu().numpy().T)
+    out["embs"] = np.asfortranarray(src.chunk(0, n_local).cpu().numpy().T)
+    out["K"] = rec["K"]
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_index_device_sharded_two_rank_processes_one_gpu(oracle):
+    """Two rank processes on this box's GPU, exchanges staged over gloo: sample rule, init all-gather, device k-means
+    shards, statistics broadcast, resident codec, device IVF.  Against the oracle's sharded restatement, bit for bit."""
+    import torch.multiprocessing as mp
+    store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_device_worker, args=(r, 2, store.name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    K = res[0]["K"]
+    assert K == res[1]["K"] == 4096
+    assert np.array_equal(res[0]["init"], res[1]["init"])                       # identical on every rank
+    per = K // 2
+    assert np.array_equal(res[0]["init"][:, :per], res[0]["sample"][:, :per])   # rank r's share, rank order
+    assert np.array_equal(res[0]["init"][:, per:], res[1]["sample"][:, :per])
+    rc, rit = _oracle_sharded_kmeans(oracle, [res[0]["sample"], res[1]["sample"]], res[0]["init"], 3)
+    rcut, rw, _ravg, _ = oracle.compute_avg_residuals(2, rc, res[0]["heldout"])
+    for r in (0, 1):
+        assert res[r]["pid_offset"] == r * 1200
+        assert res[r]["kmeans_iters"] == rit and np.array_equal(bits(res[r]["centroids"]), bits(rc))
+        assert np.array_equal(bits(res[r]["bucket_cutoffs"]), bits(rcut)) and np.array_equal(bits(res[r]["bucket_weights"]), bits(rw))
+        codes, rr = oracle.compress(rc, rcut, 128, 2, res[r]["embs"])
+        assert np.array_equal(res[r]["codes"], codes) and np.array_equal(res[r]["residuals"], rr)
+        ivf, lens = oracle.build_ivf(codes, K)
+        assert np.array_equal(res[r]["ivf"], ivf) and np.array_equal(res[r]["ivf_lengths"], lens)

@@ -255,6 +255,84 @@ def test_config2_index_build_100k(oracle):
 
 
 # ---------------------------------------------------------------------------------------------------
+# config 5, index-build half: ONE rank's 1/8 share of the 10 M-passage build (K = 262 144, ~5.5 M of the 44 M sample
+# points, 1.25 M passages = 100 M embeddings to compress) through the sharded product path over RCCL (world 1)
+# ---------------------------------------------------------------------------------------------------
+def test_config5_one_rank_share_of_the_index_build(oracle):
+    import os
+    import tempfile
+
+    import torch
+    import torch.distributed as dist
+    from colbert_jl_amd.distributed_index import HipBackend, index_device_sharded
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 60e9:
+        pytest.skip("needs ~40 GB of HBM")
+    dev = torch.device("cuda", 0)
+    n_total, n_local = 10_000_000, 1_250_000
+    src = synthetic.DeviceMixtureSource(seed=71, n_docs=n_local, device=dev)
+    store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
+    dist.init_process_group("nccl", init_method="file://" + store.name, rank=0, world_size=1, device_id=dev)
+    keep = {}
+    try:
+        index, rec = index_device_sharded(src, 0, n_total, HipBackend(0), nbits=2, kmeans_niters=2, seed=72, keep=keep)
+    finally:
+        dist.destroy_process_group()
+    K = rec["K"]
+    assert K == 262144 and rec["kmeans_iters"] == 2 and 5_000_000 < rec["sample_points_local"] < 6_000_000
+    sample, init = keep["sample"], keep["init"]
+    init_t = torch.from_numpy(np.ascontiguousarray(init.T)).to(dev)
+    # (1) the exchange over RCCL changes nothing: the same two iterations without a process group, bit for bit
+    c1, _, sh1 = codec.kmeans_device(sample, init_t, max_iters=1)
+    sh1.close()
+    c2, it2, sh2 = codec.kmeans_device(sample, init_t, max_iters=2)
+    assign = sh2.get_assignments()                      # iteration 2 assigned against c1
+    sh2.close()
+    assert it2 == 2 and torch.equal(c2, index["centroids"])
+    # (2) assignments at K = 262 144 on a sampled subset == the oracle's nearest centroid (k-means distance) against c1
+    rng = np.random.default_rng(73)
+    sel = np.sort(rng.choice(sample.shape[0], size=1500, replace=False))
+    c1_host = np.asfortranarray(c1.cpu().numpy().T)
+    pts = np.asfortranarray(sample[torch.from_numpy(sel).to(dev)].cpu().numpy().T)
+    _s, _c, ra = oracle.kmeans_shard_pass(pts, c1_host)
+    assert np.array_equal(assign[sel], ra)
+    assert assign.min() >= 1 and assign.max() <= K
+    # (3) the update rule (utils.jl:288-306) on sampled clusters, restated: per batch of 1000 points a partial sum of the
+    # members in ascending order, partials added in batch order, divided by max(count, 1); empty clusters -> 0
+    c2_host = c2.cpu().numpy()
+    order = np.argsort(assign, kind="stable")
+    starts = np.searchsorted(assign[order], np.arange(1, K + 2))
+    for j in rng.choice(K, size=60, replace=False):
+        mem = order[starts[j]:starts[j + 1]]
+        x = sample[torch.from_numpy(mem).to(dev)].cpu().numpy() if mem.size else np.zeros((0, 128), np.float32)
+        total = np.zeros(128, dtype=np.float32)
+        for b in np.unique(mem // 1000):
+            part = np.zeros(128, dtype=np.float32)
+            for r in np.nonzero(mem // 1000 == b)[0]:
+                part = part + x[r]
+            total = total + part
+        want = total / np.float32(max(mem.size, 1))
+        same_f32(c2_host[j], want, f"centroid {j} ({mem.size} members)")
+    # (4) compress at K = 262 144: sampled embeddings of sampled chunks == oracle.compress, bytes and codes
+    host_c = np.asfortranarray(c2_host.T)
+    cut = index["bucket_cutoffs"]
+    off = np.concatenate([[0], np.cumsum(src.doclens)])
+    codes = index["codes"]
+    for start in (0, 600_000, 1_225_000):
+        x = src.chunk(start, start + 25_000)
+        pick = np.sort(rng.choice(x.shape[0], size=400, replace=False))
+        xs = np.asfortranarray(x[torch.from_numpy(pick).to(dev)].cpu().numpy().T)
+        rc, rr = oracle.compress(host_c, cut, 128, 2, xs)
+        gidx = torch.from_numpy(pick + off[start]).to(dev)
+        assert np.array_equal(codes[gidx].cpu().numpy().view(np.uint32), rc)
+        assert np.array_equal(index["residuals"][gidx].cpu().numpy().T, rr)
+    # (5) the IVF over all 100 M codes == the oracle's stable sort
+    hc = codes.cpu().numpy().view(np.uint32)
+    rivf, rlens = oracle.build_ivf(hc, K)
+    assert np.array_equal(index["ivf"].cpu().numpy(), rivf) and np.array_equal(index["ivf_lengths"], rlens)
+
+
+# ---------------------------------------------------------------------------------------------------
 # config 5: 10 M passages on one GPU (properties only; the oracle would need minutes per query)
 # ---------------------------------------------------------------------------------------------------
 def test_config5_ten_million_properties():
