@@ -390,9 +390,13 @@ static __global__ void epilogue_mask_kernel(const int32_t* __restrict__ ids, int
 // one thread per token column: D .* mask, normalise, write to its compacted slot (or in place)
 static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, int dim, int L, int N,
                                           const uint8_t* __restrict__ mask, const int64_t* __restrict__ doc_start /*N, exclusive scan of doclens; null = in place*/,
-                                          float* __restrict__ out) {
+                                          float* __restrict__ out, int* __restrict__ err = nullptr /* bit 1: non-finite input row */) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (int64_t)L * N) return;
+    if (err) {
+        const float n2 = sumsq_canonical(D + j * dim, dim);
+        if (!(n2 <= FLT_MAX)) atomicOr(err, 2);
+    }
     const int n = (int)(j / L), l = (int)(j % L);
     const bool keep = mask[j] != 0;
     const float* x = D + j * dim;
@@ -423,7 +427,8 @@ static __global__ void epilogue_normalize_kernel(const float* __restrict__ D, in
 static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const float* __restrict__ D, int dim, int64_t n_tok,
                                                                          const int32_t* __restrict__ ids,
                                                                          const int64_t* __restrict__ skip, int nskip,
-                                                                         float* __restrict__ out) {
+                                                                         float* __restrict__ out,
+                                                                         int* __restrict__ err = nullptr /* bit 1: non-finite row */) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = gid >> 2;
     const int g = (int)(gid & 3);
@@ -442,6 +447,7 @@ static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const 
     const float q = p + __shfl_xor(p, 1, 64);          // lanes 0,1: p0 + p1; lanes 2,3: p2 + p3 (commutative: same bits)
     const float n2 = __shfl(q, (threadIdx.x & 60), 64) + __shfl(q, (threadIdx.x & 60) + 2, 64);   // (p0 + p1) + (p2 + p3)
     if (!live) return;
+    if (err && g == 0 && !(n2 <= FLT_MAX)) atomicOr(err, 2);      // NaN / Inf somewhere in the encoder (f16 split range)
     float* o = out + jj * dim + g;
     if (!keep) {
         // D .* mask zeroes the column (-0.0 for negative entries); 0/(0+eps) keeps it

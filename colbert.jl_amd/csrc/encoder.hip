@@ -20,13 +20,20 @@ struct clb_encoder {
     DevBuf weights;
     int attention_mode = 0;     // 0 = fused (register-resident up to 64 keys, online softmax beyond), 1 = register-resident
                                 // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64)
-    int gemm_mode = 2;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6 (bf16 MFMA products of split operands)
+    int gemm_mode = 3;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6, 3 = f16x3 (MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
     // per-layer relative offsets
     int64_t r_wqkv = 0, r_bqkv = 0, r_wo = 0, r_bo = 0, r_g1 = 0, r_b1n = 0, r_w1 = 0, r_b1 = 0, r_w2 = 0, r_b2 = 0, r_g2 = 0, r_b2n = 0;
+    // Linear weights as bf16 planes (split once at create: plane q of blob element o_layer0 + j at wplanes + q * wp_plane + j)
+    DevBuf wplanes;
+    int64_t wp_plane = 0;
+    int wp_fmt = 0;             // PF_* format the weight planes currently hold (re-split when the GEMM mode changes)
+    std::vector<float> wscale;  // PF_F16X2: the power of two every weight matrix was multiplied by (4 per layer + projection)
+    bool planes = false;        // the Linear layers read pre-split bf16 planes (gemm_planes_kernel); COLBERT_ENCODER_PLANES=0: off
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part;
+    DevBuf xp, ctxp, tmpp, hbp; // bf16 planes of the activations the Linear layers read (written by their producers)
     // per-stage HIP-event timing (clb_encoder_profile_*): off in timed runs
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[8];
@@ -167,6 +174,109 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
     return false;
 }
 
+// ---- Linear layers on pre-split bf16 planes (gemm_planes_kernel) ----------------------------------------------------
+struct PlanCfg { int bm, bn, stages, ks; };
+enum LinRole { LR_QKV = 0, LR_ATTN_OUT, LR_FFN_IN, LR_FFN_OUT, LR_PROJ, LR_COUNT };
+// COLBERT_ENC_PLAN="qkv=64x128x3x1,attn_out=64x64x3x4,...": tile / ring depth / K split per Linear role (tuning runs)
+static const PlanCfg* plan_override(int role) {
+    static PlanCfg cfg[LR_COUNT];
+    static bool have[LR_COUNT] = {false, false, false, false, false};
+    static const bool parsed = [] {
+        const char* v = getenv("COLBERT_ENC_PLAN");
+        if (!v) return true;
+        static const char* names[LR_COUNT] = {"qkv", "attn_out", "ffn_in", "ffn_out", "proj"};
+        std::string sv(v);
+        size_t pos = 0;
+        while (pos < sv.size()) {
+            size_t end = sv.find(',', pos);
+            if (end == std::string::npos) end = sv.size();
+            const std::string item = sv.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos)
+                for (int r = 0; r < LR_COUNT; ++r)
+                    if (item.substr(0, eq) == names[r]) {
+                        PlanCfg c{0, 0, 0, 0};
+                        if (sscanf(item.c_str() + eq + 1, "%dx%dx%dx%d", &c.bm, &c.bn, &c.stages, &c.ks) == 4) { cfg[r] = c; have[r] = true; }
+                    }
+            pos = end + 1;
+        }
+        return true;
+    }();
+    (void)parsed;
+    return have[role] ? &cfg[role] : nullptr;
+}
+
+template <int NS, bool F16>
+bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
+    const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
+    const size_t lds = (size_t)c.stages * NS * (c.bm + c.bn) * 64;
+#define CLB_GP_CASE(BM_, BN_, ST_, WM_, WN_)                                                                          \
+    if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
+        if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(gemm_planes_kernel<2, 2, WM_, WN_, NS, ST_, 0, F16>), (int)lds); \
+        hipLaunchKernelGGL((gemm_planes_kernel<2, 2, WM_, WN_, NS, ST_, 0, F16>), grid, dim3(256), lds, st, g);       \
+        return true;                                                                                                  \
+    }
+    CLB_GP_CASE(64, 64, 2, 1, 1) CLB_GP_CASE(64, 64, 3, 1, 1) CLB_GP_CASE(64, 64, 4, 1, 1)
+    CLB_GP_CASE(64, 128, 2, 1, 2) CLB_GP_CASE(64, 128, 3, 1, 2)
+    CLB_GP_CASE(128, 64, 2, 2, 1) CLB_GP_CASE(128, 64, 3, 2, 1)
+    CLB_GP_CASE(128, 128, 2, 2, 2) CLB_GP_CASE(128, 128, 3, 2, 2)
+#undef CLB_GP_CASE
+    return false;
+}
+
+// A planes (M x K) . W planes (N x K)^T -> C fp32 and / or Cp planes, epilogue bias / GELU / residual, optional LayerNorm
+// of the output (then both C and, if given, Cp hold the normalised rows).  part: split-K scratch (8 * M * N floats) or null.
+inline int plane_format(int gemm_mode) { return gemm_mode == 3 ? PF_F16X2 : gemm_mode == 1 ? PF_BF16X2 : PF_BF16X3; }
+
+// wscale: the power of two the weight planes were scaled by (PF_F16X2; 1 otherwise)
+void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, float wscale,
+                   float* C, uint16_t* Cp, int64_t c_plane, const float* bias, const float* R, int M, int N, int K, int epi,
+                   float* part, const LnArgs* ln) {
+    const int fmt = plane_format(e->gemm_mode);
+    const int NS = fmt == PF_BF16X3 ? 3 : 2;
+    const float out_scale = fmt == PF_F16X2 ? 1.0f / (kF16ActScale * wscale) : 1.0f;
+    auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm); };
+    PlanCfg c;
+    if (const PlanCfg* o = plan_override(role)) c = *o;
+    else if (wgs(128, 128) >= 1024) c = {128, 128, 2, 1};          // long activations (passage batches)
+    else {
+        // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured
+        // (tools/microbench/gemm_planes_bench.hip): the loop is bound by MFMA issue (three 32 x 32 tiles per SIMD at the
+        // ~1.75 GHz the chip holds) and by the ~65 GB/s an XCD's L2 delivers to one CU, both ~20 us for the 1024 x 2304 x 768
+        // product; larger tiles move fewer bytes but leave CUs without a work-group, deeper rings cost the third resident
+        // work-group.  Narrow outputs (N = hidden) are split over K until every CU has three work-groups.
+        c = {64, 64, 2, 1};
+        if (part) {
+            const int min_slice = wgs(64, 64) < 64 ? 192 : 256;
+            while (c.ks < 8 && wgs(64, 64) * c.ks < 512 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= min_slice) c.ks *= 2;
+        }
+    }
+    if (!part || K % (c.ks * 32) != 0) c.ks = 1;
+    GemmPArgs g{Ap, Wp, a_plane, e->wp_plane, C, bias, R, Cp, c_plane, M, N, K, N, epi, c.ks, out_scale};
+    // an output that is normalised next keeps its planes for the LayerNorm kernel to write
+    if (ln) g.Cp = nullptr;
+    if (c.ks > 1) { g.C = part; g.Cp = nullptr; }
+    auto go = [&](const PlanCfg& cc) {
+        return fmt == PF_F16X2 ? launch_planes<2, true>(st, cc, g) : NS == 2 ? launch_planes<2, false>(st, cc, g) : launch_planes<3, false>(st, cc, g);
+    };
+    if (!go(c)) { c = {64, 64, 2, c.ks}; (void)go(c); }
+    if (c.ks > 1) {
+        if (ln && N <= 1024) {
+            if (N <= 768)
+                hipLaunchKernelGGL(gemm_splitk_reduce_ln_kernel<3>, dim3(M), dim3(256), 0, st, part, c.ks, (int64_t)M, N, C, bias, R,
+                                   out_scale, epi, ln->gamma, ln->beta, ln->eps, Cp, c_plane, fmt);
+            else
+                hipLaunchKernelGGL(gemm_splitk_reduce_ln_kernel<4>, dim3(M), dim3(256), 0, st, part, c.ks, (int64_t)M, N, C, bias, R,
+                                   out_scale, epi, ln->gamma, ln->beta, ln->eps, Cp, c_plane, fmt);
+            return;
+        }
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, c.ks, (int64_t)M, N,
+                           C, bias, R, out_scale, epi, ln ? (uint16_t*)nullptr : Cp, c_plane, fmt);
+    }
+    if (ln) hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, st, C, (int64_t)M, N, ln->gamma, ln->beta,
+                               ln->eps, Cp, c_plane, fmt);
+}
+
 // Linear (+ optional LayerNorm of the output, in place)
 void linear(clb_encoder* e, hipStream_t st, const float* A, const float* Wt, float* C, const float* bias, const float* R,
             int M, int N, int K, int epi, float* part, const LnArgs* ln = nullptr) {
@@ -179,6 +289,50 @@ void linear(clb_encoder* e, hipStream_t st, const float* A, const float* Wt, flo
         if (done) return;
     }
     if (ln) hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, st, C, (int64_t)M, N, ln->gamma, ln->beta, ln->eps);
+}
+
+// Every Linear weight (N x K, torch layout) into K-blocked planes of format `fmt` at its own blob offset.  PF_F16X2: each
+// matrix is first scaled by the power of two that brings its largest |entry| into [2^13, 2^14) (exact; the GEMM epilogue
+// divides it out again) -- fp16 carries 5 exponent bits, and an unscaled N(0, 0.02) weight would leave its low plane in the
+// subnormals.
+int split_weights(clb_encoder* e, int fmt) {
+    const int64_t H = e->H, I = e->I, n_lin = e->wp_plane;
+    struct Mat { int64_t off, rows, cols; };
+    std::vector<Mat> mats;
+    for (int64_t l = 0; l < e->layers; ++l) {
+        const int64_t lo = e->o_layer0 + l * e->layer_stride;
+        mats.push_back({lo + e->r_wqkv, 3 * H, H}); mats.push_back({lo + e->r_wo, H, H});
+        mats.push_back({lo + e->r_w1, I, H}); mats.push_back({lo + e->r_w2, H, I});
+    }
+    mats.push_back({e->o_lin_w, e->dim, H});
+    e->wscale.assign(e->layers * 4 + 4, 1.0f);
+    hipStream_t st = e->stream;
+    if (fmt == PF_F16X2) {
+        DevBuf mx;
+        CLB_TRY(mx.alloc(sizeof(unsigned int) * mats.size()));
+        CLB_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned int) * mats.size(), st));
+        for (size_t i = 0; i < mats.size(); ++i)
+            hipLaunchKernelGGL(max_abs_kernel, dim3(256), dim3(256), 0, st, e->weights.as<float>() + mats[i].off,
+                               (int)(mats[i].rows * mats[i].cols), mx.as<unsigned int>() + i);
+        std::vector<unsigned int> bits(mats.size());
+        CLB_HIP(hipMemcpyAsync(bits.data(), mx.p, sizeof(unsigned int) * mats.size(), hipMemcpyDeviceToHost, st));
+        CLB_HIP(hipStreamSynchronize(st));
+        for (size_t i = 0; i < mats.size(); ++i) {
+            float m;
+            memcpy(&m, &bits[i], sizeof m);
+            int ex = 0;
+            if (m > 0.f && m <= FLT_MAX) (void)std::frexp(m, &ex);          // m = f * 2^ex, f in [0.5, 1)
+            e->wscale[i] = std::ldexp(1.0f, std::max(-100, std::min(100, 14 - ex)));   // m * scale in [2^13, 2^14)
+        }
+    }
+    for (size_t i = 0; i < mats.size(); ++i)
+        hipLaunchKernelGGL(split_planes_kernel, dim3(blocks_for(mats[i].rows * mats[i].cols / 4)), dim3(256), 0, st,
+                           e->weights.as<float>() + mats[i].off, e->wplanes.as<uint16_t>() + (mats[i].off - e->o_layer0), mats[i].rows,
+                           (int)mats[i].cols, n_lin, fmt, e->wscale[i]);
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipStreamSynchronize(st));
+    e->wp_fmt = fmt;
+    return CLB_OK;
 }
 
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
@@ -195,16 +349,35 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     CLB_TRY(e->hbuf.ensure(sizeof(float) * T * I));
     CLB_TRY(e->tmp.ensure(sizeof(float) * T * H));
     CLB_TRY(e->out.ensure(sizeof(float) * T * e->dim));
+    // the Linear layers read bf16 planes: activations are split once, by their producer (three planes are always written;
+    // bf16x3 reads the first two)
+    const bool P = e->planes && e->gemm_mode != 0 && H % 32 == 0 && I % 32 == 0 && T * std::max(H, I) * 6 < ((int64_t)1 << 31);
+    const int64_t hp = T * H, ip = T * I;      // plane strides of the activation planes
+    if (P) {
+        CLB_TRY(e->xp.ensure(sizeof(uint16_t) * 3 * hp));
+        CLB_TRY(e->ctxp.ensure(sizeof(uint16_t) * 3 * hp));
+        CLB_TRY(e->tmpp.ensure(sizeof(uint16_t) * 3 * hp));
+        CLB_TRY(e->hbp.ensure(sizeof(uint16_t) * 3 * ip));
+    }
+    const int PF = plane_format(e->gemm_mode);
+    if (P && e->wp_fmt != PF) CLB_TRY(split_weights(e, PF));
+    uint16_t* xp = e->xp.as<uint16_t>(); uint16_t* ctxp = e->ctxp.as<uint16_t>();
+    uint16_t* tmpp = e->tmpp.as<uint16_t>(); uint16_t* hbp = e->hbp.as<uint16_t>();
+    const uint16_t* WP = e->wplanes.as<uint16_t>();
+    auto wp = [&](int64_t blob_off) { return WP + (blob_off - e->o_layer0); };
+    auto ws = [&](int64_t layer, int which) { return e->wscale.empty() ? 1.0f : e->wscale[(size_t)(layer * 4 + which)]; };
     const bool short_batch = T <= 4096;         // split-K scratch only where it can be used (query batches)
     if (short_batch) CLB_TRY(e->part.ensure(sizeof(float) * 8 * T * H));
     float* part = short_batch ? e->part.as<float>() : nullptr;
-    CLB_TRY(e->err.ensure(sizeof(int)));
-    CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
+    if (!e->err.p) {      // the flag is STICKY: set by any encode since the last check, cleared by whoever reads it
+        CLB_TRY(e->err.ensure(sizeof(int)));
+        CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
+    }
     {
         EncTimed tm(e, ES_EMBED, st);
         hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, d_ids, T, (int)L,
                            (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
-                           e->x.as<float>(), e->err.as<int>());
+                           e->x.as<float>(), e->err.as<int>(), P ? xp : (uint16_t*)nullptr, hp, PF);
     }
     float* x = e->x.as<float>();
     float* qkv = e->qkv.as<float>();
@@ -214,17 +387,21 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     float* tmp = e->tmp.as<float>();
     const float inv_sqrt = 1.0f / std::sqrt((float)dh);
     for (int64_t l = 0; l < e->layers; ++l) {
-        const float* P = W + e->o_layer0 + l * e->layer_stride;
+        const float* P_ = W + e->o_layer0 + l * e->layer_stride;
         // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
+        const int64_t lo = e->o_layer0 + l * e->layer_stride;       // blob offset of this layer's parameters
         { EncTimed tm(e, ES_QKV, st);
-        linear(e, st, x, P + e->r_wqkv, qkv, P + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
+        if (P) linear_planes(e, st, LR_QKV, xp, hp, wp(lo + e->r_wqkv), ws(l, 0), qkv, nullptr, 0, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H),
+                             (int)H, EPI_BIAS, nullptr, nullptr);
+        else linear(e, st, x, P_ + e->r_wqkv, qkv, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
         EncTimed* t_att = new EncTimed(e, ES_ATTENTION, st);
         if (fused) {
             // softmax(Q K^T / sqrt(dh) + mask) V, one wave per (sequence, head, 32 queries), scores never leave registers
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
-#define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt)
+            uint16_t* cp_ = P ? ctxp : nullptr;
+#define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
             if (L > 64 && e->attention_mode != 1)
-                hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt);
+                hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF);
             else if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
             else if (L <= 256) CLB_ATT(8); else if (L <= 320) CLB_ATT(10); else if (L <= 384) CLB_ATT(12); else CLB_ATT(16);
 #undef CLB_ATT
@@ -237,27 +414,38 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             // context[n, head] = P V   (B(k = key, n = dim) = V[key][dim]: ldb_k = 3H, ldb_n = 1)
             gemm(st, sc, qkv + 2 * H, ctx, nullptr, nullptr, (int)L, (int)dh, (int)L, L, 1, 3 * H, H, 0, 1.0f, (int)N, (int)heads,
                  heads * L * L, L * L, L * 3 * H, dh, L * H, dh);
+            if (P) hipLaunchKernelGGL(split_planes_kernel, dim3(blocks_for(hp / 4)), dim3(256), 0, st, ctx, ctxp, T, (int)H, hp, PF, kF16ActScale);
         }
         delete t_att;
         // attention output + residual, LayerNorm
-        const LnArgs ln1{P + e->r_g1, P + e->r_b1n, e->eps}, ln2{P + e->r_g2, P + e->r_b2n, e->eps};
+        const LnArgs ln1{P_ + e->r_g1, P_ + e->r_b1n, e->eps}, ln2{P_ + e->r_g2, P_ + e->r_b2n, e->eps};
         { EncTimed tm(e, ES_ATTN_OUT, st);
-        linear(e, st, ctx, P + e->r_wo, tmp, P + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1); }
-        // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm
+        if (P) linear_planes(e, st, LR_ATTN_OUT, ctxp, hp, wp(lo + e->r_wo), ws(l, 1), tmp, tmpp, hp, P_ + e->r_bo, x, (int)T, (int)H, (int)H,
+                             EPI_BIAS | EPI_RESID, part, &ln1);
+        else linear(e, st, ctx, P_ + e->r_wo, tmp, P_ + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1); }
+        // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm.  On the plane path the (T x I) intermediate
+        // exists only as the bf16 planes the second Linear reads
         { EncTimed tm(e, ES_FFN_IN, st);
-        linear(e, st, tmp, P + e->r_w1, hb, P + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr); }
+        if (P) linear_planes(e, st, LR_FFN_IN, tmpp, hp, wp(lo + e->r_w1), ws(l, 2), nullptr, hbp, ip, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H,
+                             EPI_BIAS | EPI_GELU, nullptr, nullptr);
+        else linear(e, st, tmp, P_ + e->r_w1, hb, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr); }
         { EncTimed tm(e, ES_FFN_OUT, st);
-        linear(e, st, hb, P + e->r_w2, x, P + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2); }
+        if (P) linear_planes(e, st, LR_FFN_OUT, hbp, ip, wp(lo + e->r_w2), ws(l, 3), x, xp, hp, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I,
+                             EPI_BIAS | EPI_RESID, part, &ln2);
+        else linear(e, st, hb, P_ + e->r_w2, x, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2); }
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
     { EncTimed tm(e, ES_PROJECTION, st);
-    linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part); }
+    if (P) linear_planes(e, st, LR_PROJ, xp, hp, wp(e->o_lin_w), ws(e->layers, 0), e->out.as<float>(), nullptr, 0, W + e->o_lin_b, nullptr, (int)T,
+                         (int)e->dim, (int)H, EPI_BIAS, part, nullptr);
+    else linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part); }
     CLB_HIP(hipGetLastError());
     if (!sync) return CLB_OK;
     int herr = 0;
     CLB_HIP(hipMemcpyAsync(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
     CLB_HIP(hipStreamSynchronize(st));
-    if (herr) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    if (herr & 1) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
     return CLB_OK;
 }
 
@@ -325,6 +513,19 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
         clb_encoder_destroy(e);
         return rc ? rc : fail(CLB_EHIP, "weight upload failed");
     }
+    {   // the Linear weights as bf16 planes, split ONCE (the region from the first layer to the end of the blob: biases and
+        // LayerNorm parameters ride along unused).  1.5x the bytes of the fp32 region.
+        const char* v = getenv("COLBERT_ENCODER_PLANES");
+        const int64_t n_lin = n_weights - e->o_layer0;
+        e->planes = (!v || atoi(v) != 0) && H % 32 == 0 && I % 32 == 0 && e->o_layer0 % 4 == 0 && n_lin * 6 < ((int64_t)1 << 31);
+        if (e->planes) {
+            e->wp_plane = n_lin;
+            if ((rc = e->wplanes.alloc(sizeof(uint16_t) * 3 * n_lin)) || (rc = split_weights(e, plane_format(e->gemm_mode)))) {
+                clb_encoder_destroy(e);
+                return rc;
+            }
+        }
+    }
     *out = e;
     return CLB_OK;
 }
@@ -341,7 +542,7 @@ int clb_encoder_destroy(clb_encoder* e) {
 
 int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
-    if (mode < 0 || mode > 2) return fail(CLB_EARGUMENT, "gemm mode %d: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6", mode);
+    if (mode < 0 || mode > 3) return fail(CLB_EARGUMENT, "gemm mode %d: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = f16x3", mode);
     e->gemm_mode = mode;
     return CLB_OK;
 }
@@ -422,7 +623,7 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
         EncTimed tm(e, ES_EPILOGUE, st);
         if (e->dim % 4 == 0)
             hipLaunchKernelGGL(epilogue_query_fused_kernel, dim3(blocks_for(L * N * 4, 256)), dim3(256), 0, st, e->out.as<float>(),
-                               (int)e->dim, (int64_t)(L * N), d_integer_ids, d_skiplist, (int)n_skip, d_out);
+                               (int)e->dim, (int64_t)(L * N), d_integer_ids, d_skiplist, (int)n_skip, d_out, e->err.as<int>());
         else {
             hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N,
                                d_skiplist, (int)n_skip, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>());
@@ -441,7 +642,10 @@ int clb_encoder_check_last_ids(clb_encoder* e) {
     int herr = 0;
     CLB_HIP(hipDeviceSynchronize());                  // the asynchronous encode may run on any of the caller's streams
     CLB_HIP(hipMemcpy(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (herr) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    CLB_HIP(hipMemset(e->err.p, 0, sizeof(int)));     // sticky until read: covers EVERY encode since the previous check
+    if (herr & 1) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    if (herr & 2) return fail(CLB_EDOMAIN, "non-finite encoder output (an activation outside the range of the f16 operand split? "
+                                           "clb_encoder_set_gemm_mode(e, 2) selects the bf16x6 split)");
     return CLB_OK;
 }
 

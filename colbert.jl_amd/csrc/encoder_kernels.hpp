@@ -439,11 +439,286 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16split_kernel(G
         }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Round 4: the same split products with the operand split taken OUT of the GEMM.  PMC of the kernel above on a query
+// batch: 224 VALU + 24 MFMA instructions per 32-deep step and wave, matrix pipe 20 % busy -- every work-group re-split the
+// activation rows it shares with the N / BN other work-groups of its tile row, and the static weights were re-split on
+// every call.  Here both operands arrive as 16-bit PLANES: the weights are split once at clb_encoder_create (and again
+// when the GEMM mode changes), an activation is split once by the kernel that PRODUCES it (LayerNorm, GELU epilogue,
+// attention output: 2-byte stores per plane instead of one 4-byte store), and the GEMM's loader does no arithmetic at all:
+// every 16 rows x 64 bytes of a plane go global -> LDS with ONE global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no ds_write),
+// the lane -> chunk map of the instruction producing the swizzled LDS image of the kernel above (16-byte chunk c of row r
+// at position c ^ ((r >> 2) & 3)).  A ring of STAGES tile buffers, one barrier per step: step k waits for its own DMAs
+// (s_waitcnt vmcnt(DPW * (STAGES - 2)): vector memory operations complete in order), meets the barrier -- every wave has
+// then left buffer (k - 1) % STAGES -- and refills that buffer with tile k + STAGES - 1 before its MFMAs.  The DMAs are
+// hand-issued (inline asm): behind the builtin hipcc places s_waitcnt vmcnt(0) in front of every LDS read that may alias
+// DMA-written memory, which would serialise the ring.  (The asm writes M0 without declaring it: hipcc rejects M0 in a
+// clobber list as a reserved register, and nothing here keeps a value in M0 across a statement.)
+// bf16 planes: the same products in the same order as the kernel above -- for equal tiles and K slices the results are
+// bit-identical.  Output: fp32 C (bias / GELU / residual epilogue, or raw split-K partial sums) and / or the planes of the
+// epilogue's result (Cp: the FFN intermediate is only ever read as planes and never exists in fp32).
+// -------------------------------------------------------------------------------------------------------------
+struct GemmPArgs {
+    const uint16_t* A; const uint16_t* B;      // plane 0 of each operand, K-BLOCKED (see plane_index)
+    int64_t a_plane, b_plane;                  // plane strides (elements)
+    float* C; const float* bias; const float* R;
+    uint16_t* Cp; int64_t c_plane;             // optional planes of the output, K-blocked with M rows (the next Linear's A)
+    int M, N, K;
+    int64_t ldc;
+    int epi;
+    int ksplit;                                // > 1: blockIdx.z = K slice; raw partial sums go to C + z*M*ldc
+    float out_scale;                           // multiplies the accumulator first (PF_F16X2: the inverse operand scales; else 1)
+};
+
+// Plane layout, K-BLOCKED: element (row, k) of a (rows x K) operand sits at (k / 32) * rows * 32 + row * 32 + k % 32 --
+// the 64-byte row pieces one 32-deep GEMM step needs from a tile's rows are CONTIGUOUS (a 64-row tile = one 4-KB run, every
+// request a whole 128-byte line).  With plain row-major planes the same pieces are rows * K * 2 bytes apart: at K = 768 the
+// stride is 1 536 B, at K = 3 072 it is 6 144 B, and the requests of a step pile onto a half / an eighth of an XCD's L2
+// channels -- the first plane kernel of this round ran the query GEMMs at 4 TB/s of L2 traffic, no faster than the
+// kernel it replaces.
+__device__ __host__ __forceinline__ int64_t plane_index(int64_t row, int64_t k, int64_t rows) {
+    return (k >> 5) * rows * 32 + row * 32 + (k & 31);
+}
+
+// x = p0 + p1 + p2 with p0 = RN_bf16(x), p1 = RN_bf16(x - p0), p2 = RN_bf16(x - p0 - p1): the split of split_store4
+__device__ __forceinline__ void split3_bf16(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
+    const uint32_t h = cvt_pk_bf16(x, 0.f) & 0xffffu;
+    const float r = x - __uint_as_float(h << 16);
+    const uint32_t l = cvt_pk_bf16(r, 0.f) & 0xffffu;
+    const uint32_t t = cvt_pk_bf16(r - __uint_as_float(l << 16), 0.f) & 0xffffu;
+    p0 = (uint16_t)h; p1 = (uint16_t)l; p2 = (uint16_t)t;
+}
+// Plane formats.  PF_BF16X2 / PF_BF16X3: two / three bf16 planes (bf16x3 / bf16x6 products).  PF_F16X2 (round 4): TWO fp16
+// planes of x * scale -- h = RN_f16(x s), l = RN_f16(x s - h): round-to-nearest leaves |x s - h| <= 2^-12 |x s| and
+// |x s - h - l| <= 2^-24 |x s|, i.e. two fp16 planes hold a whole fp32 significand (24 bits; the sign of l is the extra
+// bit), so THREE products  al bh + ah bl + ah bh  (each exact in the fp32 accumulator, smallest first) reproduce the
+// fp32 product to 2^-24 |a||b| -- what bf16x6 needs six products and three planes per operand for.  What fp16 lacks is
+// exponent range: values are scaled by powers of two (exact) so that they sit well inside it -- activations by 2^4
+// (|x| < 4 094 representable; below |x| = 2^-7 the low plane is an fp16 subnormal and the absolute error is 2^-29, the
+// rounding fp32 itself applies to a value of 2^-5; the MFMA multiplies subnormal inputs exactly,
+// tools/microbench/mfma_f16_denorm.hip), every weight matrix by the power of two that brings its largest entry to
+// [2^13, 2^14); the epilogue multiplies the accumulator by the product of the inverse scales.  An activation beyond the
+// range becomes Inf in the high plane and NaN downstream: the encode's epilogue reports non-finite output.
+enum { PF_BF16X2 = 2, PF_BF16X3 = 3, PF_F16X2 = 16 };
+constexpr float kF16ActScale = 16.0f;
+__device__ __forceinline__ void split2_f16(float xs, uint16_t& h, uint16_t& l) {
+    const _Float16 hh = (_Float16)xs;                       // v_cvt_f16_f32, round to nearest even
+    const _Float16 ll = (_Float16)(xs - (float)hh);         // the subtraction is exact in fp32
+    h = __builtin_bit_cast(uint16_t, hh);
+    l = __builtin_bit_cast(uint16_t, ll);
+}
+// p = plane 0 + plane_index(row, k, rows) of the element; fmt = one of PF_*
+__device__ __forceinline__ void store_planes(uint16_t* p, int64_t plane, int fmt, float x) {
+    uint16_t a, b, c;
+    if (fmt == PF_F16X2) {
+        split2_f16(x * kF16ActScale, a, b);
+        p[0] = a; p[plane] = b;
+        return;
+    }
+    split3_bf16(x, a, b, c);
+    p[0] = a; p[plane] = b;
+    if (fmt == PF_BF16X3) p[2 * plane] = c;
+}
+
+// fp32 (rows x K, row-major) -> K-blocked planes, four elements per thread (weights at create time; activations whose
+// producer is not fused)
+static __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes_,
+                                                                 int64_t rows, int K, int64_t plane, int fmt, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index of the row-major (rows x K) input
+    if (i >= rows * (K / 4)) return;
+    const int64_t row = i / (K / 4);
+    const int k = (int)(i % (K / 4)) * 4;
+    uint16_t* planes = planes_ + plane_index(row, k, rows);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    if (fmt == PF_F16X2) {       // `scale`: kF16ActScale for activations, the matrix's own power of two for weights
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2_f16(v[j] * scale, h[j], l[j]);
+        *reinterpret_cast<uint2*>(planes) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+        *reinterpret_cast<uint2*>(planes + plane) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+        return;
+    }
+    const uint32_t h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
+    *reinterpret_cast<uint2*>(planes) = make_uint2(h0, h1);
+    const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[1] - __uint_as_float(h0 & 0xffff0000u);
+    const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
+    const uint32_t l0 = cvt_pk_bf16(r0, r1), l1 = cvt_pk_bf16(r2, r3);
+    *reinterpret_cast<uint2*>(planes + plane) = make_uint2(l0, l1);
+    if (fmt == PF_BF16X3) {
+        const uint32_t t0 = cvt_pk_bf16(r0 - __uint_as_float(l0 << 16), r1 - __uint_as_float(l0 & 0xffff0000u));
+        const uint32_t t1 = cvt_pk_bf16(r2 - __uint_as_float(l1 << 16), r3 - __uint_as_float(l1 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(planes + 2 * plane) = make_uint2(t0, t1);
+    }
+}
+
+// number of work-groups to launch for gemm_planes_kernel's XCD-aware mapping (1-D grid)
+inline int gemm_planes_grid(int M, int N, int bm, int bn, int ksplit) {
+    const int TM = (M + bm - 1) / bm, TN = (N + bn - 1) / bn, Ctot = TN * ksplit;
+    int widest = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int w = (int)((int64_t)(x + 1) * Ctot / 8) - (int)((int64_t)x * Ctot / 8);
+        widest = w > widest ? w : widest;
+    }
+    return 8 * widest * TM;
+}
+
+// ABL (tools/microbench/gemm_planes_bench.hip only): 1 = no DMAs (the MFMA / LDS-read side alone), 2 = no LDS reads and
+// MFMAs (the DMA side alone); results are meaningless.  F16: the planes are PF_F16X2 (NS = 2), else bf16.
+template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false>
+static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes_kernel(GemmPArgs g) {
+    static_assert(!F16 || NS == 2, "the fp16 split has two planes");
+    constexpr int PFMT = F16 ? PF_F16X2 : (NS == 3 ? PF_BF16X3 : PF_BF16X2);
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+    constexpr int PA = BM * 64, PB = BN * 64;                              // bytes per plane and stage
+    constexpr int STAGEB = NS * (PA + PB);
+    constexpr int NDMA = NS * (BM + BN) / 16;                              // wave-instructions per stage
+    constexpr int DPW = (NDMA + NW - 1) / NW;       // a stage's DMAs dealt over the waves; a surplus slot repeats the last one
+    static_assert(STAGES >= 2 && STAGES <= 4 && DPW * (STAGES - 2) <= 63, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gplds[];
+    // ---- work-group -> tile, XCD-aware.  The launch is 1-D; blocks b and b + 8 share an XCD (round-robin placement: a
+    // speed heuristic, never needed for correctness), and every XCD has its own 4-MB L2.  Dealt n-major, every XCD would pull
+    // ALL of both operands through its L2 (FFN-out of a query batch: 33 MB of planes per XCD, 264 MB from the Infinity Cache
+    // per GEMM, which then bounds it).  Here XCD x owns a contiguous range of the combined (K slice, n tile) index c and all
+    // m tiles of it, m fastest: its L2 holds 1/8 of the weights (or one K slice of both operands) and co-resident
+    // work-groups share the same weight tile.  Ranges differ by at most one c: the grid is padded to 8 x the largest
+    // range, the surplus work-groups return at once (gemm_planes_grid).
+    const bool split = g.ksplit > 1;
+    int z, m0, n0;
+    {
+        const int TM = (g.M + BM - 1) / BM, TN = (g.N + BN - 1) / BN;
+        const int Ctot = TN * g.ksplit;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int c_lo = (int)((int64_t)x * Ctot / 8), c_hi = (int)((int64_t)(x + 1) * Ctot / 8);
+        const int c = c_lo + j / TM;
+        if (c >= c_hi) return;
+        z = c / TN;
+        n0 = (c % TN) * BN;
+        m0 = (j % TM) * BM;
+    }
+    const int K_ = split ? g.K / g.ksplit : g.K;                // a multiple of 32 (host)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int i = lane & 31, h = lane >> 5;
+    float* C = g.C ? g.C + (split ? (int64_t)z * g.M * g.ldc : 0) : nullptr;
+    // ---- loader: DMA instruction d = wave + NW j of a stage moves 16 rows x 64 B of one plane of one operand.  Lane l
+    // lands at slot + 16 l: row 16 rb + (l >> 2), chunk position l & 3, i.e. it must FETCH chunk (l & 3) ^ ((l >> 4) & 3)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)gplds;
+    const int64_t a_step = (int64_t)g.M * 64, b_step = (int64_t)g.N * 64;      // bytes from one 32-deep block to the next
+    const char* a_base = reinterpret_cast<const char*>(g.A) + (split ? (int64_t)z * (K_ / 32) * a_step : 0);
+    const char* b_base = reinterpret_cast<const char*>(g.B) + (split ? (int64_t)z * (K_ / 32) * b_step : 0);
+    uint32_t voff[DPW];           // per-lane byte offset from the operand's base (plane, row, chunk)
+    uint32_t loff[DPW];           // wave-uniform LDS offset inside a stage
+    bool isb[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int d = wave + NW * j < NDMA ? wave + NW * j : NDMA - 1;
+        const bool b_op = d >= NS * (BM / 16);
+        const int dd = b_op ? d - NS * (BM / 16) : d;
+        const int rows16 = b_op ? BN / 16 : BM / 16;
+        const int q = dd / rows16, rb = dd % rows16;
+        int row = (b_op ? n0 : m0) + 16 * rb + (lane >> 2);
+        const int lim = b_op ? g.N : g.M;
+        row = row < lim ? row : lim - 1;
+        const uint32_t chunk = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);
+        voff[j] = (uint32_t)(((int64_t)q * (b_op ? g.b_plane : g.a_plane) + (int64_t)row * 32) * 2) + chunk * 16u;
+        loff[j] = (uint32_t)((b_op ? NS * PA : 0) + q * (b_op ? PB : PA) + rb * 1024);
+        isb[j] = b_op;
+    }
+#define CLB_GP_ISSUE(KSTEP, BUF)                                                                                     \
+    {                                                                                                                \
+        const char* ab_ = a_base + (int64_t)(KSTEP) * a_step;                                                        \
+        const char* bb_ = b_base + (int64_t)(KSTEP) * b_step;                                                        \
+        if (ABL != 1) _Pragma("unroll") for (int j = 0; j < DPW; ++j)                                                \
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                                        \
+                         :: "v"(voff[j]), "s"(isb[j] ? bb_ : ab_), "s"(lds0 + (uint32_t)(BUF) * STAGEB + loff[j]) : "memory"); \
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nsteps = K_ / 32;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsteps) CLB_GP_ISSUE(s, s)
+    const int sw = (i >> 2) & 3;
+    const unsigned char* As0 = gplds + (wr * 32 * WM + i) * 64;
+    const unsigned char* Bs0 = gplds + NS * PA + (wc * 32 * WN + i) * 64;
+    int buf = 0;
+    for (int k = 0; k < nsteps; ++k) {
+        // tile k has landed once at most the DMAs of the tiles issued after it are pending
+        if (k + STAGES - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DPW * (STAGES - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (k + STAGES - 1 < nsteps) {
+            const int nb = buf == 0 ? STAGES - 1 : buf - 1;               // (k + STAGES - 1) % STAGES = (k - 1) % STAGES
+            CLB_GP_ISSUE(k + STAGES - 1, nb)
+        }
+        const unsigned char* As = As0 + buf * STAGEB;
+        const unsigned char* Bs = Bs0 + buf * STAGEB;
+        if (ABL != 2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((2 * s + h) ^ sw) << 4;
+            u32x4 av[NS][WM], bv[NS][WN];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int a = 0; a < WM; ++a) av[q][a] = *reinterpret_cast<const u32x4*>(As + q * PA + a * 32 * 64 + off);
+#pragma unroll
+                for (int b = 0; b < WN; ++b) bv[q][b] = *reinterpret_cast<const u32x4*>(Bs + q * PB + b * 32 * 64 + off);
+            }
+#define CLB_GP_MFMA(QA, QB)                                                                                            \
+            c = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[QA][a]), __builtin_bit_cast(f16x8, bv[QB][b]), c, 0, 0, 0) \
+                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[QA][a]), __builtin_bit_cast(bf16x8, bv[QB][b]), c, 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    f32x16 c = acc[a][b];
+                    if (NS == 3) { CLB_GP_MFMA(2, 0) CLB_GP_MFMA(0, 2) CLB_GP_MFMA(1, 1) }
+                    CLB_GP_MFMA(1, 0) CLB_GP_MFMA(0, 1) CLB_GP_MFMA(0, 0)
+                    acc[a][b] = c;
+                }
+#undef CLB_GP_MFMA
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+#undef CLB_GP_ISSUE
+    // C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            const int n = n0 + (wc * WN + b) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wr * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M && n < g.N) {
+                    float v = acc[a][b][r];
+                    if (!split) {
+                        if (F16) v = v * g.out_scale;
+                        if (g.epi & EPI_BIAS) v += g.bias[n];
+                        if (g.epi & EPI_GELU) v = gelu_erf(v);
+                        if (g.epi & EPI_RESID) v += g.R[(int64_t)m * g.ldc + n];
+                        if (g.Cp) store_planes(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
+                    }
+                    if (C) C[(int64_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
 // split-K second pass: C = epilogue(sum over the K slices, in slice order -- deterministic)
 static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ksplit,
                                                                        int64_t M, int N, float* __restrict__ C,
                                                                        const float* __restrict__ bias,
-                                                                       const float* __restrict__ R, float scale, int epi) {
+                                                                       const float* __restrict__ R, float scale, int epi,
+                                                                       uint16_t* __restrict__ Cp = nullptr, int64_t c_plane = 0,
+                                                                       int ns = 0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int n = (int)(idx % N);
@@ -453,7 +728,8 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
     if (epi & EPI_BIAS) v += bias[n];
     if (epi & EPI_GELU) v = gelu_erf(v);
     if (epi & EPI_RESID) v += R[idx];
-    C[idx] = v;
+    if (C) C[idx] = v;
+    if (Cp) store_planes(Cp + plane_index(idx / N, n, M), c_plane, ns, v);   // the bf16 planes the next Linear reads
 }
 
 // split-K second pass fused with the LayerNorm that follows it (the attention-output and FFN-output Linears of a short
@@ -467,23 +743,37 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(const
                                                                           const float* __restrict__ bias,
                                                                           const float* __restrict__ R, float scale, int epi,
                                                                           const float* __restrict__ gamma,
-                                                                          const float* __restrict__ beta, float eps) {
+                                                                          const float* __restrict__ beta, float eps,
+                                                                          uint16_t* __restrict__ Cp = nullptr, int64_t c_plane = 0,
+                                                                          int ns = 0) {
     __shared__ float red[2][4];
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t slice = (size_t)M * N;
-    float v[NR];
+    // every slice's value is requested before the first is used (ksplit <= 8: a rolled loop of load -> wait -> add made the
+    // kernel a chain of ksplit memory latencies: 13 us for 1 024 rows); the additions stay in slice order
+    float pv[8][NR];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int n = tid + 256 * j;
-        v[j] = n < N ? part[t * N + n] : 0.f;
-    }
-    for (int z = 1; z < ksplit; ++z) {
+    for (int z = 0; z < 8; ++z)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int n = tid + 256 * j;
-            if (n < N) v[j] = v[j] + part[z * slice + t * N + n];
+            pv[z][j] = (z < ksplit && n < N) ? part[z * slice + t * N + n] : 0.f;
         }
+    float rres[NR], rbias[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int n = tid + 256 * j;
+        rres[j] = ((epi & EPI_RESID) && n < N) ? R[t * N + n] : 0.f;
+        rbias[j] = ((epi & EPI_BIAS) && n < N) ? bias[n] : 0.f;
+    }
+    float v[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        v[j] = pv[0][j];
+#pragma unroll
+        for (int z = 1; z < 8; ++z)
+            if (z < ksplit) v[j] = v[j] + pv[z][j];
     }
     float sum = 0.f;
 #pragma unroll
@@ -491,9 +781,9 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(const
         const int n = tid + 256 * j;
         if (n < N) {
             float x = v[j] * scale;
-            if (epi & EPI_BIAS) x += bias[n];
+            if (epi & EPI_BIAS) x += rbias[j];
             if (epi & EPI_GELU) x = gelu_erf(x);
-            if (epi & EPI_RESID) x += R[t * N + n];
+            if (epi & EPI_RESID) x += rres[j];
             v[j] = x;
             sum += x;
         }
@@ -513,7 +803,11 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(const
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int n = tid + 256 * j;
-        if (n < N) C[t * N + n] = (v[j] - mean) * rstd * gamma[n] + beta[n];
+        if (n < N) {
+            const float y = (v[j] - mean) * rstd * gamma[n] + beta[n];
+            C[t * N + n] = y;
+            if (Cp) store_planes(Cp + plane_index(t, n, M), c_plane, ns, y);
+        }
     }
 }
 
@@ -526,7 +820,9 @@ static __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32
                                                                     const float* __restrict__ type0,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float eps,
-                                                                    float* __restrict__ out, int* __restrict__ err) {
+                                                                    float* __restrict__ out, int* __restrict__ err,
+                                                                    uint16_t* __restrict__ outp = nullptr, int64_t o_plane = 0,
+                                                                    int ns = 0) {
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= n_tok) return;
@@ -548,13 +844,19 @@ static __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32
     }
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = 1.0f / sqrtf(var / (float)H + eps);
-    for (int d = lane; d < H; d += 64) out[t * H + d] = (out[t * H + d] - mean) * rstd * gamma[d] + beta[d];
+    for (int d = lane; d < H; d += 64) {
+        const float y = (out[t * H + d] - mean) * rstd * gamma[d] + beta[d];
+        out[t * H + d] = y;
+        if (outp) store_planes(outp + plane_index(t, d, n_tok), o_plane, ns, y);
+    }
 }
 
 // in-place LayerNorm over rows of length H.  One wave per row.
 static __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int64_t rows, int H,
                                                               const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float eps) {
+                                                              const float* __restrict__ beta, float eps,
+                                                              uint16_t* __restrict__ xp = nullptr, int64_t x_plane = 0,
+                                                              int ns = 0) {
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= rows) return;
@@ -567,7 +869,11 @@ static __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict
     for (int d = lane; d < H; d += 64) { const float c = row[d] - mean; var += c * c; }
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = 1.0f / sqrtf(var / (float)H + eps);
-    for (int d = lane; d < H; d += 64) row[d] = (row[d] - mean) * rstd * gamma[d] + beta[d];
+    for (int d = lane; d < H; d += 64) {
+        const float y = (row[d] - mean) * rstd * gamma[d] + beta[d];
+        row[d] = y;
+        if (xp) store_planes(xp + plane_index(t, d, rows), x_plane, ns, y);
+    }
 }
 
 // masked softmax over the key axis of attention scores S[z][q][k] (z = document*heads + head), in place.
@@ -614,7 +920,9 @@ static __global__ __launch_bounds__(256) void masked_softmax_kernel(float* __res
 template <int NT>
 static __global__ __launch_bounds__(64) void attention_fused_kernel(const float* __restrict__ qkv,
                                                                     const uint8_t* __restrict__ mask,
-                                                                    float* __restrict__ ctx, int L, int H, float scale) {
+                                                                    float* __restrict__ ctx, int L, int H, float scale,
+                                                                    uint16_t* __restrict__ ctxp = nullptr, int64_t c_plane = 0,
+                                                                    int ns = 0) {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 32, head = blockIdx.y;
     const int64_t n = blockIdx.z;
@@ -691,13 +999,19 @@ static __global__ __launch_bounds__(64) void attention_fused_kernel(const float*
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr, vrow[32], o1, 0, 0, 0);
         }
     // o[r] = O[query q0 + (r & 3) + 8 (r >> 2) + 4 h][d = i (+ 32)]
-    float* out = ctx + n * L * (int64_t)H + head * 64 + i;
+    const int64_t obase = n * L * (int64_t)H + head * 64 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (q < L) {
-            out[(int64_t)q * H] = o0[r];
-            out[(int64_t)q * H + 32] = o1[r];
+            if (ctxp) {      // the output projection reads bf16 planes (gemm_planes_kernel): no fp32 copy is kept
+                const int64_t trow = n * L + q, rows_ = (int64_t)gridDim.z * L;
+                store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[r]);
+                store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[r]);
+            } else {
+                ctx[obase + (int64_t)q * H] = o0[r];
+                ctx[obase + (int64_t)q * H + 32] = o1[r];
+            }
         }
     }
 }
@@ -713,7 +1027,9 @@ static __global__ __launch_bounds__(64) void attention_fused_kernel(const float*
 // grid = (ceil(L / 32), heads, N), block = 64.
 static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const float* __restrict__ qkv,
                                                                         const uint8_t* __restrict__ mask,
-                                                                        float* __restrict__ ctx, int L, int H, float scale) {
+                                                                        float* __restrict__ ctx, int L, int H, float scale,
+                                                                        uint16_t* __restrict__ ctxp = nullptr, int64_t c_plane = 0,
+                                                                        int ns = 0) {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 32, head = blockIdx.y;
     const int64_t n = blockIdx.z;
@@ -791,7 +1107,7 @@ static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const fl
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    float* out = ctx + n * L * (int64_t)H + head * 64 + i;
+    const int64_t obase = n * L * (int64_t)H + head * 64 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int qa = (r & 3) + 8 * (r >> 2);
@@ -800,8 +1116,14 @@ static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const fl
         const float sc = h ? s1 : s0;
         const int q = q0 + qa + 4 * h;
         if (q < L) {
-            out[(int64_t)q * H] = o0[r] * sc;
-            out[(int64_t)q * H + 32] = o1[r] * sc;
+            if (ctxp) {
+                const int64_t trow = n * L + q, rows_ = (int64_t)gridDim.z * L;
+                store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[r] * sc);
+                store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[r] * sc);
+            } else {
+                ctx[obase + (int64_t)q * H] = o0[r] * sc;
+                ctx[obase + (int64_t)q * H + 32] = o1[r] * sc;
+            }
         }
     }
 }
