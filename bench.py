@@ -291,21 +291,21 @@ def sharded_index_build(torch, dist, rank, world, docs, kmeans_iters, dev):
     return out
 
 
-def encoder_l2_operand_bytes(M, N, Kd):
-    """fp32 operand bytes the work-groups of one Linear layer pull through L2, mirroring linear_split's tile choice
-    (csrc/encoder.hip): every work-group streams its A rows and B rows of the K range it owns."""
+def encoder_l2_operand_bytes(M, N, Kd, gemm="f16x3"):
+    """Operand bytes the work-groups of one Linear layer pull through L2, mirroring linear_planes' tile choice
+    (csrc/encoder.hip): every work-group streams the planes of its A rows and B rows of the K range it owns -- two
+    16-bit planes per operand for f16x3 / bf16x3, three for bf16x6 (the fp32 MFMA mode reads fp32 operands)."""
     def wgs(bm, bn):
         return -(-N // bn) * -(-M // bm)
-    if wgs(128, 128) >= 384:
+    bytes_per_el = {"f16x3": 4, "bf16x3": 4, "bf16x6": 6}.get(gemm, 4)
+    if wgs(128, 128) >= 1024:
         bm, bn, ks = 128, 128, 1
-    elif wgs(64, 128) >= 384 and N >= 128:
-        bm, bn, ks = 64, 128, 1
     else:
         bm, bn, ks = 64, 64, 1
         min_slice = 192 if wgs(64, 64) < 64 else 256
         while ks < 8 and wgs(64, 64) * ks < 512 and Kd % (ks * 2 * 32) == 0 and Kd // (ks * 2) >= min_slice:
             ks *= 2
-    return wgs(bm, bn) * (bm + bn) * Kd * 4, (bm, bn, ks)
+    return wgs(bm, bn) * (bm + bn) * Kd * bytes_per_el, (bm, bn, ks)
 
 
 def main():
@@ -682,23 +682,26 @@ def main():
                       "linear_ffn_out_ln": (H, I), "linear_projection": (128, H)}
             lin = {kname: v for kname, v in eprof.items() if kname in shapes}
             domk = max(lin.items(), key=lambda kv: kv[1]["ms"])[0]
-            nprod = {"bf16x6": 6, "bf16x3": 3}.get(enc.gemm, 1)
+            nprod = {"bf16x6": 6, "bf16x3": 3, "f16x3": 3}.get(enc.gemm, 1)
             Nn, Kd = shapes[domk]
             ms1 = eprof[domk]["ms"] / max(eprof[domk]["launches"], 1)
             peak = BF16_MFMA_PEAK_TF if nprod > 1 else F32_MFMA_PEAK_TF
             ach = nprod * 2.0 * M * Nn * Kd / (ms1 * 1e-3) / 1e12
-            l2b, tile = encoder_l2_operand_bytes(M, Nn, Kd)
-            enc_roof = {"kernel": f"{domk} ({M} x {Nn} x {Kd}, gemm_bf16split_kernel {tile[0]}x{tile[1]} tiles, split-K {tile[2]})",
+            l2b, tile = encoder_l2_operand_bytes(M, Nn, Kd, enc.gemm)
+            op16 = "fp16" if enc.gemm == "f16x3" else "bf16"
+            enc_roof = {"kernel": f"{domk} ({M} x {Nn} x {Kd}, gemm_planes_kernel {tile[0]}x{tile[1]} tiles, split-K {tile[2]})",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
-                        "unit": f"TFLOP/s ({'bf16, ' + str(nprod) + ' products per fp32 product' if nprod > 1 else 'fp32 MFMA'})",
+                        "unit": f"TFLOP/s ({op16 + ', ' + str(nprod) + ' products per fp32 product' if nprod > 1 else 'fp32 MFMA'})",
                         "frac": round(ach / peak, 4), "ms_per_launch": round(ms1, 4),
                         "l2_operand_bytes": int(l2b), "l2_operand_GBps": round(l2b / (ms1 * 1e-3) / 1e9, 1),
-                        "note": "l2_operand_bytes = fp32 operand bytes the work-groups stream through L2 (tile rule of csrc/encoder.hip), "
-                                "the bound of these small-M GEMMs; kernel statistics: profiles/r03_encoder_kernel_stats.csv",
+                        "note": "l2_operand_bytes = bytes of pre-split 16-bit operand planes the work-groups stream through L2 (tile rule of "
+                                "csrc/encoder.hip); an XCD's L2 delivers ~65 GB/s to one CU, which together with MFMA issue bounds these "
+                                "small-M GEMMs (tools/microbench/gemm_planes_bench.hip); kernel statistics: profiles/r04_encoder_kernel_stats.csv",
                         "all_stages_ms_per_encode": {kn: round(v["ms"] / n_prof, 4) for kn, v in eprof.items()}}
         e2e = {"value": round(B * args.steps / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
                "encoder_ms_per_step": round(dt_enc / args.steps * 1e3, 4),
-               "dtype": "f32" if enc.gemm == "f32" else f"f32 ({enc.gemm}: every fp32 product of the Linear layers as exact bf16 MFMA products of split operands, fp32 accumulation)",
+               "dtype": "f32" if enc.gemm == "f32" else (f"f32 ({enc.gemm}: every fp32 product of the Linear layers as exact "
+                        f"{'fp16' if enc.gemm == 'f16x3' else 'bf16'} MFMA products of operands pre-split into 16-bit planes, fp32 accumulation)"),
                "encoder": "bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072) + Dense 768->128, random weights, "
                           "synthetic token ids; " + (f"every rank encodes {Bl} of the batch's {B} queries, one all-gather of Q"
                                                      if split else "this rank encodes the whole batch"),

@@ -262,7 +262,10 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     if (!go(c)) { c = {64, 64, 2, c.ks}; (void)go(c); }
     if (c.ks > 1) {
         if (ln && N <= 1024) {
-            if (N <= 768)
+            if (N % 4 == 0)
+                hipLaunchKernelGGL(gemm_splitk_reduce_ln4_kernel, dim3(M), dim3(256), 0, st, part, c.ks, (int64_t)M, N, C, bias, R,
+                                   out_scale, epi, ln->gamma, ln->beta, ln->eps, Cp, c_plane, fmt);
+            else if (N <= 768)
                 hipLaunchKernelGGL(gemm_splitk_reduce_ln_kernel<3>, dim3(M), dim3(256), 0, st, part, c.ks, (int64_t)M, N, C, bias, R,
                                    out_scale, epi, ln->gamma, ln->beta, ln->eps, Cp, c_plane, fmt);
             else
@@ -449,6 +452,17 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     return CLB_OK;
 }
 
+// waits for `st`, then reads and clears the non-finite-output bit of the sticky flag (set by the epilogue kernels)
+int finish_checked(clb_encoder* e, hipStream_t st) {
+    int herr = 0;
+    CLB_HIP(hipMemcpyAsync(&herr, e->err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (herr & 2) return fail(CLB_EDOMAIN, "non-finite encoder output (an activation outside the range of the f16 operand split? "
+                                           "clb_encoder_set_gemm_mode(e, 2) selects the bf16x6 split)");
+    return CLB_OK;
+}
+
 int upload_inputs(clb_encoder* e, const int32_t* ids, const uint8_t* mask, int64_t L, int64_t N) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     if (L < 1 || N < 1) return fail(CLB_EARGUMENT, "empty batch");
@@ -582,11 +596,10 @@ int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* b
     CLB_TRY(upload(dStart, start.data(), sizeof(int64_t) * N, st));
     CLB_TRY(dOut.alloc(sizeof(float) * e->dim * run));
     hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
-                       (int)L, (int)N, dMask.as<uint8_t>(), dStart.as<int64_t>(), dOut.as<float>());
+                       (int)L, (int)N, dMask.as<uint8_t>(), dStart.as<int64_t>(), dOut.as<float>(), e->err.as<int>());
     CLB_HIP(hipGetLastError());
     CLB_HIP(hipMemcpyAsync(out_embs, dOut.p, sizeof(float) * e->dim * run, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipStreamSynchronize(st));
-    return CLB_OK;
+    return finish_checked(e, st);
 }
 
 int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
@@ -602,11 +615,10 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
     hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->ids.as<int32_t>(), (int)L, (int)N,
                        dSkip.as<int64_t>(), (int)n_skip, dMask.as<uint8_t>(), dLens.as<int64_t>());
     hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
-                       (int)L, (int)N, dMask.as<uint8_t>(), (const int64_t*)nullptr, dOut.as<float>());
+                       (int)L, (int)N, dMask.as<uint8_t>(), (const int64_t*)nullptr, dOut.as<float>(), e->err.as<int>());
     CLB_HIP(hipGetLastError());
     CLB_HIP(hipMemcpyAsync(out, dOut.p, sizeof(float) * e->dim * L * N, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipStreamSynchronize(st));
-    return CLB_OK;
+    return finish_checked(e, st);
 }
 
 int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,

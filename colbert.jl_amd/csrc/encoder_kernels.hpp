@@ -520,6 +520,24 @@ __device__ __forceinline__ void store_planes(uint16_t* p, int64_t plane, int fmt
     if (fmt == PF_BF16X3) p[2 * plane] = c;
 }
 
+// four consecutive k of one row (k % 4 == 0: they share a 32-deep block): one 8-byte store per plane
+__device__ __forceinline__ void store_planes4(uint16_t* p, int64_t plane, int fmt, const f32x4 v) {
+    if (fmt == PF_F16X2) {
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2_f16(v[j] * kF16ActScale, h[j], l[j]);
+        *reinterpret_cast<uint2*>(p) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+        *reinterpret_cast<uint2*>(p + plane) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+        return;
+    }
+    uint16_t a[4], b[4], c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3_bf16(v[j], a[j], b[j], c[j]);
+    *reinterpret_cast<uint2*>(p) = make_uint2(a[0] | ((uint32_t)a[1] << 16), a[2] | ((uint32_t)a[3] << 16));
+    *reinterpret_cast<uint2*>(p + plane) = make_uint2(b[0] | ((uint32_t)b[1] << 16), b[2] | ((uint32_t)b[3] << 16));
+    if (fmt == PF_BF16X3) *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(c[0] | ((uint32_t)c[1] << 16), c[2] | ((uint32_t)c[3] << 16));
+}
+
 // fp32 (rows x K, row-major) -> K-blocked planes, four elements per thread (weights at create time; activations whose
 // producer is not fused)
 static __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes_,
@@ -811,6 +829,65 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(const
     }
 }
 
+// The same pass with four CONSECUTIVE columns per thread (N % 4 == 0, N <= 1 024): 16-byte loads of the slices, the
+// residual and the LayerNorm parameters, one 16-byte store of the row and one 8-byte store per plane (the strided form
+// above: 4-byte loads and 2-byte plane stores, 6.7 us per 1 024 x 768 pass; the element arithmetic is the same, the
+// mean / variance partial sums associate differently).
+static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln4_kernel(const float* __restrict__ part, int ksplit,
+                                                                           int64_t M, int N, float* __restrict__ C,
+                                                                           const float* __restrict__ bias,
+                                                                           const float* __restrict__ R, float scale, int epi,
+                                                                           const float* __restrict__ gamma,
+                                                                           const float* __restrict__ beta, float eps,
+                                                                           uint16_t* __restrict__ Cp, int64_t c_plane, int fmt) {
+    __shared__ float red[2][4];
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = 4 * tid;
+    const bool live = n < N;
+    const size_t slice = (size_t)M * N;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pv[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) pv[z] = (z < ksplit && live) ? *reinterpret_cast<const f32x4*>(part + z * slice + t * N + n) : zero;
+    const f32x4 rres = ((epi & EPI_RESID) && live) ? *reinterpret_cast<const f32x4*>(R + t * N + n) : zero;
+    const f32x4 rbias = ((epi & EPI_BIAS) && live) ? *reinterpret_cast<const f32x4*>(bias + n) : zero;
+    const f32x4 gm = live ? *reinterpret_cast<const f32x4*>(gamma + n) : zero;
+    const f32x4 bt = live ? *reinterpret_cast<const f32x4*>(beta + n) : zero;
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+        if (z < ksplit) v = v + pv[z];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = v[j] * scale;
+        if (epi & EPI_BIAS) x += rbias[j];
+        if (epi & EPI_GELU) x = gelu_erf(x);
+        if (epi & EPI_RESID) x += rres[j];
+        v[j] = live ? x : 0.f;
+        sum += v[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    const float mean = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)N;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (live) { const float c = v[j] - mean; var += c * c; }
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    if (lane == 0) red[1][wave] = var;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)N + eps);
+    if (!live) return;
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (v[j] - mean) * rstd * gm[j] + bt[j];
+    *reinterpret_cast<f32x4*>(C + t * N + n) = y;
+    if (Cp) store_planes4(Cp + plane_index(t, n, M), c_plane, fmt, y);
+}
+
 // embeddings: word[id] + position[pos] + token_type[0], then LayerNorm.  One wave per token.  ids are the
 // reference's 1-based Int32 ids (Julia), (L, N) column-major = token (l, n) at ids[l + L*n].
 static __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __restrict__ ids, int64_t n_tok,
@@ -829,6 +906,34 @@ static __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32
     int id = ids[t] - 1;
     if (id < 0 || id >= vocab) { if (lane == 0) atomicOr(err, 1); id = 0; }
     const int l = (int)(t % L);
+    if (H <= 64 * 16) {      // the row stays in registers between the three passes (it was written and re-read twice: 17 us)
+        float v[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = lane + 64 * j;
+            v[j] = d < H ? word[(int64_t)id * H + d] + pos[(int64_t)l * H + d] + type0[d] : 0.f;
+            if (d < H) sum += v[j];
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)H;
+        float var = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (lane + 64 * j < H) { const float c = v[j] - mean; var += c * c; }
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+        const float rstd = 1.0f / sqrtf(var / (float)H + eps);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = lane + 64 * j;
+            if (d < H) {
+                const float y = (v[j] - mean) * rstd * gamma[d] + beta[d];
+                out[t * H + d] = y;
+                if (outp) store_planes(outp + plane_index(t, d, n_tok), o_plane, ns, y);
+            }
+        }
+        return;
+    }
     float sum = 0.f;
     for (int d = lane; d < H; d += 64) {
         const float v = word[(int64_t)id * H + d] + pos[(int64_t)l * H + d] + type0[d];

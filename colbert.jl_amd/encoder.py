@@ -69,9 +69,11 @@ class BertEncoder:
     def __init__(self, weights: np.ndarray, bert_cfg: dict, dim: int = 128, device: int = 0,
                  tokenizer=None, config: Optional[ColBERTConfig] = None, gemm: Optional[str] = None,
                  attention: str = "fused"):
-        """`gemm`: arithmetic of the Linear layers -- "bf16x6" (default: fp32 operands split into three bf16 planes, six
-        exact bf16 MFMA products per fp32 product, fp32 accumulation: fp32-faithful), "bf16x3" (two planes, three
-        products, ~16 significant bits) or "f32" (fp32 MFMA); COLBERT_ENCODER_GEMM sets the default."""
+        """`gemm`: arithmetic of the Linear layers -- "f16x3" (default: every fp32 operand, scaled by a power of two, split
+        into TWO fp16 planes -- round-to-nearest makes them hold all 24 significant bits -- and three exact fp16 MFMA products
+        per fp32 product, fp32 accumulation: fp32-faithful like bf16x6 at half its products), "bf16x6" (three bf16 planes, six
+        products: fp32-faithful over the whole fp32 exponent range), "bf16x3" (two bf16 planes, three products, ~16 significant
+        bits) or "f32" (fp32 MFMA); COLBERT_ENCODER_GEMM sets the default."""
         self.cfg = dict(bert_cfg); self.dim = dim; self.device = device
         self.tokenizer = tokenizer
         self.config = config or ColBERTConfig(dim=dim)
@@ -83,8 +85,8 @@ class BertEncoder:
                                        i64(bert_cfg.get("type_vocab_size", 2)), i64(dim),
                                        C.c_float(bert_cfg.get("layer_norm_eps", 1e-12)), fptr(w), i64(w.size),
                                        C.byref(self._h)))
-        self.gemm = gemm or os.environ.get("COLBERT_ENCODER_GEMM", "bf16x6")
-        modes = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+        self.gemm = gemm or os.environ.get("COLBERT_ENCODER_GEMM", "f16x3")
+        modes = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
         if self.gemm not in modes:
             raise ValueError(f"gemm must be one of {sorted(modes)}, not {self.gemm!r}")
         check(lib().clb_encoder_set_gemm_mode(self._h, modes[self.gemm]))

@@ -311,10 +311,12 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
                        const float* weights, int64_t n_weights, clb_encoder** out);
 int clb_encoder_destroy(clb_encoder* e);
 /* Arithmetic of the Linear layers (the reference multiplies in Float32, checkpoint.jl:21-25 through Transformers.jl).
- * Every fp32 operand is split into bf16 planes and the product is a sum of exact bf16 MFMA plane products in an
- * fp32 accumulator: mode 2 (default) = "bf16x6": three planes (all 24 significant bits), six products, relative
- * error per product < 2^-22; mode 1 = "bf16x3": two planes, three products, < 2^-15; mode 0 = fp32 MFMA
- * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate). */
+ * Every fp32 operand is split into 16-bit planes and the product is a sum of exact MFMA plane products in an fp32
+ * accumulator.  mode 3 (default) = "f16x3": two fp16 planes of the operand scaled by a power of two (round-to-nearest makes
+ * two fp16 planes hold all 24 significant bits), three products, error per product < 2^-23 |a||b|; fp16's exponent range
+ * limits the activations to |x| < 4 094 (an encode that leaves it reports CLB_EDOMAIN: non-finite output).
+ * mode 2 = "bf16x6": three bf16 planes, six products, < 2^-22 per product over the whole fp32 range; mode 1 = "bf16x3": two
+ * bf16 planes, three products, < 2^-15; mode 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the 16-bit rate). */
 int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
 /* Self-attention for head size 64 and up to 512 positions: mode 0 (default) = fused in registers (all score tiles
  * resident up to 64 keys, online softmax beyond), 1 = register-resident for every length, 2 = the three-kernel path
@@ -338,8 +340,9 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
 int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
                               const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream);
 /* The asynchronous device path cannot report an id outside the vocabulary when it is enqueued (it clamps): this call
- * waits for the device and returns the BoundsError of the last encode, if it had one (the host-buffer entry points
- * report it themselves). */
+ * waits for the device and returns the BoundsError of ANY device-path encode since the previous check (the flag is
+ * sticky: set by the kernels, cleared by this call), or CLB_EDOMAIN when an encode produced non-finite embeddings (the
+ * f16x3 split's range).  The host-buffer entry points report both themselves. */
 int clb_encoder_check_last_ids(clb_encoder* e);
 /* Per-stage HIP-event timing of the encoder forward (bench.py's encoder roofline; the stages are the Linear layers of
  * `doc`, src/modelling/checkpoint.jl:21-25, by role).  enable, run encodes, then read: names[i] (static strings), total

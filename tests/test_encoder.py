@@ -121,12 +121,50 @@ def _state(bert, linear):
 # tolerance against the independent fp32 implementation: "f32" = fp32 MFMA GEMMs and "bf16x6" = six exact bf16 plane
 # products per fp32 product (differences are summation order / < 2^-22 per product); "bf16x3" = three plane products,
 # < 2^-15 relative error per product on top of that
-GEMM_TOL = {"f32": 2e-4, "bf16x6": 2e-4, "bf16x3": 6e-4}
-GEMM_TOL_BASE = {"f32": 1e-3, "bf16x6": 1e-3, "bf16x3": 6e-3}
+# "f16x3" (round 4) = two fp16 planes per (power-of-two scaled) operand, three products: held to bf16x6's tolerances
+GEMM_TOL = {"f32": 2e-4, "bf16x6": 2e-4, "f16x3": 2e-4, "bf16x3": 6e-4}
+GEMM_TOL_BASE = {"f32": 1e-3, "bf16x6": 1e-3, "f16x3": 1e-3, "bf16x3": 6e-3}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "bf16x3"])
+def test_f16x3_split_is_as_accurate_as_bf16x6():
+    """The default split (two scaled fp16 planes, three products) against a float64 evaluation of the same network: its
+    error must be that of the fp32-faithful modes (bf16x6, fp32 MFMA), not that of bf16x3 -- and an activation outside the
+    fp16 range is reported, not returned as numbers."""
+    torch, cfg, bert, linear = _random_bert()
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    w = pack_weights(_state(bert, linear), bcfg, 32)
+    rng = np.random.default_rng(7)
+    L, N = 40, 6
+    ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
+    mask = np.ones((N, L), bool)
+    with torch.no_grad():
+        ref = linear.double()(bert.double()(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state).numpy()
+    err = {}
+    for gemm in ("f32", "bf16x6", "f16x3", "bf16x3"):
+        enc = clb.BertEncoder(w, bcfg, dim=32, gemm=gemm)
+        got = enc.doc((ids0.T + 1).astype(np.int32), mask.T).transpose(2, 1, 0).astype(np.float64)
+        enc.close()
+        err[gemm] = float(np.abs(got - ref).max())
+    print("[encoder vs float64]", {k: f"{v:.3g}" for k, v in err.items()})
+    faithful = max(err["f32"], err["bf16x6"])
+    assert err["f16x3"] <= 1.5 * faithful, err
+    assert err["bf16x3"] > 3 * err["f16x3"], err                  # the test can tell the two classes apart
+    # out of range: weights x 1e4 push the hidden activations past 4 094 -> Inf in a high plane -> reported
+    big = w.copy()
+    big *= 1e4
+    enc = clb.BertEncoder(big, bcfg, dim=32, gemm="f16x3")
+    with pytest.raises(clb.DomainError):
+        enc.query_embeddings([1], (ids0.T + 1).astype(np.int32), mask.T)
+    enc.close()
+    enc = clb.BertEncoder(big, bcfg, dim=32, gemm="bf16x6")        # the bf16 split covers the whole fp32 range
+    assert np.isfinite(enc.query_embeddings([1], (ids0.T + 1).astype(np.int32), mask.T)).all()
+    enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "f16x3", "bf16x3"])
 def test_bert_forward_matches_fp32_reference(gemm):
     torch, cfg, bert, linear = _random_bert()
     from colbert_jl_amd.encoder import pack_weights
@@ -210,7 +248,7 @@ def test_fused_attention_long_sequences(L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6", "f16x3", "bf16x3"])
 def test_bert_base_shape_and_export_roundtrip(tmp_path, tok, gemm):
     """bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072), one short batch; weights through the export tool."""
     torch, cfg, bert, linear = _random_bert(hidden=768, layers=12, heads=12, inter=3072, vocab=len(VOCAB), max_pos=64, dim=128, seed=3)
