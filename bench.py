@@ -747,6 +747,55 @@ def main():
         p50_graph_ms = float(np.median(glat[5:]) * 1e3)
         del graph
 
+    # ---- the reference API's own operating point: search(searcher, query::String, k) (src/searching.jl:93-128), ONE text
+    # query per call -- tokenize (host, WordPiece over a synthetic bert-base-sized vocabulary) -> ids up -> encode 1 x 32
+    # (bert-base geometry, random weights) -> search -> k (pid, score) pairs down; as stream launches and as ONE captured
+    # HIP graph of encoder + search (Searcher.text_search).  N = 1 only.
+    text_lat = None
+    if lat and not gather and not args.no_encoder:
+        import tempfile
+        from colbert_jl_amd import tokenization
+        from colbert_jl_amd.encoder import BERT_BASE, random_weights
+        words = [f"w{i}" for i in range(BERT_BASE["vocab_size"] - 1000)]
+        vocab = (["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] +
+                 [f"[unused{i}]" for i in range(99, 99 + 896 - 0)])[:1000] + words
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as vf:
+            vf.write("\n".join(vocab) + "\n")
+        tokz = tokenization.WordPieceTokenizer(vf.name)
+        os.unlink(vf.name)
+        enc1 = clb.BertEncoder(random_weights(BERT_BASE, 128, seed=5), dict(BERT_BASE), dim=128, device=local_rank, tokenizer=tokz,
+                               config=clb.ColBERTConfig(query_maxlen=T, dim=128))
+        s.encoder = enc1
+        rngq = np.random.default_rng(9)
+        texts = [" ".join(words[j] for j in rngq.integers(0, len(words), size=int(rngq.integers(4, 12)))) for _ in range(48)]
+        text_lat = {}
+        results = {}
+        for label, use_graph in (("stream_launches", False), ("hip_graph", True)):
+            try:
+                ts = s.text_search(k, args.nprobe, graph=use_graph)
+                tl, tok_s = [], []
+                for q in texts:
+                    t1 = time.perf_counter()
+                    out_q = ts(q)
+                    tl.append(time.perf_counter() - t1)
+                results[label] = out_q
+                for q in texts[:16]:
+                    t1 = time.perf_counter()
+                    tokenization.tensorize_queries("[Q]", True, tokz, [q], T)
+                    tok_s.append(time.perf_counter() - t1)
+                text_lat[label] = {"p50_ms": round(float(np.median(tl[8:]) * 1e3), 4), "p90_ms": round(float(np.quantile(tl[8:], 0.9) * 1e3), 4),
+                                   "tokenize_ms": round(float(np.median(tok_s) * 1e3), 4)}
+                ts.close()
+            except clb.ColBERTError as e_:      # e.g. fewer than k candidates for a random-weight query on a tiny corpus
+                text_lat[label] = {"error": str(e_)[:200]}
+        if len(results) == 2:
+            text_lat["graph_matches_stream"] = bool(np.array_equal(results["stream_launches"][0], results["hip_graph"][0]) and
+                                                    np.array_equal(results["stream_launches"][1], results["hip_graph"][1]))
+        text_lat["note"] = ("search(searcher, query::String, k) per call: tokenizer + H2D of 32 ids + encoder (1 x 32 tokens, bert-base "
+                            "geometry, random weights: the embeddings are meaningless, the work is not) + search + D2H of the top-k")
+        s.encoder = None
+        enc1.close()
+
     # ---- roofline of the dominant kernel (per launch = one batch on this rank's shard)
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
     roof = None
@@ -902,7 +951,10 @@ def main():
                              "note": "the same loop repeated until the timed region lasts --min-seconds"},
                "end_to_end_with_query_encoder": e2e,
                "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4),
-               "p50_latency_graph_replay_ms": None if p50_graph_ms is None else round(p50_graph_ms, 4), "roofline": roof, "cpu_baseline": cpu,
+               "p50_latency_graph_replay_ms": None if p50_graph_ms is None else round(p50_graph_ms, 4),
+               "p50_text_to_topk_ms": (text_lat or {}).get("stream_launches", {}).get("p50_ms"),
+               "p50_text_to_topk_graph_ms": (text_lat or {}).get("hip_graph", {}).get("p50_ms"),
+               "text_to_topk": text_lat, "roofline": roof, "cpu_baseline": cpu,
                "worst_case_uniform_codes": worst, "built_index": built, "built_index_1M": built_1m, "batch_sweep": batch_sweep,
                "fixed_batch_32": fixed32, "single_exchange": single_exchange, "index_build": index_build,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},

@@ -10,4 +10,4 @@ from ._lib import (ArgumentError, BoundsError, ColBERTError, DimensionMismatch, 
 from .config import ColBERTConfig  # noqa: F401
 from .encoder import BertEncoder  # noqa: F401
 from .indexer import Indexer, PrecomputedEncoder, index, train  # noqa: F401
-from .searcher import Searcher, search  # noqa: F401
+from .searcher import Searcher, TextSearch, search  # noqa: F401

@@ -238,6 +238,15 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm); };
     PlanCfg c;
     if (const PlanCfg* o = plan_override(role)) c = *o;
+    else if (M <= 64 && part) {
+        // ONE query (search(searcher, query::String, k), 32 rows): every Linear is a weight stream with one tile row.  Split
+        // over K until the chip is full (at least three 32-deep steps per slice) with a four-buffer ring: a work-group's
+        // whole slice is in flight from its prologue, i.e. ONE memory round trip per work-group instead of one per step
+        // (24 dependent round trips made each of these launches 24 us)
+        c = {64, 64, 4, 1};
+        const int tn = (N + 63) / 64;
+        while (c.ks < 32 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= 96 && tn * c.ks * 2 <= 1024) c.ks *= 2;
+    }
     else if (wgs(128, 128) >= 1024) c = {128, 128, 2, 1};          // long activations (passage batches)
     else {
         // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured
@@ -370,8 +379,10 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     auto wp = [&](int64_t blob_off) { return WP + (blob_off - e->o_layer0); };
     auto ws = [&](int64_t layer, int which) { return e->wscale.empty() ? 1.0f : e->wscale[(size_t)(layer * 4 + which)]; };
     const bool short_batch = T <= 4096;         // split-K scratch only where it can be used (query batches)
-    if (short_batch) CLB_TRY(e->part.ensure(sizeof(float) * 8 * T * H));
+    const bool tiny = T <= 64;                  // one query: every Linear is split over K (up to 32 slices)
+    if (short_batch) CLB_TRY(e->part.ensure(sizeof(float) * (tiny ? 32 * T * std::max(3 * H, I) : 8 * T * H)));
     float* part = short_batch ? e->part.as<float>() : nullptr;
+    float* part_wide = tiny ? part : nullptr;   // scratch for the wide outputs (QKV, FFN-in), which only a single query splits
     if (!e->err.p) {      // the flag is STICKY: set by any encode since the last check, cleared by whoever reads it
         CLB_TRY(e->err.ensure(sizeof(int)));
         CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
@@ -395,7 +406,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         const int64_t lo = e->o_layer0 + l * e->layer_stride;       // blob offset of this layer's parameters
         { EncTimed tm(e, ES_QKV, st);
         if (P) linear_planes(e, st, LR_QKV, xp, hp, wp(lo + e->r_wqkv), ws(l, 0), qkv, nullptr, 0, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H),
-                             (int)H, EPI_BIAS, nullptr, nullptr);
+                             (int)H, EPI_BIAS, part_wide, nullptr);
         else linear(e, st, x, P_ + e->r_wqkv, qkv, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
         EncTimed* t_att = new EncTimed(e, ES_ATTENTION, st);
         if (fused) {
@@ -430,7 +441,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         // exists only as the bf16 planes the second Linear reads
         { EncTimed tm(e, ES_FFN_IN, st);
         if (P) linear_planes(e, st, LR_FFN_IN, tmpp, hp, wp(lo + e->r_w1), ws(l, 2), nullptr, hbp, ip, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H,
-                             EPI_BIAS | EPI_GELU, nullptr, nullptr);
+                             EPI_BIAS | EPI_GELU, part_wide, nullptr);
         else linear(e, st, tmp, P_ + e->r_w1, hb, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr); }
         { EncTimed tm(e, ES_FFN_OUT, st);
         if (P) linear_planes(e, st, LR_FFN_OUT, hbp, ip, wp(lo + e->r_w2), ws(l, 3), x, xp, hp, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I,

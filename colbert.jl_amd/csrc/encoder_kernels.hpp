@@ -740,8 +740,15 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int n = (int)(idx % N);
-    float v = part[idx];
-    for (int z = 1; z < ksplit; ++z) v = v + part[(size_t)z * M * N + idx];
+    float v = 0.f;
+    for (int z0 = 0; z0 < ksplit; z0 += 8) {      // eight slices requested at a time, added in slice order
+        float pv[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) pv[z] = z0 + z < ksplit ? part[(size_t)(z0 + z) * M * N + idx] : 0.f;
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+            if (z0 + z < ksplit) v = (z0 + z == 0) ? pv[z] : v + pv[z];
+    }
     v = v * scale;
     if (epi & EPI_BIAS) v += bias[n];
     if (epi & EPI_GELU) v = gelu_erf(v);
@@ -847,17 +854,20 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln4_kernel(cons
     const bool live = n < N;
     const size_t slice = (size_t)M * N;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 pv[8];
+    f32x4 v = zero;
+    for (int z0 = 0; z0 < ksplit; z0 += 8) {      // eight slices requested at a time, added in slice order (ksplit <= 32)
+        f32x4 pv[8];
 #pragma unroll
-    for (int z = 0; z < 8; ++z) pv[z] = (z < ksplit && live) ? *reinterpret_cast<const f32x4*>(part + z * slice + t * N + n) : zero;
+        for (int z = 0; z < 8; ++z)
+            pv[z] = (z0 + z < ksplit && live) ? *reinterpret_cast<const f32x4*>(part + (z0 + z) * slice + t * N + n) : zero;
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+            if (z0 + z < ksplit) v = (z0 + z == 0) ? pv[z] : v + pv[z];
+    }
     const f32x4 rres = ((epi & EPI_RESID) && live) ? *reinterpret_cast<const f32x4*>(R + t * N + n) : zero;
     const f32x4 rbias = ((epi & EPI_BIAS) && live) ? *reinterpret_cast<const f32x4*>(bias + n) : zero;
     const f32x4 gm = live ? *reinterpret_cast<const f32x4*>(gamma + n) : zero;
     const f32x4 bt = live ? *reinterpret_cast<const f32x4*>(beta + n) : zero;
-    f32x4 v = pv[0];
-#pragma unroll
-    for (int z = 1; z < 8; ++z)
-        if (z < ksplit) v = v + pv[z];
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

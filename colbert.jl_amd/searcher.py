@@ -185,6 +185,11 @@ class Searcher:
         assert Q.shape[2] == 1 and Q.shape[1] == self.config.query_maxlen, Q.shape
         return self.search_embeddings(Q[:, :, 0], k)
 
+    def text_search(self, k: int, nprobe: Optional[int] = None, graph: bool = True) -> "TextSearch":
+        """A session for repeated `search(searcher, query::String, k)` calls with everything after the tokenizer on the
+        device (TextSearch below)."""
+        return TextSearch(self, k, nprobe, graph)
+
     # -- profiling (bench.py) -----------------------------------------------------------------------
     def profile_enable(self, on: bool = True, counters: bool = False):
         """Per-kernel HIP-event timing; `counters` additionally fills `last_batch_stats` (one extra kernel per
@@ -203,6 +208,81 @@ class Searcher:
         a, b, c, d = i64(0), i64(0), i64(0), i64(0)
         check(lib().clb_last_batch_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"cand_docs": a.value, "cand_embs": b.value, "rescored_docs": c.value, "rescored_embs": d.value}
+
+
+class TextSearch:
+    """search(searcher, query::String, k) (src/searching.jl:93-128) for a serving loop: one text query per call --
+    tokenize on the host, then encode_queries (1 x query_maxlen) -> search -> the k (pid, score) pairs, all on the device
+    with no host round trip in between: the token ids go up in one 128-byte copy, the encoder writes the (1, T, dim) query
+    tensor the search reads (clb_encode_queries_device -> clb_search_batch_device), the results come back in one copy.
+    `graph=True`: the ~100 kernel launches of encoder + search are captured ONCE as a HIP graph over static buffers and
+    replayed per query (the library only enqueues kernels and memsets on the stream it is handed).  Results are those of
+    Searcher.search: BoundsError when the query has fewer than k candidates (searching.jl:127)."""
+
+    def __init__(self, searcher: Searcher, k: int, nprobe: Optional[int] = None, graph: bool = True):
+        import torch
+        from .distributed import DeviceSearch
+        if searcher.encoder is None or searcher.encoder.tokenizer is None:
+            raise ColBERTError("text search needs an encoder with a tokenizer attached to the Searcher")
+        self.s, self.enc, self.k = searcher, searcher.encoder, int(k)
+        cfg = self.enc.config
+        self.T = int(cfg.query_maxlen)
+        self.dev = torch.device("cuda", searcher.device)
+        tok = self.enc.tokenizer
+        self.h_ids = torch.empty((1, self.T), dtype=torch.int32).pin_memory()
+        self.h_mask = torch.empty((1, self.T), dtype=torch.uint8).pin_memory()
+        self.d_ids = torch.zeros((1, self.T), dtype=torch.int32, device=self.dev)
+        self.d_mask = torch.ones((1, self.T), dtype=torch.uint8, device=self.dev)
+        self.d_skip = torch.tensor([tok.pad_id], dtype=torch.int64, device=self.dev)            # searching.jl:62
+        self.d_q = torch.empty((1, self.T, searcher.dim), dtype=torch.float32, device=self.dev)
+        self.run = DeviceSearch(searcher, self.T, 1, self.k, int(nprobe or searcher.config.nprobe))
+        self.h_out = torch.empty(self.run.packed.numel(), dtype=torch.uint8).pin_memory()
+        self.h_ncand = torch.empty(1, dtype=torch.int64).pin_memory()
+        self.stream = torch.cuda.Stream(self.dev)
+        self.graph = None
+        # a first pass sizes every workspace (allocations cannot be captured)
+        self.d_ids.fill_(tok.lookup("[MASK]"))
+        with torch.cuda.stream(self.stream):
+            self._enqueue()
+        self.stream.synchronize()
+        self.enc.check_last_ids()
+        if graph:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self._enqueue()
+
+    def _enqueue(self):
+        self.enc.query_embeddings_device(self.d_ids, self.d_mask, self.d_skip, self.d_q)
+        self.run(self.d_q)
+
+    def __call__(self, query: str):
+        """-> (pids Int64[k] 1-based, scores Float32[k])"""
+        import torch
+        from . import tokenization
+        cfg = self.enc.config
+        ids, mask = tokenization.tensorize_queries(cfg.query_token, cfg.attend_to_mask_tokens, self.enc.tokenizer, [query], self.T)
+        self.h_ids.numpy()[0, :] = ids[:, 0]
+        self.h_mask.numpy()[0, :] = mask[:, 0]
+        with torch.cuda.stream(self.stream):
+            self.d_ids.copy_(self.h_ids, non_blocking=True)
+            self.d_mask.copy_(self.h_mask, non_blocking=True)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._enqueue()
+            self.h_out.copy_(self.run.packed, non_blocking=True)
+            self.h_ncand.copy_(self.run.ncand, non_blocking=True)
+        self.stream.synchronize()
+        n = int(self.h_ncand[0])
+        self.s.last_num_candidates = n
+        if n < self.k:                                                            # searching.jl:127
+            raise BoundsError(f"attempt to access {n}-element Vector at index [1:{self.k}] (the query has {n} candidate passages)")
+        k = self.k
+        out = self.h_out.numpy()
+        return out[:k * 8].view(np.int64).copy(), out[k * 8:k * 12].view(np.float32).copy()
+
+    def close(self):
+        self.graph = None
 
 
 def search(searcher: Searcher, query, k: int):

@@ -320,4 +320,15 @@ def test_text_to_search_end_to_end(tmp_path, tok, which):
     assert np.array_equal(pids, rp) and np.array_equal(scores.view(np.uint32), rs.view(np.uint32))
     with pytest.raises(clb.BoundsError):
         clb.search(searcher, query, n + 1)
+    # the serving session (tokenizer on the host, encode -> search on the device without a host round trip), as stream
+    # launches and as ONE captured HIP graph: the same pids and the same score bits for every query
+    for graph in (False, True):
+        ts = searcher.text_search(3, graph=graph)
+        for q in (query, collection[0], "hello world", collection[-1]):
+            want = clb.search(searcher, q, 3)
+            got = ts(q)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), (graph, q)
+        ts.close()
+    with pytest.raises(clb.BoundsError):
+        searcher.text_search(n + 1, graph=False)(query)
     searcher.close(); enc.close()
