@@ -338,6 +338,10 @@ def main():
                     help="make the config-2 built index (100k passages through this repo's own index build) the HEADLINE workload")
     ap.add_argument("--built-docs", type=int, default=100_000, help="passages of the built_index workload (BASELINE config 2)")
     ap.add_argument("--built-kmeans-iters", type=int, default=20, help="k-means iterations of the built index (reference default)")
+    ap.add_argument("--exchange", choices=["two-phase", "single"], default="two-phase",
+                    help="N > 1: the exchange `value` is measured with -- two-phase (default: a small all-gather of every shard's k largest "
+                         "approximate scores gives all shards the GLOBAL threshold, then one all-gather of the packed top-k) or single "
+                         "(BASELINE north_star's wording: ONE all-gather of the per-shard top-k per batch); the other one is in the same line")
     ap.add_argument("--no-built-1m", action="store_true",
                     help="skip built_index_1M (the headline corpus size through this repo's own device-resident index build, ~40 s)")
     ap.add_argument("--built-1m-docs", type=int, default=0,
@@ -446,7 +450,7 @@ def main():
     # With several shards the search runs in two phases around a second, small all-gather (every shard's k largest
     # approximate scores): all shards then cut at the GLOBAL k-th score and re-score ~k/N passages each instead of
     # ~k.  COLBERT_BENCH_TWO_PHASE=0/1 overrides.
-    two_phase_default = gather and s.mode == 1 and (world >= 2 if "COLBERT_BENCH_TWO_PHASE" not in os.environ
+    two_phase_default = gather and s.mode == 1 and ((world >= 2 and args.exchange == "two-phase") if "COLBERT_BENCH_TWO_PHASE" not in os.environ
                                                     else os.environ["COLBERT_BENCH_TWO_PHASE"] == "1")
     import torch.distributed as _dist
     overlap = [not args.no_overlap]
@@ -596,7 +600,7 @@ def main():
     # ---- N > 1: the same 32-query batch at every N (so that the N-GPU point and the 1-GPU point of a strong-scaling
     # curve run the same batch), and the single-exchange mode north_star describes (ONE all-gather of the per-shard top-k
     # per batch, every shard cutting at its own threshold) beside the two-phase default
-    fixed32 = single_exchange = None
+    fixed32 = single_exchange = two_phase_leg = None
     if world > 1:
         if B != 32:
             p32 = Plan(32, two_phase_default)
@@ -609,6 +613,11 @@ def main():
             single_exchange = {"batch": B, "value": round(B * n1x / s1x, 2), "unit": "queries/s",
                                "ms_per_step": round(s1x / n1x * 1e3, 4), "steps": n1x,
                                "note": "one all-gather (packed per-shard top-k) per batch; every shard re-scores against its own k-th approximate score"}
+        elif s.mode == 1:
+            p2x = Plan(B, True)
+            n2x, s2x = sustained_of(p2x, min(args.min_seconds, 0.3))
+            two_phase_leg = {"batch": B, "value": round(B * n2x / s2x, 2), "unit": "queries/s", "ms_per_step": round(s2x / n2x * 1e3, 4),
+                             "steps": n2x, "note": "global-threshold exchange between the passes + one all-gather of the packed top-k"}
 
     # ---- the metric as the reference's search(::String) defines it (src/searching.jl:93-128): encode_queries first.
     # No checkpoint exists in the build image, so the encoder has bert-base-uncased GEOMETRY with random weights and
@@ -956,7 +965,9 @@ def main():
                "p50_text_to_topk_graph_ms": (text_lat or {}).get("hip_graph", {}).get("p50_ms"),
                "text_to_topk": text_lat, "roofline": roof, "cpu_baseline": cpu,
                "worst_case_uniform_codes": worst, "built_index": built, "built_index_1M": built_1m, "batch_sweep": batch_sweep,
-               "fixed_batch_32": fixed32, "single_exchange": single_exchange, "index_build": index_build,
+               "exchange": (None if not gather else "two-phase (global threshold: 2 all-gathers per batch)" if two_phase
+                            else "single (north_star: 1 all-gather of the per-shard top-k per batch)"),
+               "fixed_batch_32": fixed32, "single_exchange": single_exchange, "two_phase_exchange": two_phase_leg, "index_build": index_build,
                "setup_seconds": {"generate": round(t_gen, 1), "upload_and_build": round(t_load, 1)},
                "hbm_bytes": device_bytes}
         sys.stdout.flush()

@@ -145,6 +145,8 @@ void allow_large_topk_lds() {
     allow_dynamic_lds(reinterpret_cast<const void*>(topk_kernel), (int)(sizeof(unsigned long long) * kMaxTopK));
 }
 
+constexpr int64_t kSubBatch = 64;      // queries per pass of the single-call search entry points (see clb_search_batch_device_slot)
+
 int next_pow2(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -993,8 +995,17 @@ int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, in
     hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP null stream, as for any HIP API
     Workspace& w = s->ws[slot];
     w.pending.valid = false;
-    CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
-    CLB_TRY(run_search(s, w, st, d_Q, (int)B, (int)T, (int)nprobe, (int)k, d_out_pids, d_out_scores, d_n_cand));
+    // A large batch runs as sub-batches of kSubBatch queries, back to back on the caller's stream and on this slot's scratch:
+    // every query carries an 8-MB fp16 score table (K = 131 072), and from ~64 queries on the tables of a batch outgrow
+    // the 256-MB Infinity Cache before pass 1 reads them (measured: 29.4 k queries/s at 64, 27.8 k at 256 in one piece);
+    // the centroid kernel shares a staged tile between 16 queries whatever the batch, so nothing is lost above that.
+    // (The two-phase sharded calls keep the whole batch: phase 2 continues on the scratch of phase 1.)
+    for (int64_t b0 = 0; b0 < B; b0 += kSubBatch) {
+        const int64_t bn = std::min<int64_t>(kSubBatch, B - b0);
+        CLB_TRY(ensure_workspace(s, w, bn, T, nprobe, k));
+        CLB_TRY(run_search(s, w, st, d_Q + (size_t)b0 * T * s->dim, (int)bn, (int)T, (int)nprobe, (int)k, d_out_pids + (size_t)b0 * k,
+                           d_out_scores + (size_t)b0 * k, d_n_cand ? d_n_cand + b0 : nullptr));
+    }
     return CLB_OK;
 }
 
@@ -1055,16 +1066,19 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
     w.pending.valid = false;
-    CLB_TRY(ensure_workspace(s, w, B, T, nprobe, k));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * B * T * s->dim, hipMemcpyHostToDevice, st));
-    CLB_TRY(run_search(s, w, st, w.Qdev.as<float>(), (int)B, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(),
-                       w.outs.as<float>()));
     std::vector<int> nc((size_t)B), fl((size_t)B);
-    CLB_HIP(hipMemcpyAsync(out_pids, w.outp.p, sizeof(int64_t) * B * k, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(out_scores, w.outs.p, sizeof(float) * B * k, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(nc.data(), w.ncand.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    CLB_HIP(hipMemcpyAsync(fl.data(), w.flags.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    for (int64_t b0 = 0; b0 < B; b0 += kSubBatch) {           // sub-batches: see clb_search_batch_device_slot
+        const int64_t bn = std::min<int64_t>(kSubBatch, B - b0);
+        CLB_TRY(ensure_workspace(s, w, bn, T, nprobe, k));
+        CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q + (size_t)b0 * T * s->dim, sizeof(float) * bn * T * s->dim, hipMemcpyHostToDevice, st));
+        CLB_TRY(run_search(s, w, st, w.Qdev.as<float>(), (int)bn, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(),
+                           w.outs.as<float>()));
+        CLB_HIP(hipMemcpyAsync(out_pids + (size_t)b0 * k, w.outp.p, sizeof(int64_t) * bn * k, hipMemcpyDeviceToHost, st));
+        CLB_HIP(hipMemcpyAsync(out_scores + (size_t)b0 * k, w.outs.p, sizeof(float) * bn * k, hipMemcpyDeviceToHost, st));
+        CLB_HIP(hipMemcpyAsync(nc.data() + b0, w.ncand.p, sizeof(int) * bn, hipMemcpyDeviceToHost, st));
+        CLB_HIP(hipMemcpyAsync(fl.data() + b0, w.flags.p, sizeof(int) * bn, hipMemcpyDeviceToHost, st));
+    }
     CLB_HIP(hipStreamSynchronize(st));
     int64_t docs = 0;
     for (int64_t b = 0; b < B; ++b) {

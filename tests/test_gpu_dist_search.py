@@ -1,0 +1,95 @@
+"""The sharded search with the HIP searcher on BOTH sides of a real process group: two rank processes share this box's
+one GPU, each holds a contiguous passage shard in its own `Searcher` (libcolbert_hip), the exchanges go over gloo
+(staged through host memory: RCCL refuses two ranks on one device) -- what tests/test_dist_gloo.py does with the oracle
+standing in for the local search.  Both protocols against the oracle's unsharded search, pids and score bits:
+  * single exchange (BASELINE north_star): every shard searches with its own threshold, ONE all-gather of the packed
+    per-shard top-k, merge;
+  * two-phase: clb_search_shard_phase1 -> all-gather of the shards' k largest approximate scores -> phase2 at the global
+    threshold (after the shards have shared one error bound) -> packed all-gather, merge."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, store, k, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import colbert_jl_amd as clb
+    from colbert_jl_amd.distributed import DeviceSearch, merge_packed, packed_topk_bytes
+    from colbert_jl_amd.sharding import shard_index
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    idx = clb.synthetic.make_index(seed=141, n_docs=6000, K=512)
+    Qs = clb.synthetic.make_queries(idx, 142, 6)
+    B, T = Qs.shape[2], Qs.shape[1]
+    sub, off = shard_index(idx, rank, world)
+    s = clb.Searcher(index=sub, device=0, pid_offset=off)
+    # one error bound on every shard (all-reduce MAX over the process group)
+    t = torch.from_numpy(s.bound_consts.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    s.raise_bound_consts(t.numpy())
+    Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).to(dev)
+    run = DeviceSearch(s, T, B, k, 2)
+
+    def gather_cpu(t_dev):            # (n, ...) device tensor -> (world, n, ...) CPU tensor over gloo
+        c = t_dev.cpu().contiguous()
+        out = torch.empty((world,) + tuple(c.shape), dtype=c.dtype)
+        dist.all_gather_into_tensor(out.view(-1), c.view(-1))
+        return out
+
+    out = {}
+    # single exchange
+    run(Qdev)
+    torch.cuda.synchronize()
+    g = gather_cpu(run.packed).to(dev)
+    mp, ms = merge_packed(g.view(world, packed_topk_bytes(k, B)), B, k)
+    out["single"] = (mp.cpu().numpy(), ms.cpu().numpy())
+    # two-phase
+    lt = run.phase1(Qdev)
+    torch.cuda.synchronize()
+    allt = gather_cpu(lt).to(dev)                                    # (world, B, k)
+    run.phase2(Qdev, allt)
+    torch.cuda.synchronize()
+    g = gather_cpu(run.packed).to(dev)
+    mp, ms = merge_packed(g.view(world, packed_topk_bytes(k, B)), B, k)
+    out["two_phase"] = (mp.cpu().numpy(), ms.cpu().numpy())
+    out["rescored"] = s.last_batch_stats()["rescored_docs"] if False else None
+    q.put((rank, out))
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [100, 700])
+def test_two_rank_processes_hip_search_both_protocols(oracle, k):
+    import torch.multiprocessing as mp
+
+    import colbert_jl_amd as clb
+    store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, store.name, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    idx = clb.synthetic.make_index(seed=141, n_docs=6000, K=512)
+    Qs = clb.synthetic.make_queries(idx, 142, 6)
+    oidx = dict(idx, emb2pid=oracle.build_emb2pid(idx["doclens"]))
+    for b in range(Qs.shape[2]):
+        rp, rs, _ = oracle.search(oidx, Qs[:, :, b], 2, k)
+        for r in (0, 1):                                            # the merged result is identical on every rank
+            for proto in ("single", "two_phase"):
+                p, sc = res[r][proto]
+                assert np.array_equal(p[b], rp), (r, proto, b)
+                assert np.array_equal(sc[b].view(np.uint32), rs.view(np.uint32)), (r, proto, b)
