@@ -24,6 +24,42 @@ static __global__ __launch_bounds__(128) void generic_cells_kernel(const float* 
     if (c < K) cells[(size_t)t * K + c] = dot_canonical(gq, C + (size_t)c * dim, dim);
 }
 
+// The same products on the fp32 MFMA, for B queries at once and in the layout the tuned selection kernels read
+// ([b][centroid][Tpad]: topn_partial / topn_final, mark, compaction then serve the general shapes unchanged): one wave per
+// 16 centroids, v_mfma_f32_16x16x4_f32 with k walked in ascending order = the canonical fmaf chain of dot_canonical
+// (lane (r, g) supplies dims 4s + g of centroid c0 + r and of token t0 + r).  The centroid values of the wave's tile stay in
+// registers (dim <= 4 KSMAX) while it walks the token groups of all queries.  grid = (ceil(K / 64), B), block = 256.
+template <int KSMAX>
+static __global__ __launch_bounds__(256) void generic_cells_mfma_kernel(const float* __restrict__ C, const float* __restrict__ Q,
+                                                                       int dim, int K, int T, int Tpad,
+                                                                       float* __restrict__ cells) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (c0 >= K) return;
+    const int b = blockIdx.y;
+    const int ks = dim >> 2;
+    const float* crow = C + (size_t)(c0 + r < K ? c0 + r : K - 1) * dim + g;
+    float a[KSMAX];
+#pragma unroll
+    for (int s = 0; s < KSMAX; ++s) a[s] = s < ks ? crow[4 * s] : 0.f;
+    float* out = cells + ((size_t)b * K + c0) * Tpad;
+    for (int t0 = 0; t0 < Tpad; t0 += 16) {
+        const int t = t0 + r;
+        const float* qrow = Q + ((size_t)b * T + (t < T ? t : T - 1)) * dim + g;
+        float q[KSMAX];
+#pragma unroll
+        for (int s = 0; s < KSMAX; ++s) q[s] = (s < ks && t < T) ? qrow[4 * s] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSMAX; ++s)
+            if (s < ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], q[s], acc, 0, 0, 0);
+        // accumulator: lane (col = token r, g) holds centroids c0 + 4 g + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c0 + 4 * g + i < K) out[(size_t)(4 * g + i) * Tpad + t] = acc[i];
+    }
+}
+
 // Top-nprobe per token by a stable radix sort (utils.jl:327-332: partialsortperm(v, 1:k, rev = true), lower index
 // first on ties): key = token << 32 | ~order(score) ascending == token ascending, score descending; the sort is
 // stable and the values enter in ascending centroid order.  `cells` is addressed with strides so that both layouts
@@ -170,6 +206,110 @@ static __global__ __launch_bounds__(256) void generic_score_mfma_kernel(
             }
         }
         if (lane == 0) scores[j] = total;
+    }
+}
+
+// The same kernel with a step's 16 decompressed, normalised embeddings held in REGISTERS (dim <= 4 KSMAX) and for B queries
+// per launch (grid = (G, B)).  In the loop form above every k-step issues its byte, centroid and query loads inside the
+// MFMA chain -- with `dim` and `nbits` run-time values hipcc keeps them there, one memory round trip per k-step: 58 us per
+// 16-row step, 0.64 ms per query on 100 k passages of dim 64 / nbits 8 (69 % of the general path).  Here the unrolled,
+// predicated loops put all loads of a step in flight at once, the values are decompressed once per step instead of once
+// per token group, and the division is the correctly rounded reciprocal form of the tuned kernels (div_by_reciprocal;
+// IEEE division outside its guarded range).  Bit-identical to the loop form and to the oracle.
+template <int KSMAX>
+static __global__ __launch_bounds__(256) void generic_score_mfma_fast_kernel(
+    const float* __restrict__ C, const float* __restrict__ weights, const uint32_t* __restrict__ codes0,
+    const uint8_t* __restrict__ residuals, const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand,
+    const float* __restrict__ Q, int dim, int nbits, int T, size_t cand_cap, float* __restrict__ scores) {
+    constexpr int NG = 8;                                // token groups of 16: T <= 128 on this path (host)
+    extern __shared__ float gw[];                        // [1 << nbits] bucket weights, then the query: T rows of dim + 1 floats
+    const int b = blockIdx.y;
+    const float* Qb = Q + (size_t)b * T * dim;
+    float* qs = gw + (1 << nbits);
+    const int qld = dim + 1;                             // row stride 1 mod 64 banks: lanes r = 0..15 of a read hit 16 banks
+    for (int i = threadIdx.x; i < (1 << nbits); i += blockDim.x) gw[i] = weights[i];
+    for (int i = threadIdx.x; i < T * dim; i += blockDim.x) qs[(i / dim) * qld + i % dim] = Qb[i];
+    __syncthreads();
+    const int n = ncand[b];
+    const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
+    float* out = scores + (size_t)b * cand_cap;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int rows = dim / 8 * nbits;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const int ks = dim >> 2;
+    const int ngroups = (T + 15) >> 4;
+    const int stride = (int)gridDim.x * 4;
+    int j = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint2 hd = j < n ? hdr[j] : make_uint2(0u, 0u);
+    for (; j < n; j += stride) {
+        const uint32_t off = hd.x, len = hd.y;
+        if (j + stride < n) hd = hdr[j + stride];        // the next passage's header flies during this one
+        float mt[NG];
+#pragma unroll
+        for (int tg = 0; tg < NG; ++tg) mt[tg] = kNegInf;
+        uint32_t code = len ? codes0[off + (r < len ? r : len - 1)] : 0u;
+        for (uint32_t e0 = 0; e0 < len; e0 += 16) {
+            const uint32_t e = off + (e0 + r < len ? e0 + r : len - 1);
+            const uint8_t* rp = residuals + (size_t)e * rows;
+            const float* cent = C + (size_t)code * dim + g;
+            if (e0 + 16 < len) code = codes0[off + (e0 + 16 + r < len ? e0 + 16 + r : len - 1)];   // one step ahead
+            float x[KSMAX];
+            uint32_t by[KSMAX];
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s) {          // all loads of the step first
+                const int bit = (4 * s + g) * nbits;
+                by[s] = s < ks ? (uint32_t)rp[bit >> 3] : 0u;
+                x[s] = s < ks ? cent[4 * s] : 0.f;
+            }
+            float p = 0.f;
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s)
+                if (s < ks) {
+                    const int bit = (4 * s + g) * nbits;
+                    const float v = x[s] + gw[(by[s] >> (bit & 7)) & mask];
+                    x[s] = v;
+                    const float sq = v * v;
+                    p = p + sq;
+                }
+            const float a2 = p + __shfl_xor(p, 16, 64);
+            const float n2 = a2 + __shfl_xor(a2, 32, 64);
+            const float den = sqrtf(n2) + FLT_EPSILON;
+            if (__builtin_expect(den > 1e-18f && den < 1e18f, 1)) {
+                const float y = 1.0f / den;
+#pragma unroll
+                for (int s = 0; s < KSMAX; ++s) x[s] = div_by_reciprocal(x[s], den, y);
+            } else {
+#pragma unroll
+                for (int s = 0; s < KSMAX; ++s) x[s] = x[s] / den;
+            }
+#pragma unroll
+            for (int tg = 0; tg < NG; ++tg) {
+                if (tg < ngroups) {
+                    const int t = 16 * tg + r;
+                    const float* qrow = qs + (size_t)(t < T ? t : T - 1) * qld + g;      // staged in LDS once per work-group
+                    float q[KSMAX];
+#pragma unroll
+                    for (int s = 0; s < KSMAX; ++s) q[s] = (s < ks && t < T) ? qrow[4 * s] : 0.f;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KSMAX; ++s)
+                        if (s < ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], q[s], acc, 0, 0, 0);
+                    float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                    m = fmaxf(m, __shfl_xor(m, 16, 64));
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    mt[tg] = fmaxf(mt[tg], m);
+                }
+            }
+        }
+        float total = 0.f;
+#pragma unroll
+        for (int tg = 0; tg < NG; ++tg)
+            if (tg < ngroups)
+                for (int c = 0; c < 16; ++c) {
+                    const float v = __shfl(mt[tg], c, 64);
+                    if (16 * tg + c < T) total = total + v;
+                }
+        if (lane == 0) out[j] = total;
     }
 }
 

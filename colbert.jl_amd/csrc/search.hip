@@ -60,6 +60,7 @@ struct Prof {
 // Per-batch workspace (everything a batch of queries needs besides the resident index).
 struct Workspace {
     int64_t Bcap = 0, Tcap = 0, npcap = 0, kcap = 0;
+    int64_t Ttuned = 0;         // largest query length <= 128 this slot has seen (what the tuned-path buffers are sized for)
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
@@ -154,14 +155,17 @@ int next_pow2(int x) {
 }
 
 int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_t nprobe, int64_t k) {
-    if (B <= w.Bcap && T <= w.Tcap && nprobe <= w.npcap && k <= w.kcap) return CLB_OK;
+    const int64_t t_tuned = T <= 128 ? T : 0;       // queries of up to 128 tokens take the tuned (or batched general) kernels
+    if (B <= w.Bcap && T <= w.Tcap && t_tuned <= w.Ttuned && nprobe <= w.npcap && k <= w.kcap) return CLB_OK;
     CLB_HIP(hipDeviceSynchronize());       // buffers may be in use on any of the caller's streams
     B = std::max(B, w.Bcap); T = std::max(T, w.Tcap);
     nprobe = std::max(nprobe, w.npcap); k = std::max(k, w.kcap);
-    // T is the LARGEST query length this slot has seen; queries of up to 128 tokens take the tuned kernels whatever came
-    // before them on the handle, so the tuned-path buffers are sized for min(T, 128) whenever the index has the tuned
-    // shape -- a longer query earlier on (general path) must not leave them unallocated or short
-    const int64_t Tpad = token_tiles(std::min<int64_t>(T, 128)) * 32;
+    // T is the LARGEST query length this slot has seen; the buffers of the tuned kernels (the fp32 / fp16 score tables:
+    // B K Tpad entries, 2 GB at B = 32, K = 131 072) are sized for the largest query of UP TO 128 tokens it has seen --
+    // a longer query (per-query general path, which touches none of them) neither allocates them for 128 tokens nor
+    // leaves a later short query without them
+    const int64_t Ttuned = std::max(w.Ttuned, t_tuned);
+    const int64_t Tpad = token_tiles(std::max<int64_t>(Ttuned, 1)) * 32;
     // candidates of one query <= sum of the T*nprobe longest IVF lists (and <= n_docs)
     size_t lists = (size_t)std::min<int64_t>(T * nprobe, s->K);
     size_t cap = 0;
@@ -176,8 +180,12 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
     const bool general = s->generic;
     CLB_TRY(w.Qdev.ensure(sizeof(float) * B * T * s->dim));
     // the fp32 T x K score matrix is only materialised by the unfused S1/S2 path (nprobe > 2 or T > 32)
-    if (!general && !(nprobe <= 2 && T <= 32)) CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
-    if (!general) CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * std::min<int64_t>(NPs, 32)));
+    // (the general-shape path scores its centroids into the same matrix whenever its batched kernels apply)
+    const bool general_batched = general && s->dim % 4 == 0 && s->dim <= 256;
+    if (Ttuned > 0 && ((!general && !(nprobe <= 2 && Ttuned <= 32)) || general_batched))
+        CLB_TRY(w.cells.ensure(sizeof(float) * B * s->K * Tpad));
+    if (Ttuned > 0 && (!general || general_batched))
+        CLB_TRY(w.partial.ensure(sizeof(ValIdx) * B * w.topn_blocks * Tpad * std::min<int64_t>(NPs, 32)));
     CLB_TRY(w.sel.ensure(sizeof(int) * B * std::max<int64_t>(Tpad, T) * NPs));
     const size_t bm_bytes = sizeof(uint32_t) * (size_t)B * w.W;
     const bool bm_new = bm_bytes > w.bitmap.bytes || !w.bitmap.p;
@@ -203,13 +211,13 @@ int ensure_workspace(clb_searcher* s, Workspace& w, int64_t B, int64_t T, int64_
         CLB_TRY(w.stats.ensure(sizeof(unsigned long long) * 8));
         CLB_HIP(hipMemset(w.stats.p, 0, sizeof(unsigned long long) * 8));
     }
-    if (s->approx_ok) {
+    if (s->approx_ok && Ttuned > 0) {
         CLB_TRY(w.cells_q.ensure(approx_cells_bytes(B, s->K, Tpad)));
         CLB_TRY(w.rowmask.ensure(sizeof(unsigned long long) * 4 * B * w.cand_cap));
         CLB_TRY(w.eps_pair.ensure(sizeof(float) * B));
         CLB_TRY(w.tokmax.ensure(sizeof(uint16_t) * 32 * B * w.cand_cap));
     }
-    w.Bcap = B; w.Tcap = T; w.npcap = nprobe; w.kcap = k;
+    w.Bcap = B; w.Tcap = T; w.Ttuned = Ttuned; w.npcap = nprobe; w.kcap = k;
     CLB_HIP(hipStreamSynchronize(s->stream));
     return CLB_OK;
 }
@@ -235,6 +243,8 @@ int select_by_sort(clb_searcher* s, Workspace& w, hipStream_t st, const float* c
                    int T, int nprobe, int NP, int* sel_b);
 
 // Candidate generation S1-S3 for B queries on stream st; leaves cand/ncand on the device.
+int mark_and_compact(clb_searcher* s, Workspace& w, hipStream_t st, int B, int T, int Tpad, int NPs, int nprobe);
+
 int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
     const int TT = token_tiles(T), Tpad = TT * 32;
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
@@ -338,6 +348,12 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             hipLaunchKernelGGL(cells_to_half_kernel, dim3(std::max(1, 1024 / B), B), dim3(256), 0, st,
                                w.cells.as<float>(), w.cells_q.as<uint32_t>(), (int)s->K);
     }
+    return mark_and_compact(s, w, st, B, T, Tpad, NPs, nprobe);
+}
+
+// S3: the union of the selected IVF lists as an ascending pid list + passage headers, for B queries (w.sel -> w.cand,
+// w.cand_hdr, w.ncand); shared by the tuned and the general-shape path
+int mark_and_compact(clb_searcher* s, Workspace& w, hipStream_t st, int B, int T, int Tpad, int NPs, int nprobe) {
     static_assert(kScanBlock * kWordsPerThread == 1024, "mark_count_kernel writes 1024-word count blocks");
     const int nslices = (w.nblk_bitmap + kMarkSliceBlocks - 1) / kMarkSliceBlocks;
     const int nslices_big = (w.nblk_bitmap + kMarkSliceBlocksBig - 1) / kMarkSliceBlocksBig;
@@ -452,10 +468,65 @@ int run_retrieve_general(clb_searcher* s, Workspace& w, hipStream_t st, const fl
     return CLB_OK;
 }
 
-// the whole search of B queries on the general-shape path (exact scoring only), one query after the other
+// S1..S3 of B queries on the general-shape path when the shape allows the batched kernels: fp32-MFMA centroid scores in
+// the tuned path's [b][centroid][Tpad] layout, then the tuned path's own selection, marking and compaction
+bool general_batched_ok(const clb_searcher* s, int T) { return s->dim % 4 == 0 && s->dim <= 256 && T <= 128; }
+
+int run_retrieve_general_batched(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe) {
+    const int TT = token_tiles(T), Tpad = TT * 32;
+    const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
+    const dim3 grid((unsigned)((s->K + 63) / 64), (unsigned)B);
+    if (s->dim <= 128)
+        hipLaunchKernelGGL(generic_cells_mfma_kernel<32>, grid, dim3(256), 0, st, s->centroids.as<float>(), dQ, (int)s->dim, (int)s->K,
+                           T, Tpad, w.cells.as<float>());
+    else
+        hipLaunchKernelGGL(generic_cells_mfma_kernel<64>, grid, dim3(256), 0, st, s->centroids.as<float>(), dQ, (int)s->dim, (int)s->K,
+                           T, Tpad, w.cells.as<float>());
+    if (NPs == 2) launch_topn<2>(s, w, st, B, Tpad);
+    else if (NPs == 8) launch_topn<8>(s, w, st, B, Tpad);
+    else if (NPs == 32) launch_topn<32>(s, w, st, B, Tpad);
+    else
+        for (int b = 0; b < B; ++b)
+            CLB_TRY(select_by_sort(s, w, st, w.cells.as<float>() + (size_t)b * s->K * Tpad, 1, (size_t)Tpad, T, nprobe, NPs,
+                                   w.sel.as<int>() + (size_t)b * Tpad * NPs));
+    return mark_and_compact(s, w, st, B, T, Tpad, NPs, nprobe);
+}
+
+// the whole search of B queries on the general-shape path (exact scoring only)
 int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int nprobe, int k,
                        int64_t* d_out_pids, float* d_out_scores, int64_t* d_n_cand) {
     s->prof.chain = nullptr;
+    if (general_batched_ok(s, T) && !CLB_KNOB("CLB_DEBUG_GENERIC_SCALAR", 0)) {
+        // batched: every stage is one launch for the B queries (the loop below: ~12 launches per query, the scoring
+        // kernel a chain of dependent loads)
+        CLB_TRY(run_retrieve_general_batched(s, w, st, dQ, B, T, nprobe));
+        const dim3 grid((unsigned)std::max(64, 2048 / std::max(1, B)), (unsigned)B);
+        const size_t lds = sizeof(float) * (((size_t)1 << s->nbits) + (size_t)T * (s->dim + 1));   // <= 133 KB (T 128, dim 256)
+        if (lds > 64 * 1024) {
+            allow_dynamic_lds(reinterpret_cast<const void*>(generic_score_mfma_fast_kernel<32>), (int)lds);
+            allow_dynamic_lds(reinterpret_cast<const void*>(generic_score_mfma_fast_kernel<64>), (int)lds);
+        }
+        if (s->dim <= 128)
+            hipLaunchKernelGGL(generic_score_mfma_fast_kernel<32>, grid, dim3(256), lds, st, s->centroids.as<float>(),
+                               s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), w.cand_hdr.as<uint2>(),
+                               w.ncand.as<int>(), dQ, (int)s->dim, s->nbits, T, w.cand_cap, w.scores.as<float>());
+        else
+            hipLaunchKernelGGL(generic_score_mfma_fast_kernel<64>, grid, dim3(256), lds, st, s->centroids.as<float>(),
+                               s->weights.as<float>(), s->codes0.as<uint32_t>(), s->residuals.as<uint8_t>(), w.cand_hdr.as<uint2>(),
+                               w.ncand.as<int>(), dQ, (int)s->dim, s->nbits, T, w.cand_cap, w.scores.as<float>());
+        CLB_HIP(hipGetLastError());
+        if (k <= kMaxTopK) {
+            const int kpow2 = next_pow2(k);
+            allow_large_topk_lds();
+            hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * kpow2, st, w.scores.as<float>(),
+                               w.cand.as<uint32_t>(), w.ncand.as<int>(), (const int*)nullptr, (const int*)nullptr, k, kpow2,
+                               w.cand_cap, s->pid_offset, d_out_pids, d_out_scores, w.flags.as<int>(), d_n_cand);
+            CLB_HIP(hipGetLastError());
+        } else {
+            for (int b = 0; b < B; ++b) CLB_TRY(topk_by_sort(s, w, st, b, nullptr, nullptr, k, d_out_pids, d_out_scores, d_n_cand));
+        }
+        return CLB_OK;
+    }
     const int grid = 1024;
     const size_t max_len = (size_t)std::max<int64_t>(s->max_doclen, 1);
     CLB_TRY(w.g_scratch.ensure(sizeof(float) * grid * max_len * s->dim));
