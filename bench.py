@@ -638,12 +638,26 @@ def main():
         q_encs = [torch.empty((B, T, 128), dtype=torch.float32, device=dev) for _ in range(NF)]
         q_part = [torch.empty((Bl, T, 128), dtype=torch.float32, device=dev) for _ in range(NF)] if split else q_encs
         enc_done = [None]          # the encoder has ONE activation workspace: its calls are chained by an event
+        # COLBERT_BENCH_ENCODER_GRAPH=1: the encoder's ~90 launches per batch as ONE captured HIP graph per result buffer
+        # (static id buffers; the step copies its batch's ids in first)
+        enc_graphs = None
+        if os.environ.get("COLBERT_BENCH_ENCODER_GRAPH", "0") != "0":       # measured: 1.39 against 1.38 ms per batch -- no gain, off
+            ids_static = [torch.empty((Bl, T), dtype=torch.int32, device=dev) for _ in range(NF)]
+            for j in range(NF):
+                ids_static[j].copy_(d_ids[0:Bl])
+            mask_static = torch.ones((Bl, T), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            enc_graphs = [enc.capture_query_graph(ids_static[j], mask_static, d_skip, q_part[j]) for j in range(NF)]
 
         def encode_into(i, st):
             off = (i * B) % (n_queries - B + 1) + (rank * Bl if split else 0)
             if enc_done[0] is not None:
                 st.wait_event(enc_done[0])
-            enc.query_embeddings_device(d_ids[off:off + Bl], d_mask[off:off + Bl], d_skip, q_part[i % NF])
+            if enc_graphs is not None:
+                ids_static[i % NF].copy_(d_ids[off:off + Bl])
+                enc_graphs[i % NF].replay()
+            else:
+                enc.query_embeddings_device(d_ids[off:off + Bl], d_mask[off:off + Bl], d_skip, q_part[i % NF])
             ev = torch.cuda.Event()
             ev.record(st)
             enc_done[0] = ev
@@ -702,6 +716,7 @@ def main():
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
                         "unit": f"TFLOP/s ({op16 + ', ' + str(nprod) + ' products per fp32 product' if nprod > 1 else 'fp32 MFMA'})",
                         "frac": round(ach / peak, 4), "ms_per_launch": round(ms1, 4),
+                        "fp32_equivalent_TFLOPs": round(2.0 * M * Nn * Kd / (ms1 * 1e-3) / 1e12, 1),
                         "l2_operand_bytes": int(l2b), "l2_operand_GBps": round(l2b / (ms1 * 1e-3) / 1e9, 1),
                         "note": "l2_operand_bytes = bytes of pre-split 16-bit operand planes the work-groups stream through L2 (tile rule of "
                                 "csrc/encoder.hip); an XCD's L2 delivers ~65 GB/s to one CU, which together with MFMA issue bounds these "
@@ -715,6 +730,7 @@ def main():
                           "synthetic token ids; " + (f"every rank encodes {Bl} of the batch's {B} queries, one all-gather of Q"
                                                      if split else "this rank encodes the whole batch"),
                "roofline": enc_roof,
+               "encoder_launches": "one captured HIP graph per batch" if enc_graphs is not None else "stream launches",
                "note": "encode_queries + search per step; the search consumes the synthetic queries of the headline line"}
         enc.close()
 

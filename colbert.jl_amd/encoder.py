@@ -155,6 +155,23 @@ class BertEncoder:
                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
         return d_out
 
+    def capture_query_graph(self, d_ids, d_mask, d_skiplist, d_out):
+        """The ~90 launches of one `query_embeddings_device` call over STATIC buffers as a HIP graph (torch.cuda.CUDAGraph):
+        write the next batch's ids into `d_ids` (and `d_mask`), `graph.replay()`, read `d_out`.  The library enqueues only
+        kernels on the stream it is handed, so the forward can be captured; a first, uncaptured call sizes the workspaces."""
+        import torch
+        dev = d_ids.device
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.query_embeddings_device(d_ids, d_mask, d_skiplist, d_out)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.query_embeddings_device(d_ids, d_mask, d_skiplist, d_out)
+        return graph
+
     def check_last_ids(self):
         """Raise BoundsError if the last (asynchronous, device-resident) encode saw a token id outside the vocabulary --
         query_embeddings_device clamps such ids because it cannot report them when it is enqueued."""
