@@ -302,8 +302,8 @@ def encoder_l2_operand_bytes(M, N, Kd, gemm="f16x3"):
         bm, bn, ks = 128, 128, 1
     else:
         bm, bn, ks = 64, 64, 1
-        min_slice = 192 if wgs(64, 64) < 64 else 256
-        while ks < 8 and wgs(64, 64) * ks < 512 and Kd % (ks * 2 * 32) == 0 and Kd // (ks * 2) >= min_slice:
+        min_slice = 192 if wgs(64, 64) < 64 else 384
+        while ks < 8 and wgs(64, 64) * ks < 768 and Kd % (ks * 2 * 32) == 0 and Kd // (ks * 2) >= min_slice:
             ks *= 2
     return wgs(bm, bn) * (bm + bn) * Kd * bytes_per_el, (bm, bn, ks)
 

@@ -256,8 +256,12 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // work-group.  Narrow outputs (N = hidden) are split over K until every CU has three work-groups.
         c = {64, 64, 2, 1};
         if (part) {
-            const int min_slice = wgs(64, 64) < 64 ? 192 : 256;
-            while (c.ks < 8 && wgs(64, 64) * c.ks < 512 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= min_slice) c.ks *= 2;
+            // K slices of at least 12 steps (6 for the few-tile hidden -> dim projection), and a three-tile ring for the short
+            // loops of a split product (in-encoder sweep, f16x3: attention output 64x64x3 ks 2: 18.3 us against 20.2 at x2 ks 4;
+            // FFN-out x3 ks 4: 32.8 against 33.5; ks 2 or 8 there: 45 / 42)
+            const int min_slice = wgs(64, 64) < 64 ? 192 : 384;
+            while (c.ks < 8 && wgs(64, 64) * c.ks < 768 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= min_slice) c.ks *= 2;
+            if (c.ks > 1) c.stages = 3;
         }
     }
     if (!part || K % (c.ks * 32) != 0) c.ks = 1;
