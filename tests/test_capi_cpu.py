@@ -91,6 +91,74 @@ def test_round3_entry_points_check_their_arguments_first():
     assert b"null" in l.clb_last_error()
 
 
+def test_round4_entry_points_check_their_arguments_first():
+    """The device-resident index-build entry points of round 4: argument contracts before any device work (the codec
+    handle mirrors compress's DomainErrors, residual.jl:523-525), no CPU fallback behind them."""
+    import ctypes as C
+    l = clb.lib()
+    null = C.c_void_p()
+    out = C.c_void_p()
+    cent = np.zeros((128, 4), np.float32, order="F")
+    cut = np.zeros(3, np.float32)
+    i64 = C.c_int64
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert l.clb_codec_create(0, i64(128), 2, i64(4), p(cent), p(cut), i64(3), None) == 4                 # out is null
+    assert l.clb_codec_create(0, i64(7), 2, i64(4), p(cent), p(cut), i64(3), C.byref(out)) == 2           # dims % 8
+    assert l.clb_codec_create(0, i64(128), 2, i64(4), p(cent), p(cut), i64(2), C.byref(out)) == 2         # 2^nbits - 1 cutoffs
+    assert l.clb_codec_create(0, i64(128), 2, i64(0), p(cent), p(cut), i64(3), C.byref(out)) == 4         # no centroids
+    assert l.clb_codec_compress_device(null, None, i64(5), None, None, None) == 4
+    assert l.clb_codec_destroy(null) == 0
+    assert l.clb_build_ivf_device(0, None, i64(-1), i64(4), None, None, None) == 4
+    assert l.clb_build_ivf_device(0, None, i64(5), i64(4), None, None, None) == 4                          # null arrays
+    assert l.clb_kmeans_shard_get_assignments(null, None) == 4
+    assert l.clb_kmeans_shard_create_device(0, None, i64(128), i64(5), i64(0), i64(1000), C.byref(out)) == 1   # K < 1
+    if l.clb_device_count() == 0:      # valid arguments reach the device check: HIP error, nothing computed on the host
+        assert l.clb_codec_create(0, i64(128), 2, i64(4), p(cent), p(cut), i64(3), C.byref(out)) == 10
+        assert l.clb_kmeans_shard_create_device(0, p(cent), i64(128), i64(4), i64(2), i64(1000), C.byref(out)) == 10
+        idx = clb.synthetic.make_index(0, 20, K=8)
+        dl = np.ascontiguousarray(idx["doclens"], np.int64); il = np.ascontiguousarray(idx["ivf_lengths"], np.int64)
+        w = np.ascontiguousarray(idx["bucket_weights"], np.float32)
+        assert l.clb_searcher_create_device(0, i64(128), 2, i64(8), None, p(w), i64(dl.size), p(dl), i64(int(dl.sum())), None, None,
+                                            None, p(il), i64(0), C.byref(out)) == 10
+
+
+def test_plane_layout_and_xcd_tile_mapping():
+    """Host restatement of two pieces of the encoder's plane GEMM (csrc/encoder_kernels.hpp): the K-blocked plane index is
+    a bijection onto [0, rows * K), and the XCD-aware work-group -> tile map covers every (K slice, n tile, m tile) exactly
+    once with every XCD owning a contiguous range of the combined (slice, n tile) index."""
+    def plane_index(row, k, rows):
+        return (k >> 5) * rows * 32 + row * 32 + (k & 31)
+    for rows, K in ((5, 64), (64, 96), (33, 768)):
+        seen = {plane_index(r, k, rows) for r in range(rows) for k in range(K)}
+        assert seen == set(range(rows * K))
+        assert all(plane_index(r, 32 * b + 1, rows) - plane_index(r, 32 * b, rows) == 1 for r in range(rows) for b in range(K // 32))
+
+    def grid(M, N, bm, bn, ks):
+        TM, TN = -(-M // bm), -(-N // bn)
+        C = TN * ks
+        widest = max((x + 1) * C // 8 - x * C // 8 for x in range(8))
+        return 8 * widest * TM
+
+    def tile_of(b, M, N, bm, bn, ks):
+        TM, TN = -(-M // bm), -(-N // bn)
+        C = TN * ks
+        x, j = b & 7, b >> 3
+        c_lo, c_hi = x * C // 8, (x + 1) * C // 8
+        c = c_lo + j // TM
+        if c >= c_hi:
+            return None
+        return (c // TN, c % TN, j % TM, x)
+    for M, N, bm, bn, ks in ((1024, 2304, 64, 64, 1), (1024, 768, 64, 64, 4), (32, 3072, 64, 64, 8), (19200, 768, 128, 128, 1),
+                             (100, 130, 64, 64, 2)):
+        tiles = [tile_of(b, M, N, bm, bn, ks) for b in range(grid(M, N, bm, bn, ks))]
+        live = [t for t in tiles if t is not None]
+        TM, TN = -(-M // bm), -(-N // bn)
+        assert sorted((z, n, m) for z, n, m, _ in live) == sorted((z, n, m) for z in range(ks) for n in range(TN) for m in range(TM))
+        for x in range(8):                                   # one contiguous c range per XCD
+            cs = sorted({z * TN + n for z, n, m, xx in live if xx == x})
+            assert cs == list(range(cs[0], cs[0] + len(cs))) if cs else True
+
+
 def test_host_planning_helpers_match_oracle(oracle):
     for n in (1, 10, 1000, 141431, 10 ** 6):
         assert clb.codec.num_sampled_pids(n) == oracle.num_sampled_pids(n)
