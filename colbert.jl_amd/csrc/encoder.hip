@@ -662,6 +662,29 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
     return CLB_OK;
 }
 
+int clb_encode_docs_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
+                           const int64_t* d_skiplist, int64_t n_skip, float* d_out_embs, int64_t* d_doclens, int64_t* d_n_out,
+                           void* hip_stream) {
+    if (!e || !d_integer_ids || !d_bitmask || !d_out_embs || !d_doclens || !d_n_out) return fail(CLB_EARGUMENT, "null argument");
+    if (L < 1 || N < 1) return fail(CLB_EARGUMENT, "empty batch");
+    if (L > e->max_pos) return fail(CLB_EBOUNDS, "sequence length %lld exceeds max_position_embeddings %lld", (long long)L, (long long)e->max_pos);
+    CLB_TRY(use_device(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    CLB_TRY(e->qmask.ensure((size_t)L * N));
+    CLB_TRY(e->qlens.ensure(sizeof(int64_t) * N));          // here: the exclusive scan of the document lengths
+    CLB_TRY(forward(e, L, N, st, d_integer_ids, d_bitmask, /*sync=*/false));
+    {
+        EncTimed tm(e, ES_EPILOGUE, st);
+        hipLaunchKernelGGL(epilogue_mask_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, d_integer_ids, (int)L, (int)N, d_skiplist,
+                           (int)n_skip, e->qmask.as<uint8_t>(), d_doclens);
+        hipLaunchKernelGGL(doclens_scan_kernel, dim3(1), dim3(64), 0, st, d_doclens, (int)N, e->qlens.as<int64_t>(), d_n_out);
+        hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
+                           (int)L, (int)N, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>(), d_out_embs, e->err.as<int>());
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
 int clb_encoder_check_last_ids(clb_encoder* e) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     if (!e->err.p) return CLB_OK;                     // nothing has been encoded yet

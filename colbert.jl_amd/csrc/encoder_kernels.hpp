@@ -1243,6 +1243,24 @@ static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const fl
     }
 }
 
+// exclusive prefix sum of the N document lengths (one wave; N is a batch of passages) + their total
+static __global__ __launch_bounds__(64) void doclens_scan_kernel(const int64_t* __restrict__ doclens, int N,
+                                                                 int64_t* __restrict__ start, int64_t* __restrict__ total) {
+    const int lane = threadIdx.x;
+    const int per = (N + 63) / 64;
+    int64_t mine = 0;
+    for (int i = lane * per; i < N && i < (lane + 1) * per; ++i) mine += doclens[i];
+    int64_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    int64_t run = incl - mine;
+    for (int i = lane * per; i < N && i < (lane + 1) * per; ++i) { start[i] = run; run += doclens[i]; }
+    if (lane == 63) *total = incl;
+}
+
 // (N*L, dim) row-major projection output -> the reference's (dim, L, N) column-major array is the same memory:
 // element (d, l, n) at d + dim*(l + L*n) = row (l + L*n), column d.  So no transpose kernel is needed.
 

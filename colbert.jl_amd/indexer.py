@@ -56,12 +56,18 @@ def train(sample, heldout, num_partitions: int, nbits: int, kmeans_niters: int, 
     return centroids, cut, w, avg
 
 
-def index(indexer: Indexer) -> Optional[str]:
-    """index(indexer) (indexing.jl:63-147)."""
+def index(indexer: Indexer, device_resident: Optional[bool] = None) -> Optional[str]:
+    """index(indexer) (indexing.jl:63-147).  With an encoder that can leave its embeddings on the device
+    (BertEncoder.doc_embeddings_device) the build runs through index_device -- no embedding crosses PCIe -- and writes the
+    same files (`device_resident=False` forces the host-buffer route; both draw the same numbers from indexer.rng)."""
     cfg = indexer.config
     path = cfg.index_path
     if os.path.isdir(path):                                  # indexing.jl:64-67
         return None
+    if device_resident is None:
+        device_resident = hasattr(indexer.encoder, "doc_embeddings_device")
+    if device_resident:
+        return _index_through_device(indexer)
     n_docs = len(indexer.collection)
     # sample -> embeddings (collection_indexer.jl:17-24, 56-79)
     n_s = codec.num_sampled_pids(n_docs)
@@ -102,6 +108,51 @@ def index(indexer: Indexer) -> Optional[str]:
     return path
 
 
+def _index_through_device(indexer: Indexer) -> str:
+    """index() over index_device: the encoder's output, the sample, the codes and the residuals stay in HBM; what is
+    written is the reference's directory (sample, sample_heldout, plan.json, config.json, the codec, per chunk codes /
+    residuals / doclens / metadata, ivf, ivf_lengths -- indexing.jl:84-147)."""
+    cfg = indexer.config
+    path = cfg.index_path
+    source = EncoderSource(indexer.encoder, indexer.collection, indexer.device)
+    os.makedirs(path)
+    state = {}
+
+    def on_sample(sample, heldout, plan):
+        storage._save(os.path.join(path, "sample"), np.asfortranarray(sample.cpu().numpy().T))
+        storage._save(os.path.join(path, "sample_heldout"), np.asfortranarray(heldout.cpu().numpy().T))
+        storage.save_json(path, "plan.json", plan)
+        cfg.save(path)
+        state["plan"] = plan
+
+    ix, _ = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
+                         nranks=cfg.nranks, on_sample=on_sample)
+    plan = state["plan"]
+    storage.save_codec(path, np.asfortranarray(ix["centroids"].cpu().numpy().T), ix["bucket_cutoffs"], ix["bucket_weights"],
+                       ix["avg_residual"])
+    n_docs = len(indexer.collection)
+    off = np.concatenate([[0], np.cumsum(ix["doclens"])])
+    counts = []
+    for ci, start in enumerate(range(0, n_docs, plan["chunksize"]), start=1):
+        end = min(n_docs, start + plan["chunksize"])
+        a, b = int(off[start]), int(off[end])
+        storage.save_chunk(path, ix["codes"][a:b].cpu().numpy().view(np.uint32),
+                           np.asfortranarray(ix["residuals"][a:b].cpu().numpy().T), ci, start + 1, ix["doclens"][start:end])
+        counts.append(b - a)
+    total, offsets = codec.collect_embedding_id_offset(counts)
+    plan["num_embeddings"] = total
+    plan["embeddings_offsets"] = [int(o) for o in offsets]
+    storage.save_json(path, "plan.json", plan)
+    for ci, o in enumerate(offsets[: len(counts)], start=1):
+        meta = storage.load_json(path, f"{ci}.metadata.json")
+        meta["embedding_offset"] = int(o)
+        storage.save_json(path, f"{ci}.metadata.json", meta)
+    storage._save(os.path.join(path, "ivf"), ix["ivf"].cpu().numpy())
+    storage._save(os.path.join(path, "ivf_lengths"), np.asarray(ix["ivf_lengths"]))
+    assert storage.check_all_files_are_saved(path)
+    return path
+
+
 # ---- the same build with every large array resident in HBM ----------------------------------------------------------
 class DeviceEmbeddingSource:
     """Stands in for the BERT checkpoint when the collection's fp32 embeddings do not fit host memory (1 M passages:
@@ -116,9 +167,91 @@ class DeviceEmbeddingSource:
     def chunk(self, start: int, end: int):
         raise NotImplementedError
 
+    def sample(self, pids):
+        """The embeddings of the passages `pids` (sorted, 0-based), (n, dim) on the device.  Default: cut them out of the
+        chunks they fall in; a source that can encode a list of passages directly overrides this (encode only the sample,
+        as the reference does: collection_indexer.jl:56-79)."""
+        return _sample_from_chunks(self, pids)
+
+
+def _sample_from_chunks(source, pids, step: Optional[int] = None):
+    import torch
+    pids = np.asarray(pids, dtype=np.int64)
+    doclens = np.asarray(source.doclens, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    n_docs = doclens.size
+    step = int(step or min(25000, 1 + n_docs))
+    out = torch.empty((int(doclens[pids].sum()), source.dim), dtype=torch.float32, device=source.device)
+    fill = 0
+    for start in range(0, n_docs, step):
+        end = min(n_docs, start + step)
+        mine = pids[(pids >= start) & (pids < end)]
+        if mine.size == 0:
+            continue
+        x = source.chunk(start, end)
+        rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in mine])
+        out[fill:fill + rows.size] = x[torch.from_numpy(rows).to(source.device)]
+        fill += rows.size
+        del x
+    assert fill == out.shape[0]
+    return out
+
+
+class EncoderSource(DeviceEmbeddingSource):
+    """The BERT checkpoint as a device-resident source: passages are tokenised on the host in batches of index_bsize
+    (encode_passages, checkpoint.jl:159-189) and encoded, masked, normalised and compacted on the device
+    (BertEncoder.doc_embeddings_device = clb_encode_docs_device).  `doclens` needs no forward pass: a passage keeps the
+    tokens that are attended to and not in the skiplist (checkpoint.jl:37-43), which tokenisation alone decides."""
+
+    def __init__(self, encoder, collection, device: int = 0):
+        import torch
+        self.encoder = encoder
+        self.collection = collection
+        self.dim = encoder.dim
+        self.device = torch.device("cuda", device)
+        cfg = encoder.config
+        self.skiplist = np.asarray(encoder.tokenizer.doc_skiplist(cfg.mask_punctuation), dtype=np.int64)
+        self._d_skip = torch.from_numpy(self.skiplist).to(self.device)
+        lens = []
+        for start in range(0, len(collection), cfg.index_bsize):
+            ids, mask = self._tensorize(collection[start:start + cfg.index_bsize])
+            lens.append((mask.astype(bool) & ~np.isin(ids, self.skiplist)).sum(axis=0))
+        self.doclens = np.concatenate(lens).astype(np.int64) if lens else np.zeros(0, np.int64)
+
+    def _tensorize(self, passages):
+        from . import tokenization
+        cfg = self.encoder.config
+        return tokenization.tensorize_docs(cfg.doc_token_id, self.encoder.tokenizer, passages, cfg.doc_maxlen)   # (L, N)
+
+    def encode(self, passages):
+        """encode_passages with the result left on the device -> (n, dim) float32 CUDA tensor, doclens (host)."""
+        import torch
+        bs = self.encoder.config.index_bsize
+        parts, lens = [], []
+        for start in range(0, len(passages), bs):
+            ids, mask = self._tensorize(passages[start:start + bs])
+            d_ids = torch.from_numpy(np.ascontiguousarray(ids.T, dtype=np.int32)).to(self.device)
+            d_mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).T.astype(np.uint8))).to(self.device)
+            x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip)
+            parts.append(x); lens.append(dl)
+        self.encoder.check_last_ids()
+        if not parts:
+            return torch.empty((0, self.dim), dtype=torch.float32, device=self.device), np.zeros(0, np.int64)
+        return (torch.cat(parts) if len(parts) > 1 else parts[0]), torch.cat(lens).cpu().numpy()
+
+    def chunk(self, start: int, end: int):
+        x, dl = self.encode(self.collection[start:end])
+        assert np.array_equal(dl, self.doclens[start:end])
+        return x
+
+    def sample(self, pids):
+        x, dl = self.encode([self.collection[int(p)] for p in pids])
+        assert np.array_equal(dl, self.doclens[np.asarray(pids, dtype=np.int64)])
+        return x
+
 
 def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: int = 20, chunksize=None, seed: int = 0,
-                 num_partitions=None, log=None):
+                 num_partitions=None, log=None, rng=None, nranks: int = 1, on_sample=None):
     """The array stages of index() (src/indexing.jl:63-147) with the sample, the codes, the residuals and the IVF kept in
     HBM: sample pids -> gather their embeddings -> shuffle, held-out split -> setup -> k-means (the device-resident shard
     handle) -> codec statistics -> per chunk: compress (resident codec) -> _build_ivf.  Returns (index, record): `index`
@@ -132,7 +265,7 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     n_docs = doclens.size
     dim = source.dim
     dev = source.device
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed) if rng is None else rng
     off = np.concatenate([[0], np.cumsum(doclens)])
     n_emb = int(off[-1])
     rec = {"passages": int(n_docs), "embeddings": n_emb}
@@ -148,21 +281,9 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     t0 = time.time()
     n_s = codec.num_sampled_pids(n_docs)
     sampled = np.unique(rng.integers(0, n_docs, size=n_s))
-    plan_chunk = int(chunksize or min(25000, 1 + n_docs))
     n_sample = int(doclens[sampled].sum())
-    sample = torch.empty((n_sample, dim), dtype=torch.float32, device=dev)
-    fill = 0
-    for start in range(0, n_docs, plan_chunk):
-        end = min(n_docs, start + plan_chunk)
-        mine = sampled[(sampled >= start) & (sampled < end)]
-        if mine.size == 0:
-            continue
-        x = source.chunk(start, end)
-        rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in mine])
-        sample[fill:fill + rows.size] = x[torch.from_numpy(rows).to(dev)]
-        fill += rows.size
-        del x
-    assert fill == n_sample
+    sample = source.sample(sampled) if hasattr(source, "sample") else _sample_from_chunks(source, sampled, chunksize)
+    assert sample.shape[0] == n_sample
     avg_doclen_est = float(np.float32(doclens[sampled].sum() / max(sampled.size, 1)))
     # held-out split (collection_indexer.jl:81-91): shuffle the columns, the last heldout_size go to the held-out set
     perm = torch.from_numpy(rng.permutation(n_sample)).to(dev)
@@ -171,8 +292,10 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     h = codec.heldout_size(n_sample)
     heldout = sample[n_sample - h:]
     sample = sample[:n_sample - h]
-    plan = codec.setup(n_docs, avg_doclen_est, sample.shape[0], chunksize, 1)
+    plan = codec.setup(n_docs, avg_doclen_est, sample.shape[0], chunksize, nranks)
     K = int(num_partitions or plan["num_partitions"])
+    if on_sample is not None:                                # index(): the files written before training (indexing.jl:84-96)
+        on_sample(sample, heldout, plan)
     init = sample[torch.from_numpy(rng.permutation(sample.shape[0])[:K]).to(dev)].contiguous()
     rec.update({"sample_points": int(sample.shape[0]), "heldout": int(h), "K": K, "chunksize": plan["chunksize"]})
     tick("sample_and_split_s", t0)

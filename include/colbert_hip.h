@@ -339,6 +339,14 @@ int clb_encode_queries(clb_encoder* e, const int32_t* integer_ids, const uint8_t
  * cannot be reported from an asynchronous call: it is clamped (use clb_encode_queries to validate inputs). */
 int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
                               const int64_t* d_skiplist, int64_t n_skip, float* d_out, void* hip_stream);
+/* _doc_embeddings_and_doclens  (checkpoint.jl:27-52) with every pointer on the encoder's device, enqueued on `hip_stream`
+ * and not waited for: forward, skiplist mask, normalisation, doclens and compaction without a host round trip -- the chunk
+ * loop of index() (src/indexing.jl:102-118) then hands the embeddings of a batch straight to clb_codec_compress_device.
+ * d_out_embs: capacity (dim, L*N); the first *d_n_out columns are valid (read d_n_out / d_doclens back when needed).
+ * Ids outside the vocabulary are clamped and reported by clb_encoder_check_last_ids, like clb_encode_queries_device. */
+int clb_encode_docs_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
+                           const int64_t* d_skiplist, int64_t n_skip, float* d_out_embs, int64_t* d_doclens,
+                           int64_t* d_n_out, void* hip_stream);
 /* The asynchronous device path cannot report an id outside the vocabulary when it is enqueued (it clamps): this call
  * waits for the device and returns the BoundsError of ANY device-path encode since the previous check (the flag is
  * sticky: set by the kernels, cleared by this call), or CLB_EDOMAIN when an encode produced non-finite embeddings (the

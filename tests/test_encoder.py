@@ -332,3 +332,42 @@ def test_text_to_search_end_to_end(tmp_path, tok, which):
     with pytest.raises(clb.BoundsError):
         searcher.text_search(n + 1, graph=False)(query)
     searcher.close(); enc.close()
+
+
+@pytest.mark.gpu
+def test_index_device_resident_route_writes_the_same_files(tmp_path, tok):
+    """index() with the encoder's output left in HBM (clb_encode_docs_device -> index_device) against the host-buffer
+    route: the same embeddings and doclens per batch, and byte-identical index directories."""
+    import filecmp
+    torch, cfg, bert, linear = _random_bert(hidden=64, layers=2, heads=4, inter=128, vocab=len(VOCAB), max_pos=64, dim=128, seed=9)
+    from colbert_jl_amd.encoder import pack_weights
+    from colbert_jl_amd.indexer import EncoderSource
+    bcfg = cfg.to_dict()
+    words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with", "many", "words", "query", "colbert"]
+    rng = np.random.default_rng(11)
+    collection = [" ".join(rng.choice(words, size=rng.integers(1, 14))) + rng.choice([".", "!", "", " , ok"]) for _ in range(23)]
+    paths = {}
+    for route in ("host", "device"):
+        config = clb.ColBERTConfig(index_path=str(tmp_path / route), doc_maxlen=24, query_maxlen=12, index_bsize=5,
+                                   chunksize=7, kmeans_niters=3, nbits=2)
+        enc = clb.BertEncoder(pack_weights(_state(bert, linear), bcfg, 128), bcfg, dim=128, tokenizer=tok, config=config)
+        if route == "device":
+            src = EncoderSource(enc, collection, 0)
+            want, want_dl = enc.encode_passages(collection)
+            assert np.array_equal(src.doclens, want_dl)                 # doclens from tokenisation alone
+            got, got_dl = src.encode(collection)
+            assert np.array_equal(got_dl, want_dl)
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), np.ascontiguousarray(want.T).view(np.uint32))
+            x = src.sample(np.array([2, 3, 17]))
+            ref = enc.encode_passages([collection[i] for i in (2, 3, 17)])[0]
+            assert np.array_equal(x.cpu().numpy().view(np.uint32), np.ascontiguousarray(ref.T).view(np.uint32))
+        indexer = clb.Indexer(config, encoder=enc, collection=collection, seed=3)
+        assert clb.index(indexer, device_resident=(route == "device")) == config.index_path
+        paths[route] = config.index_path
+        enc.close()
+    names = sorted(os.listdir(paths["host"]))
+    assert names == sorted(os.listdir(paths["device"])) and len(names) >= 12
+    for n in names:
+        if n == "config.json":
+            continue                                                    # holds its own index_path
+        assert filecmp.cmp(os.path.join(paths["host"], n), os.path.join(paths["device"], n), shallow=False), n
