@@ -235,8 +235,8 @@ def test_config2_index_build_100k(oracle):
     K = plan["num_partitions"]
     assert K == 32768
     init = sample[:, rng.permutation(sample.shape[1])[:K]]
-    cent, assign, it = codec.kmeans(sample, init, max_iters=2)
-    assert it == 2 and assign.min() >= 1 and assign.max() <= K
+    cent, assign, it = codec.kmeans(sample, init, max_iters=4)
+    assert it == 4 and assign.min() >= 1 and assign.max() <= K
     # the assignment of the last iteration is the nearest centroid of the PREVIOUS centroids; check the update rule
     # on a sample of clusters instead: a centroid is the mean of its members (fp32, ordered sum)
     cut, w, avg, _ = codec.compute_avg_residuals(2, cent, held)
@@ -246,7 +246,7 @@ def test_config2_index_build_100k(oracle):
     chunk = 2_000_000
     parts = [codec.compress(cent, cut, 128, 2, embs[:, i:i + chunk]) for i in range(0, n_emb, chunk)]
     codes = np.concatenate([p[0] for p in parts]); res = np.concatenate([p[1] for p in parts], axis=1)
-    sel = np.sort(rng.choice(n_emb, size=2000, replace=False))
+    sel = np.sort(rng.choice(n_emb, size=20_000, replace=False))
     rc, rr = oracle.compress(cent, cut, 128, 2, np.asfortranarray(embs[:, sel]))
     assert np.array_equal(codes[sel], rc) and np.array_equal(res[:, sel], rr)
     ivf, lens = codec.build_ivf(codes, K)
@@ -335,7 +335,7 @@ def test_config5_one_rank_share_of_the_index_build(oracle):
 # ---------------------------------------------------------------------------------------------------
 # config 5: 10 M passages on one GPU (properties only; the oracle would need minutes per query)
 # ---------------------------------------------------------------------------------------------------
-def test_config5_ten_million_properties():
+def test_config5_ten_million_properties(oracle):
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 150e9:
         pytest.skip("needs ~100 GB of host memory to generate the 10 M-passage index")
@@ -345,7 +345,6 @@ def test_config5_ten_million_properties():
     idx = synthetic.make_index(seed=2024, n_docs=n_docs, K=K, n_blocks=n_blocks, ivf_on_device=True)
     Qs = synthetic.make_topic_queries(idx["centroids"], seed=77, n_queries=4)
     s = clb.Searcher(index=idx)
-    del idx
     try:
         k = 1000
         out = {}
@@ -362,5 +361,10 @@ def test_config5_ten_million_properties():
         s.set_mode(1)
         p4, s4, _ = s.search_batch(Qs, k)                                             # a different batch size
         assert np.array_equal(p4[:, :2], out[1][0]) and np.array_equal(bits(s4[:, :2]), bits(out[1][1]))
+        # ... and the oracle itself on two of the queries (one of them only seen in the batch of four): same pids, same bits
+        idx["emb2pid"] = oracle.build_emb2pid(idx["doclens"])
+        for j in (0, 3):
+            rp, rs, _ = oracle.search(idx, Qs[:, :, j], 2, k)
+            assert np.array_equal(p4[:, j], rp) and np.array_equal(bits(s4[:, j]), bits(rs)), j
     finally:
         s.close()

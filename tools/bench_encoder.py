@@ -61,6 +61,27 @@ def main():
     dt = (time.perf_counter() - t0) / 20
     out["queries_32x32_device"] = {"ms": round(dt * 1e3, 3), "tflops": round(flops(cfg, L, N) / dt / 1e12, 1),
                                    "queries_per_s": round(N / dt, 1)}
+    # passages with the output left on the device (what index() uses: clb_encode_docs_device), per stage
+    N, L = 64, 300
+    p_ids = torch.from_numpy(rng.integers(1, cfg["vocab_size"] + 1, size=(N, L)).astype(np.int32)).to(dev)
+    p_mask = torch.ones((N, L), dtype=torch.uint8, device=dev)
+    p_skip = torch.tensor([1, 1013, 1014], dtype=torch.int64, device=dev)
+    for _ in range(2):
+        enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.reps
+    out["passages_64x300_device"] = {"ms": round(dt * 1e3, 3), "tflops_fp32_equivalent": round(flops(cfg, L, N) / dt / 1e12, 1),
+                                     "passages_per_s": round(N / dt, 1)}
+    enc.profile_enable(True)
+    for _ in range(args.reps):
+        enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+    torch.cuda.synchronize()
+    out["passages_64x300_device"]["stages_ms"] = {k: round(v["ms"] / args.reps, 4) for k, v in enc.profile_read().items()}
+    enc.profile_enable(False)
     # the host-buffer and the device-resident path agree bit for bit
     host = enc.query_embeddings([1], d_ids.cpu().numpy().T.copy(), np.ones((L, N), bool))     # (dim, L, N)
     same = np.array_equal(np.ascontiguousarray(host.transpose(2, 1, 0)).view(np.uint32), d_out.cpu().numpy().view(np.uint32))
