@@ -206,20 +206,29 @@ static const PlanCfg* plan_override(int role) {
     return have[role] ? &cfg[role] : nullptr;
 }
 
+// COLBERT_ENC_GEMM_FORM=1: the first form of the plane GEMM (element-wise epilogue, LDS reads not pipelined) -- comparison runs
+static bool planes_first_form() {
+    static const bool v = [] { const char* e = getenv("COLBERT_ENC_GEMM_FORM"); return e && atoi(e) == 1; }();
+    return v;
+}
+
 template <int NS, bool F16>
 bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
     const size_t lds = (size_t)c.stages * NS * (c.bm + c.bn) * 64;
-#define CLB_GP_CASE(BM_, BN_, ST_, WM_, WN_)                                                                          \
+    const bool second = g.N % 4 == 0 && !planes_first_form();
+#define CLB_GP_CASE(BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                              \
     if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
-        if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(gemm_planes_kernel<2, 2, WM_, WN_, NS, ST_, 0, F16>), (int)lds); \
-        hipLaunchKernelGGL((gemm_planes_kernel<2, 2, WM_, WN_, NS, ST_, 0, F16>), grid, dim3(256), lds, st, g);       \
+        auto kern = second ? gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16> : gemm_planes_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16>; \
+        if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);                        \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WGM_ * WGN_), lds, st, g);                                           \
         return true;                                                                                                  \
     }
-    CLB_GP_CASE(64, 64, 2, 1, 1) CLB_GP_CASE(64, 64, 3, 1, 1) CLB_GP_CASE(64, 64, 4, 1, 1)
-    CLB_GP_CASE(64, 128, 2, 1, 2) CLB_GP_CASE(64, 128, 3, 1, 2)
-    CLB_GP_CASE(128, 64, 2, 2, 1) CLB_GP_CASE(128, 64, 3, 2, 1)
-    CLB_GP_CASE(128, 128, 2, 2, 2) CLB_GP_CASE(128, 128, 3, 2, 2)
+    CLB_GP_CASE(64, 64, 2, 2, 2, 1, 1) CLB_GP_CASE(64, 64, 3, 2, 2, 1, 1) CLB_GP_CASE(64, 64, 4, 2, 2, 1, 1)
+    CLB_GP_CASE(64, 128, 2, 2, 2, 1, 2) CLB_GP_CASE(64, 128, 3, 2, 2, 1, 2)
+    CLB_GP_CASE(128, 64, 2, 2, 2, 2, 1) CLB_GP_CASE(128, 64, 3, 2, 2, 2, 1)
+    CLB_GP_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GP_CASE(128, 128, 3, 2, 2, 2, 2)
+    if (NS == 2) { CLB_GP_CASE(128, 256, 2, 2, 4, 2, 2) }        // eight waves; three planes would need 144 KB
 #undef CLB_GP_CASE
     return false;
 }
@@ -247,7 +256,10 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         const int tn = (N + 63) / 64;
         while (c.ks < 32 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= 96 && tn * c.ks * 2 <= 1024) c.ks *= 2;
     }
-    else if (wgs(128, 128) >= 1024) c = {128, 128, 2, 1};          // long activations (passage batches)
+    else if (wgs(128, 128) >= 512)
+        // long activations (passage batches; tools/microbench/gemm_planes_bigm_bench.hip): enough tiles to fill the chip, the
+        // widest tile that still leaves two waves per SIMD -- 128 x 256 on eight waves (two planes: 96 KB of LDS), else 128 x 128
+        c = (NS == 2 && wgs(128, 256) >= 384 && N % 4 == 0 && !planes_first_form()) ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
     else {
         // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured
         // (tools/microbench/gemm_planes_bench.hip): the loop is bound by MFMA issue (three 32 x 32 tiles per SIMD at the

@@ -571,13 +571,28 @@ static __global__ __launch_bounds__(256) void split_planes_kernel(const float* _
 
 // number of work-groups to launch for gemm_planes_kernel's XCD-aware mapping (1-D grid)
 inline int gemm_planes_grid(int M, int N, int bm, int bn, int ksplit) {
-    const int TM = (M + bm - 1) / bm, TN = (N + bn - 1) / bn, Ctot = TN * ksplit;
-    int widest = 0;
-    for (int x = 0; x < 8; ++x) {
-        const int w = (int)((int64_t)(x + 1) * Ctot / 8) - (int)((int64_t)x * Ctot / 8);
-        widest = w > widest ? w : widest;
-    }
-    return 8 * widest * TM;
+    const int TM = (M + bm - 1) / bm, TN = (N + bn - 1) / bn;
+    const int64_t T = (int64_t)TM * TN * ksplit;
+    return (int)(8 * ((T + 7) / 8));
+}
+
+// work-group -> (K slice z, n tile, m tile): XCD x (= blockIdx.x & 7 under round-robin placement: a speed heuristic, never
+// needed for correctness) owns the contiguous range [x T / 8, (x + 1) T / 8) of the linear tile index t = c TM + m, c = the
+// combined (K slice, n tile) index: every XCD gets T / 8 tiles to within one (dealing whole c ranges left XCDs with 3 against
+// 2 n tiles on 18-tile-wide outputs, and two of eight XCDs idle on the 6-tile-wide ones of a passage batch), its L2 holds the
+// weights of its ~TN / 8 n tiles, and co-resident work-groups share a weight tile.  Surplus work-groups return at once.
+__device__ __forceinline__ bool gemm_planes_tile(int M, int N, int BM, int BN, int ksplit, int& z, int& m0, int& n0) {
+    const int TM = (M + BM - 1) / BM, TN = (N + BN - 1) / BN;
+    const int64_t T = (int64_t)TM * TN * ksplit;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int64_t t_lo = x * T / 8, t_hi = (x + 1) * T / 8;
+    const int64_t t = t_lo + j;
+    if (t >= t_hi) return false;
+    const int c = (int)(t / TM);
+    z = c / TN;
+    n0 = (c % TN) * BN;
+    m0 = (int)(t % TM) * BM;
+    return true;
 }
 
 // ABL (tools/microbench/gemm_planes_bench.hip only): 1 = no DMAs (the MFMA / LDS-read side alone), 2 = no LDS reads and
@@ -594,26 +609,12 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes_kernel(Gemm
     constexpr int DPW = (NDMA + NW - 1) / NW;       // a stage's DMAs dealt over the waves; a surplus slot repeats the last one
     static_assert(STAGES >= 2 && STAGES <= 4 && DPW * (STAGES - 2) <= 63, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char gplds[];
-    // ---- work-group -> tile, XCD-aware.  The launch is 1-D; blocks b and b + 8 share an XCD (round-robin placement: a
-    // speed heuristic, never needed for correctness), and every XCD has its own 4-MB L2.  Dealt n-major, every XCD would pull
-    // ALL of both operands through its L2 (FFN-out of a query batch: 33 MB of planes per XCD, 264 MB from the Infinity Cache
-    // per GEMM, which then bounds it).  Here XCD x owns a contiguous range of the combined (K slice, n tile) index c and all
-    // m tiles of it, m fastest: its L2 holds 1/8 of the weights (or one K slice of both operands) and co-resident
-    // work-groups share the same weight tile.  Ranges differ by at most one c: the grid is padded to 8 x the largest
-    // range, the surplus work-groups return at once (gemm_planes_grid).
+    // ---- work-group -> tile, XCD-aware (gemm_planes_tile).  Every XCD has its own 4-MB L2: dealt n-major over the whole
+    // chip, every XCD would pull ALL of both operands through its L2 (FFN-out of a query batch: 33 MB of planes per XCD,
+    // 264 MB from the Infinity Cache per GEMM, which then bounds it)
     const bool split = g.ksplit > 1;
     int z, m0, n0;
-    {
-        const int TM = (g.M + BM - 1) / BM, TN = (g.N + BN - 1) / BN;
-        const int Ctot = TN * g.ksplit;
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int c_lo = (int)((int64_t)x * Ctot / 8), c_hi = (int)((int64_t)(x + 1) * Ctot / 8);
-        const int c = c_lo + j / TM;
-        if (c >= c_hi) return;
-        z = c / TN;
-        n0 = (c % TN) * BN;
-        m0 = (j % TM) * BM;
-    }
+    if (!gemm_planes_tile(g.M, g.N, BM, BN, g.ksplit, z, m0, n0)) return;
     const int K_ = split ? g.K / g.ksplit : g.K;                // a multiple of 32 (host)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -728,6 +729,156 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes_kernel(Gemm
                 }
             }
         }
+}
+
+// The same product, second form (the default): (1) the accumulators are TRANSPOSED -- the MFMA takes the weight fragment as
+// its row operand, so a lane owns ONE output row (m = lane & 31) and its registers run along n in groups of four consecutive
+// columns: the epilogue is one 16-byte store (fp32) or one 8-byte store per plane for four outputs, where the first form
+// issued 4-byte / 2-byte stores per element (the epilogue of a 19 200-row passage batch was 45 of 300 us); (2) the two
+// 16-deep halves of a step are double-buffered in REGISTERS: the LDS reads of the next half are issued before the MFMAs of
+// this one, and the single barrier of a step sits between the halves -- "tile k + 1 has landed and tile k has been read by
+// everyone" -- after which the DMA of tile k + STAGES goes into the buffer just freed: the LDS latency is never exposed and a
+// DMA has a whole step to land even with two buffers.  Requires N % 4 == 0 (host).
+template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false>
+static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(GemmPArgs g) {
+    static_assert(!F16 || NS == 2, "the fp16 split has two planes");
+    constexpr int PFMT = F16 ? PF_F16X2 : (NS == 3 ? PF_BF16X3 : PF_BF16X2);
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+    constexpr int PA = BM * 64, PB = BN * 64;
+    constexpr int STAGEB = NS * (PA + PB);
+    constexpr int NDMA = NS * (BM + BN) / 16;
+    constexpr int DPW = (NDMA + NW - 1) / NW;
+    static_assert(STAGES >= 2 && STAGES <= 5 && DPW * (STAGES - 1) <= 63, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gplds[];
+    const bool split = g.ksplit > 1;
+    int z, m0, n0;
+    if (!gemm_planes_tile(g.M, g.N, BM, BN, g.ksplit, z, m0, n0)) return;
+    const int K_ = split ? g.K / g.ksplit : g.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int i = lane & 31, h = lane >> 5;
+    float* C = g.C ? g.C + (split ? (int64_t)z * g.M * g.ldc : 0) : nullptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)gplds;
+    const int64_t a_step = (int64_t)g.M * 64, b_step = (int64_t)g.N * 64;
+    const char* a_base = reinterpret_cast<const char*>(g.A) + (split ? (int64_t)z * (K_ / 32) * a_step : 0);
+    const char* b_base = reinterpret_cast<const char*>(g.B) + (split ? (int64_t)z * (K_ / 32) * b_step : 0);
+    uint32_t voff[DPW], loff[DPW];
+    bool isb[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int d = wave + NW * j < NDMA ? wave + NW * j : NDMA - 1;
+        const bool b_op = d >= NS * (BM / 16);
+        const int dd = b_op ? d - NS * (BM / 16) : d;
+        const int rows16 = b_op ? BN / 16 : BM / 16;
+        const int q = dd / rows16, rb = dd % rows16;
+        int row = (b_op ? n0 : m0) + 16 * rb + (lane >> 2);
+        const int lim = b_op ? g.N : g.M;
+        row = row < lim ? row : lim - 1;
+        const uint32_t chunk = ((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u);
+        voff[j] = (uint32_t)(((int64_t)q * (b_op ? g.b_plane : g.a_plane) + (int64_t)row * 32) * 2) + chunk * 16u;
+        loff[j] = (uint32_t)((b_op ? NS * PA : 0) + q * (b_op ? PB : PA) + rb * 1024);
+        isb[j] = b_op;
+    }
+#define CLB_GP2_ISSUE(KSTEP, BUF)                                                                                    \
+    {                                                                                                                \
+        const char* ab_ = a_base + (int64_t)(KSTEP) * a_step;                                                        \
+        const char* bb_ = b_base + (int64_t)(KSTEP) * b_step;                                                        \
+        if (ABL != 1 && ABL != 3) _Pragma("unroll") for (int j = 0; j < DPW; ++j)                                                \
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                                        \
+                         :: "v"(voff[j]), "s"(isb[j] ? bb_ : ab_), "s"(lds0 + (uint32_t)(BUF) * STAGEB + loff[j]) : "memory"); \
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nsteps = K_ / 32;
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+        if (s < nsteps) CLB_GP2_ISSUE(s, s)
+    const int sw = (i >> 2) & 3;
+    const unsigned char* As0 = gplds + (wr * 32 * WM + i) * 64;
+    const unsigned char* Bs0 = gplds + NS * PA + (wc * 32 * WN + i) * 64;
+    u32x4 fa[2][NS][WM], fb[2][NS][WN];
+#define CLB_GP2_READ(W, BUF, S)                                                                                       \
+    if (ABL != 2) {                                                                                                   \
+        const int off_ = ((2 * (S) + h) ^ sw) << 4;                                                                   \
+        const unsigned char* as_ = As0 + (BUF) * STAGEB + off_;                                                       \
+        const unsigned char* bs_ = Bs0 + (BUF) * STAGEB + off_;                                                       \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                                              \
+            _Pragma("unroll") for (int a = 0; a < WM; ++a) fa[W][q][a] = *reinterpret_cast<const u32x4*>(as_ + q * PA + a * 32 * 64); \
+            _Pragma("unroll") for (int b = 0; b < WN; ++b) fb[W][q][b] = *reinterpret_cast<const u32x4*>(bs_ + q * PB + b * 32 * 64); \
+        }                                                                                                             \
+    }
+    // D' = W-fragment (rows n) x A-fragment (columns m): registers along n, lanes along m
+#define CLB_GP2_ONE(W, QA, QB)                                                                                        \
+    c = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[W][QB][b]), __builtin_bit_cast(f16x8, fa[W][QA][a]), c, 0, 0, 0) \
+            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[W][QB][b]), __builtin_bit_cast(bf16x8, fa[W][QA][a]), c, 0, 0, 0);
+#define CLB_GP2_MFMA(W)                                                                                               \
+    if (ABL != 2) {                                                                                                   \
+        _Pragma("unroll") for (int a = 0; a < WM; ++a)                                                                \
+            _Pragma("unroll") for (int b = 0; b < WN; ++b) {                                                          \
+                f32x16 c = acc[a][b];                                                                                 \
+                if (NS == 3) { CLB_GP2_ONE(W, 2, 0) CLB_GP2_ONE(W, 0, 2) CLB_GP2_ONE(W, 1, 1) }                       \
+                CLB_GP2_ONE(W, 1, 0) CLB_GP2_ONE(W, 0, 1) CLB_GP2_ONE(W, 0, 0)                                        \
+                acc[a][b] = c;                                                                                        \
+            }                                                                                                         \
+    }
+    // tile 0 has landed once at most the groups issued after it are pending
+    if (nsteps >= STAGES) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(DPW * (STAGES - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    CLB_GP2_READ(0, 0, 0)
+    int buf = 0;
+    for (int k = 0; k < nsteps; ++k) {
+        CLB_GP2_READ(1, buf, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CLB_GP2_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        int nbuf = buf + 1 == STAGES ? 0 : buf + 1;
+        if (k + 1 < nsteps) {
+            // my reads of tile k are complete (lgkmcnt) and my DMAs of tile k + 1 have landed (vmcnt); after the barrier that
+            // holds for every wave: buffer `buf` is free for tile k + STAGES and tile k + 1 can be read
+            if (ABL == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (k + STAGES <= nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(DPW * (STAGES - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (k + STAGES < nsteps) CLB_GP2_ISSUE(k + STAGES, buf)
+            CLB_GP2_READ(0, nbuf, 0)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        CLB_GP2_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+#undef CLB_GP2_ISSUE
+#undef CLB_GP2_READ
+#undef CLB_GP2_ONE
+#undef CLB_GP2_MFMA
+    // D' layout: column (lane & 31) = m, row (r & 3) + 8 * (r >> 2) + 4 * h = n: four consecutive n per register group
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+        const int m = m0 + (wr * WM + a) * 32 + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
+                if (n >= g.N) continue;
+                f32x4 v = {acc[a][b][4 * gq], acc[a][b][4 * gq + 1], acc[a][b][4 * gq + 2], acc[a][b][4 * gq + 3]};
+                if (!split) {
+                    if (F16) v = v * g.out_scale;
+                    if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
+                    if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                    if (g.epi & EPI_RESID) v = v + *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
+                    if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
+                }
+                if (C) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + n) = v;
+            }
+    }
 }
 
 // split-K second pass: C = epilogue(sum over the K slices, in slice order -- deterministic)

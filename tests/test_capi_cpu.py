@@ -126,7 +126,7 @@ def test_round4_entry_points_check_their_arguments_first():
 def test_plane_layout_and_xcd_tile_mapping():
     """Host restatement of two pieces of the encoder's plane GEMM (csrc/encoder_kernels.hpp): the K-blocked plane index is
     a bijection onto [0, rows * K), and the XCD-aware work-group -> tile map covers every (K slice, n tile, m tile) exactly
-    once with every XCD owning a contiguous range of the combined (slice, n tile) index."""
+    once with every XCD owning a contiguous, equally long range of the (slice, n tile, m tile) order."""
     def plane_index(row, k, rows):
         return (k >> 5) * rows * 32 + row * 32 + (k & 31)
     for rows, K in ((5, 64), (64, 96), (33, 768)):
@@ -135,29 +135,29 @@ def test_plane_layout_and_xcd_tile_mapping():
         assert all(plane_index(r, 32 * b + 1, rows) - plane_index(r, 32 * b, rows) == 1 for r in range(rows) for b in range(K // 32))
 
     def grid(M, N, bm, bn, ks):
-        TM, TN = -(-M // bm), -(-N // bn)
-        C = TN * ks
-        widest = max((x + 1) * C // 8 - x * C // 8 for x in range(8))
-        return 8 * widest * TM
+        T = -(-M // bm) * -(-N // bn) * ks
+        return 8 * -(-T // 8)
 
     def tile_of(b, M, N, bm, bn, ks):
         TM, TN = -(-M // bm), -(-N // bn)
-        C = TN * ks
+        T = TM * TN * ks
         x, j = b & 7, b >> 3
-        c_lo, c_hi = x * C // 8, (x + 1) * C // 8
-        c = c_lo + j // TM
-        if c >= c_hi:
+        t = x * T // 8 + j
+        if t >= (x + 1) * T // 8:
             return None
-        return (c // TN, c % TN, j % TM, x)
+        c = t // TM
+        return (c // TN, c % TN, t % TM, x)
     for M, N, bm, bn, ks in ((1024, 2304, 64, 64, 1), (1024, 768, 64, 64, 4), (32, 3072, 64, 64, 8), (19200, 768, 128, 128, 1),
-                             (100, 130, 64, 64, 2)):
+                             (19200, 2304, 128, 128, 1), (100, 130, 64, 64, 2)):
         tiles = [tile_of(b, M, N, bm, bn, ks) for b in range(grid(M, N, bm, bn, ks))]
         live = [t for t in tiles if t is not None]
         TM, TN = -(-M // bm), -(-N // bn)
         assert sorted((z, n, m) for z, n, m, _ in live) == sorted((z, n, m) for z in range(ks) for n in range(TN) for m in range(TM))
-        for x in range(8):                                   # one contiguous c range per XCD
-            cs = sorted({z * TN + n for z, n, m, xx in live if xx == x})
-            assert cs == list(range(cs[0], cs[0] + len(cs))) if cs else True
+        per_xcd = [sum(1 for t in live if t[3] == x) for x in range(8)]
+        assert max(per_xcd) - min(per_xcd) <= 1              # every XCD gets its eighth of the tiles
+        for x in range(8):                                   # ... one contiguous range of the (c, m) order: ~TN / 8 weight tiles
+            ts = sorted((z * TN + n) * TM + m for z, n, m, xx in live if xx == x)
+            assert ts == list(range(ts[0], ts[0] + len(ts))) if ts else True
 
 
 def test_host_planning_helpers_match_oracle(oracle):
