@@ -298,8 +298,9 @@ def encoder_l2_operand_bytes(M, N, Kd, gemm="f16x3"):
     def wgs(bm, bn):
         return -(-N // bn) * -(-M // bm)
     bytes_per_el = {"f16x3": 4, "bf16x3": 4, "bf16x6": 6}.get(gemm, 4)
-    if wgs(128, 128) >= 1024:
-        bm, bn, ks = 128, 128, 1
+    if wgs(128, 128) >= 512:         # passage batches (a GELU epilogue keeps 128 x 128: not modelled here)
+        wide = bytes_per_el == 4 and N % 4 == 0
+        bm, bn, ks = (256, 256, 1) if wide and wgs(256, 256) >= 200 else (128, 256, 1) if wide and wgs(128, 256) >= 384 else (128, 128, 1)
     else:
         bm, bn, ks = 64, 64, 1
         min_slice = 192 if wgs(64, 64) < 64 else 384
@@ -322,6 +323,7 @@ def main():
     ap.add_argument("--mode", type=int, default=-1, help="-1 library default, 0 exact, 1 two-pass")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-passage-encoder", action="store_true", help="skip the 64 x 300 passage batch of the encoder leg")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-at-a-time latency loop (profiling runs)")
     ap.add_argument("--force-gather", action="store_true", help="exercise the all-gather + merge path even with one rank (testing)")
     ap.add_argument("--uniform-codes", action="store_true",
@@ -712,7 +714,7 @@ def main():
             ach = nprod * 2.0 * M * Nn * Kd / (ms1 * 1e-3) / 1e12
             l2b, tile = encoder_l2_operand_bytes(M, Nn, Kd, enc.gemm)
             op16 = "fp16" if enc.gemm == "f16x3" else "bf16"
-            enc_roof = {"kernel": f"{domk} ({M} x {Nn} x {Kd}, gemm_planes_kernel {tile[0]}x{tile[1]} tiles, split-K {tile[2]})",
+            enc_roof = {"kernel": f"{domk} ({M} x {Nn} x {Kd}, gemm_planes2_kernel {tile[0]}x{tile[1]} tiles, split-K {tile[2]})",
                         "bound": "mfma", "achieved": round(ach, 1), "peak": peak,
                         "unit": f"TFLOP/s ({op16 + ', ' + str(nprod) + ' products per fp32 product' if nprod > 1 else 'fp32 MFMA'})",
                         "frac": round(ach / peak, 4), "ms_per_launch": round(ms1, 4),
@@ -732,6 +734,46 @@ def main():
                "roofline": enc_roof,
                "encoder_launches": "one captured HIP graph per batch" if enc_graphs is not None else "stream launches",
                "note": "encode_queries + search per step; the search consumes the synthetic queries of the headline line"}
+        # the passage side of the same encoder (what index() spends its time in: 1 M passages = 15 600 such batches): one batch
+        # of index_bsize = 64 passages x doc_maxlen = 300 tokens, output left on the device (clb_encode_docs_device)
+        if rank == 0 and not args.no_passage_encoder:
+            Np, Lp = 64, 300
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(5)
+            p_ids = torch.randint(1, BERT_BASE["vocab_size"] + 1, (Np, Lp), generator=gen, device=dev, dtype=torch.int32)
+            p_mask = torch.ones((Np, Lp), dtype=torch.uint8, device=dev)
+            p_skip = torch.tensor([1, 1013, 1014], dtype=torch.int64, device=dev)
+            for _ in range(2):
+                enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / 5
+            enc.profile_enable(True)
+            for _ in range(3):
+                enc.doc_embeddings_device(p_ids, p_mask, p_skip)
+            torch.cuda.synchronize()
+            pprof = enc.profile_read()
+            enc.profile_enable(False)
+            Mp = Np * Lp
+            H, I, Lyr = BERT_BASE["hidden_size"], BERT_BASE["intermediate_size"], BERT_BASE["num_hidden_layers"]
+            shapes = {"linear_qkv": (3 * H, H), "linear_attn_out_ln": (H, H), "linear_ffn_in_gelu": (I, H), "linear_ffn_out_ln": (H, I)}
+            nprod = {"bf16x6": 6, "bf16x3": 3, "f16x3": 3}.get(enc.gemm, 1)
+            domk = "linear_ffn_in_gelu"               # the widest product; its stage holds nothing but the GEMM
+            msl = pprof[domk]["ms"] / max(pprof[domk]["launches"], 1)
+            ach = nprod * 2.0 * Mp * shapes[domk][0] * shapes[domk][1] / (msl * 1e-3) / 1e12
+            lin_flop = 2.0 * Mp * Lyr * sum(a * b for a, b in shapes.values())
+            e2e["passage_encoder"] = {
+                "batch": f"{Np} passages x {Lp} tokens", "ms_per_batch": round(dtp * 1e3, 3), "passages_per_s": round(Np / dtp, 1),
+                "fp32_equivalent_TFLOPs_linear_layers": round(lin_flop / dtp / 1e12, 1),
+                "dominant_linear": {"kernel": f"{domk} ({Mp} x {shapes[domk][0]} x {shapes[domk][1]})", "bound": "mfma", "achieved": round(ach, 1),
+                                    "peak": BF16_MFMA_PEAK_TF if nprod > 1 else F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": round(ach / (BF16_MFMA_PEAK_TF if nprod > 1 else F32_MFMA_PEAK_TF), 4), "ms_per_launch": round(msl, 4)},
+                "stages_ms_per_batch": {kn: round(v["ms"] / 3, 4) for kn, v in pprof.items()},
+                "encode_1M_passages_s": round(1e6 / (Np / dtp), 1),
+                "note": "random token ids, every position attended (the worst case: real passages average ~80 of 300 positions)"}
         enc.close()
 
     # ---- work counters of one batch (for the roofline) and p50 latency, outside the timed region

@@ -18,8 +18,10 @@ struct clb_encoder {
     float eps = 1e-12f;
     hipStream_t stream = nullptr;
     DevBuf weights;
-    int attention_mode = 0;     // 0 = fused (register-resident up to 64 keys, online softmax beyond), 1 = register-resident
-                                // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64)
+    int attention_mode = 0;     // 0 = fused: the fp16-plane kernel behind the f16x3 Linear layers (attention_f16_kernel), else
+                                // fp32 MFMA (register-resident up to 64 keys, online softmax beyond); 1 = fp32 register-resident
+                                // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64),
+                                // 3 = fused on the fp32 MFMA whatever the GEMM mode (comparison)
     int gemm_mode = 3;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6, 3 = f16x3 (MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
@@ -34,6 +36,8 @@ struct clb_encoder {
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part;
     DevBuf xp, ctxp, tmpp, hbp; // bf16 planes of the activations the Linear layers read (written by their producers)
+    DevBuf qkp, vtp;            // attention_f16_kernel's operands: Q | K planes (T x 2H, K-blocked) and V key-blocked (vt_index)
+    int64_t vt_L = 0, vt_N = 0; // the shape vtp was last cleared for (key slots past L are never written: they must stay finite)
     // per-stage HIP-event timing (clb_encoder_profile_*): off in timed runs
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[8];
@@ -176,6 +180,7 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
 
 // ---- Linear layers on pre-split bf16 planes (gemm_planes_kernel) ----------------------------------------------------
 struct PlanCfg { int bm, bn, stages, ks; };
+struct AttOut { uint16_t* qk; int64_t qk_plane; uint16_t* vt; int64_t vt_plane; int L, H, heads; };   // EPI_QKV_ATT targets
 enum LinRole { LR_QKV = 0, LR_ATTN_OUT, LR_FFN_IN, LR_FFN_OUT, LR_PROJ, LR_COUNT };
 // COLBERT_ENC_PLAN="qkv=64x128x3x1,attn_out=64x64x3x4,...": tile / ring depth / K split per Linear role (tuning runs)
 static const PlanCfg* plan_override(int role) {
@@ -228,7 +233,7 @@ bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     CLB_GP_CASE(64, 128, 2, 2, 2, 1, 2) CLB_GP_CASE(64, 128, 3, 2, 2, 1, 2)
     CLB_GP_CASE(128, 64, 2, 2, 2, 2, 1) CLB_GP_CASE(128, 64, 3, 2, 2, 2, 1)
     CLB_GP_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GP_CASE(128, 128, 3, 2, 2, 2, 2)
-    if (NS == 2) { CLB_GP_CASE(128, 256, 2, 2, 4, 2, 2) }        // eight waves; three planes would need 144 KB
+    if (NS == 2) { CLB_GP_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GP_CASE(256, 256, 2, 4, 2, 2, 4) }   // eight waves, two planes (96 / 128 KB)
 #undef CLB_GP_CASE
     return false;
 }
@@ -240,7 +245,7 @@ inline int plane_format(int gemm_mode) { return gemm_mode == 3 ? PF_F16X2 : gemm
 // wscale: the power of two the weight planes were scaled by (PF_F16X2; 1 otherwise)
 void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, float wscale,
                    float* C, uint16_t* Cp, int64_t c_plane, const float* bias, const float* R, int M, int N, int K, int epi,
-                   float* part, const LnArgs* ln) {
+                   float* part, const LnArgs* ln, const AttOut* att = nullptr) {
     const int fmt = plane_format(e->gemm_mode);
     const int NS = fmt == PF_BF16X3 ? 3 : 2;
     const float out_scale = fmt == PF_F16X2 ? 1.0f / (kF16ActScale * wscale) : 1.0f;
@@ -258,8 +263,14 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     }
     else if (wgs(128, 128) >= 512)
         // long activations (passage batches; tools/microbench/gemm_planes_bigm_bench.hip): enough tiles to fill the chip, the
-        // widest tile that still leaves two waves per SIMD -- 128 x 256 on eight waves (two planes: 96 KB of LDS), else 128 x 128
-        c = (NS == 2 && wgs(128, 256) >= 384 && N % 4 == 0 && !planes_first_form()) ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+        // widest tile that still leaves two waves per SIMD -- 256 x 256 on eight waves of 64 x 128 (two planes: 128 KB of LDS;
+        // half the operand bytes of 128 x 128 through L2; not behind the Q/K/V projection, whose epilogue scatters V), 128 x 256, else 128 x 128.
+        // A GELU epilogue is ~2/3 of a tile's main loop in vector instructions: two 128 x 128 work-groups per CU overlap one's
+        // epilogue with the other's loop, a single large one cannot (FFN-in of 64 x 300 passages: 322 against 358 us)
+        {
+            const bool wide = NS == 2 && N % 4 == 0 && !(epi & EPI_GELU) && !planes_first_form();
+            c = wide && !att && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+        }
     else {
         // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured
         // (tools/microbench/gemm_planes_bench.hip): the loop is bound by MFMA issue (three 32 x 32 tiles per SIMD at the
@@ -278,6 +289,10 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     }
     if (!part || K % (c.ks * 32) != 0) c.ks = 1;
     GemmPArgs g{Ap, Wp, a_plane, e->wp_plane, C, bias, R, Cp, c_plane, M, N, K, N, epi, c.ks, out_scale};
+    if (att) {      // Q | K planes and key-blocked V instead of an fp32 matrix (part is null: never split over K)
+        g.C = nullptr; g.Cp = att->qk; g.c_plane = att->qk_plane; g.epi |= EPI_QKV_ATT;
+        g.Vt = att->vt; g.vt_plane = att->vt_plane; g.att_L = att->L; g.att_H = att->H; g.att_heads = att->heads;
+    }
     // an output that is normalised next keeps its planes for the LayerNorm kernel to write
     if (ln) g.Cp = nullptr;
     if (c.ks > 1) { g.C = part; g.Cp = nullptr; }
@@ -389,6 +404,19 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     }
     const int PF = plane_format(e->gemm_mode);
     if (P && e->wp_fmt != PF) CLB_TRY(split_weights(e, PF));
+    // attention on fp16 planes: the Q/K/V projection writes them (second GEMM form, never split over K)
+    const bool att16 = P && PF == PF_F16X2 && fused && e->attention_mode == 0 && T > 64 && H % 4 == 0 && !planes_first_form();
+    const int64_t ntile = (L + 31) / 32, qk_plane = T * 2 * H, vt_plane = N * heads * ntile * 64 * 32;
+    if (att16) {
+        CLB_TRY(e->qkp.ensure(sizeof(uint16_t) * 2 * qk_plane));
+        const void* before = e->vtp.p;
+        CLB_TRY(e->vtp.ensure(sizeof(uint16_t) * 2 * vt_plane));
+        if (e->vtp.p != before || e->vt_L != L || e->vt_N != N) {
+            CLB_HIP(hipMemsetAsync(e->vtp.p, 0, sizeof(uint16_t) * 2 * vt_plane, st));
+            e->vt_L = L; e->vt_N = N;
+        }
+    }
+    const AttOut att_out{e->qkp.as<uint16_t>(), qk_plane, e->vtp.as<uint16_t>(), vt_plane, (int)L, (int)H, (int)heads};
     uint16_t* xp = e->xp.as<uint16_t>(); uint16_t* ctxp = e->ctxp.as<uint16_t>();
     uint16_t* tmpp = e->tmpp.as<uint16_t>(); uint16_t* hbp = e->hbp.as<uint16_t>();
     const uint16_t* WP = e->wplanes.as<uint16_t>();
@@ -422,7 +450,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         const int64_t lo = e->o_layer0 + l * e->layer_stride;       // blob offset of this layer's parameters
         { EncTimed tm(e, ES_QKV, st);
         if (P) linear_planes(e, st, LR_QKV, xp, hp, wp(lo + e->r_wqkv), ws(l, 0), qkv, nullptr, 0, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H),
-                             (int)H, EPI_BIAS, part_wide, nullptr);
+                             (int)H, EPI_BIAS, part_wide, nullptr, att16 ? &att_out : nullptr);
         else linear(e, st, x, P_ + e->r_wqkv, qkv, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
         EncTimed* t_att = new EncTimed(e, ES_ATTENTION, st);
         if (fused) {
@@ -430,7 +458,10 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
             uint16_t* cp_ = P ? ctxp : nullptr;
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
-            if (L > 64 && e->attention_mode != 1)
+            if (att16)
+                hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
+                                   (int)H, inv_sqrt, ctxp, hp, PF);
+            else if (L > 64 && e->attention_mode != 1)
                 hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF);
             else if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
             else if (L <= 256) CLB_ATT(8); else if (L <= 320) CLB_ATT(10); else if (L <= 384) CLB_ATT(12); else CLB_ATT(16);
@@ -590,7 +621,8 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
 
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
-    if (mode < 0 || mode > 2) return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels", mode);
+    if (mode < 0 || mode > 3)
+        return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels, 3 = fused on the fp32 MFMA", mode);
     e->attention_mode = mode;
     return CLB_OK;
 }

@@ -20,7 +20,7 @@ namespace clb {
 // Epilogue: EPI_BIAS adds bias[n]; EPI_GELU applies the erf GELU after the bias; EPI_RESID adds R(m, n) (same
 // layout as C); scale multiplies the accumulator first (attention scores).
 // -------------------------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4 };
+enum { EPI_BIAS = 1, EPI_GELU = 2, EPI_RESID = 4, EPI_QKV_ATT = 8 };   // EPI_QKV_ATT: gemm_planes2_kernel only (see GemmPArgs::Vt)
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias; const float* R;
@@ -468,7 +468,21 @@ struct GemmPArgs {
     int epi;
     int ksplit;                                // > 1: blockIdx.z = K slice; raw partial sums go to C + z*M*ldc
     float out_scale;                           // multiplies the accumulator first (PF_F16X2: the inverse operand scales; else 1)
+    // EPI_QKV_ATT (the Q/K/V projection in front of attention_f16_kernel, PF_F16X2): columns [0, 2 att_H) -- Q and K -- go to
+    // Cp as K-blocked planes of a (M x 2 att_H) matrix, columns [2 att_H, 3 att_H) -- V -- to Vt in the key-blocked layout of
+    // vt_index; no fp32 copy exists
+    uint16_t* Vt = nullptr; int64_t vt_plane = 0;
+    int att_L = 0, att_H = 0, att_heads = 0;
 };
+
+// V for attention_f16_kernel: [sequence][head][tile of 32 keys][d = 0..63][32 keys], the keys of a tile in the order in which
+// the lanes of the score accumulator hold them -- lane half h, MFMA step u, slot j <-> key 16 u + 8 (j >> 2) + 4 h + (j & 3) sits
+// at position 16 h + 8 u + j: the B fragment of P.V for lane (d, h) is 32 contiguous bytes
+__device__ __host__ __forceinline__ int64_t vt_index(int64_t seq, int head, int heads, int NT, int t, int d) {
+    const int jt = t >> 5, u = (t >> 4) & 1, w = t & 15;
+    const int pos = 16 * ((w >> 2) & 1) + 8 * u + 4 * (w >> 3) + (w & 3);
+    return ((((seq * heads + head) * NT + jt) * 64 + d) << 5) + pos;
+}
 
 // Plane layout, K-BLOCKED: element (row, k) of a (rows x K) operand sits at (k / 32) * rows * 32 + row * 32 + k % 32 --
 // the 64-byte row pieces one 32-deep GEMM step needs from a tile's rows are CONTIGUOUS (a 64-row tile = one 4-KB run, every
@@ -874,7 +888,22 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                     if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
                     if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                     if (g.epi & EPI_RESID) v = v + *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
-                    if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
+                    if (F16 && (g.epi & EPI_QKV_ATT)) {
+                        if (n < 2 * g.att_H) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
+                        else {
+                            const int d0 = n - 2 * g.att_H;
+                            const int64_t seq = m / g.att_L;
+                            const int t = m - (int)seq * g.att_L;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                uint16_t hi, lo;
+                                split2_f16(v[j] * kF16ActScale, hi, lo);
+                                const int64_t at = vt_index(seq, (d0 + j) >> 6, g.att_heads, (g.att_L + 31) >> 5, t, (d0 + j) & 63);
+                                g.Vt[at] = hi;
+                                g.Vt[at + g.vt_plane] = lo;
+                            }
+                        }
+                    } else if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
                 }
                 if (C) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + n) = v;
             }
@@ -1390,6 +1419,141 @@ static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const fl
                 ctx[obase + (int64_t)q * H] = o0[r] * sc;
                 ctx[obase + (int64_t)q * H + 32] = o1[r] * sc;
             }
+        }
+    }
+}
+
+// The same online-softmax attention on the 16-bit matrix pipe (f16x3, the default with the f16x3 Linear layers): Q, K and V
+// arrive as the fp16 hi / lo planes the Q/K/V projection's epilogue wrote (EPI_QKV_ATT: Q and K K-blocked -- a lane's 32
+// features are one 64-byte piece per plane --, V key-blocked: vt_index), so no operand is split here and every load is a
+// contiguous run across the wave.  S^T tile = K . Q^T: 4 steps of v_mfma_f32_32x32x16_f16 x 3 products (lo.hi, hi.lo, hi.hi)
+// instead of 32 fp32 MFMAs; the probabilities (<= 1, scaled by 2^10 so that their low plane stays normal) are split in
+// registers, P.V = 2 steps x 2 output halves x 3 products.  24 matrix instructions of 8 passes per 32 x 32 key tile against 64
+// of 16 passes: the kernel is now bound by its exponentials and splits, not by the matrix pipe.  Operand scales (2^4 on Q, K
+// and V, 2^10 on P) are divided out of the scores and of the output.  Tile layout, masks, running maximum / sum and the
+// rescale are attention_online_kernel's.  grid = (ceil(L / 32), heads, N), block = 64.
+static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint16_t* __restrict__ qk, int64_t qk_plane, int64_t rows,
+                                                                     const uint16_t* __restrict__ vt, int64_t vt_plane,
+                                                                     const uint8_t* __restrict__ mask, int L, int H, float scale,
+                                                                     uint16_t* __restrict__ ctxp, int64_t c_plane, int ns) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 32, head = blockIdx.y, heads = gridDim.y;
+    const int64_t n = blockIdx.z;
+    const uint8_t* mk = mask + n * L;
+    const int nt = (L + 31) >> 5;
+    u32x4 qh[4], ql[4];
+    {
+        const int64_t qrow = n * L + (q0 + i < L ? q0 + i : L - 1);
+        const uint16_t* qp = qk + plane_index(qrow, head * 64 + 32 * h, rows);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qh[s] = reinterpret_cast<const u32x4*>(qp)[s];
+            ql[s] = reinterpret_cast<const u32x4*>(qp + qk_plane)[s];
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = kNegInf, l = 0.f;
+    const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale));
+    constexpr float kPScale = 1024.0f;
+    const uint16_t* vbase = vt + ((((n * heads + head) * nt) * 64 + i) << 5) + 16 * h;
+    for (int jt = 0; jt < nt; ++jt) {
+        const int key = 32 * jt + i;
+        const int krow = key < L ? key : L - 1;
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && mk[krow] != 0);
+        if (valid == 0u) continue;
+        const uint16_t* kp = qk + plane_index(n * L + krow, H + head * 64 + 32 * h, rows);
+        u32x4 kh[4], kl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kh[s] = reinterpret_cast<const u32x4*>(kp)[s];
+            kl[s] = reinterpret_cast<const u32x4*>(kp + qk_plane)[s];
+        }
+        // the V fragments of this tile: two output halves x (hi, lo) x two steps, requested before the score MFMAs
+        const uint16_t* vp = vbase + ((int64_t)jt * 64 << 5);
+        u32x4 vh[2][2], vl[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                vh[c][u] = reinterpret_cast<const u32x4*>(vp + (c * 32 << 5))[u];
+                vl[c][u] = reinterpret_cast<const u32x4*>(vp + (c * 32 << 5) + vt_plane)[u];
+            }
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kl[s]), __builtin_bit_cast(f16x8, qh[s]), st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, ql[s]), st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, qh[s]), st, 0, 0, 0);
+        }
+        float tmax = kNegInf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = ((valid >> kb) & 1u) ? st[r] * sscale : kNegInf;
+            st[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = m > kNegInf ? expf(m - m_new) : 0.f;
+        float psum = 0.f;
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                uint16_t hh[2], ll[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int r = 8 * u + 2 * j2 + b;
+                    const float e = st[r] > kNegInf ? expf(st[r] - m_new) : 0.f;
+                    psum += e;
+                    split2_f16(e * kPScale, hh[b], ll[b]);
+                }
+                ph[u][j2] = hh[0] | ((uint32_t)hh[1] << 16);
+                pl[u][j2] = ll[0] | ((uint32_t)ll[1] << 16);
+            }
+        l = l * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qa = (r & 3) + 8 * (r >> 2);
+                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa));
+                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa + 4));
+                const float a = h ? a1 : a0;
+                o0[r] *= a;
+                o1[r] *= a;
+            }
+        }
+        m = m_new;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[0][u]), o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[1][u]), o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / (l * kPScale * kF16ActScale) : 0.f;
+    const int64_t rows_ = (int64_t)gridDim.z * L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qa = (r & 3) + 8 * (r >> 2);
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa));
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa + 4));
+        const float sc = h ? s1 : s0;
+        const int q = q0 + qa + 4 * h;
+        if (q < L) {
+            const int64_t trow = n * L + q;
+            store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[r] * sc);
+            store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[r] * sc);
         }
     }
 }

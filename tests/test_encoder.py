@@ -245,6 +245,20 @@ def test_fused_attention_long_sequences(L):
         alt = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
         enc.close()
         assert np.abs(got - alt).transpose(2, 1, 0)[mask].max() < 1e-4, other
+    # the default behind the f16x3 Linear layers: attention on the fp16 planes the Q/K/V projection writes (attention_f16_kernel,
+    # three exact products per fp32 product) -- against torch, and against the fp32-MFMA kernel behind the same Linear layers
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3")
+    g16 = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    again = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    enc.close()
+    assert np.array_equal(g16.view(np.uint32), again.view(np.uint32))
+    err16 = np.abs(g16.transpose(2, 1, 0) - ref)[mask].max()
+    print(f"[f16-plane attention L={L}] max |got - torch fp32| = {err16:.3g}")
+    assert err16 < 2e-4, err16
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_f32")
+    alt = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    enc.close()
+    assert np.abs(g16 - alt).transpose(2, 1, 0)[mask].max() < 1e-4
 
 
 @pytest.mark.gpu

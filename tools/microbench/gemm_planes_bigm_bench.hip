@@ -30,8 +30,9 @@ float run(const GemmPArgs& g, int reps) {
 }
 
 int main() {
-    struct Shape { const char* name; int M, N, K; } shapes[] = {{"qkv", 19200, 2304, 768}, {"attn_out", 19200, 768, 768},
-                                                               {"ffn_in", 19200, 3072, 768}, {"ffn_out", 19200, 768, 3072}};
+    const int Mrows = getenv("GPB_M") ? atoi(getenv("GPB_M")) : 19200;
+    struct Shape { const char* name; int M, N, K; } shapes[] = {{"qkv", Mrows, 2304, 768}, {"attn_out", Mrows, 768, 768},
+                                                               {"ffn_in", Mrows, 3072, 768}, {"ffn_out", Mrows, 768, 3072}};
     for (auto& sh : shapes) {
         const int64_t ap = (int64_t)sh.M * sh.K, bp = (int64_t)sh.N * sh.K;
         uint16_t *A, *B; float* C;
@@ -64,6 +65,16 @@ int main() {
                    flop / us / 1e6, flop / us / 1e6 / 2500.0, bytes / us / 1e6, u1, u2, u3);                                          \
             fflush(stdout);                                                                                                       \
         }
+        if (Mrows <= 4096) {
+            CFG("64x64x2 4w", 2, 2, 1, 1, 2)
+            CFG2("64x64x2 4w", 2, 2, 1, 1, 2)
+            CFG2("64x64x3 4w", 2, 2, 1, 1, 3)
+            CFG2("128x64x2 4w", 2, 2, 2, 1, 2)
+            CFG2("128x64x3 4w", 2, 2, 2, 1, 3)
+            CFG2("64x128x2 4w", 2, 2, 1, 2, 2)
+            CFG2("64x128x3 4w", 2, 2, 1, 2, 3)
+            CFG2("128x128x4 4w", 2, 2, 2, 2, 4)
+        }
         CFG2("128x128x2 4w", 2, 2, 2, 2, 2)
         CFG2("128x128x3 4w", 2, 2, 2, 2, 3)
         CFG2("128x128x4 4w", 2, 2, 2, 2, 4)
@@ -72,7 +83,8 @@ int main() {
         CFG2("128x256x3 8w(2x4)", 2, 4, 2, 2, 3)
         CFG2("256x128x2 8w(4x2)", 4, 2, 2, 2, 2)
         CFG2("128x256x2 8w(2x4)", 2, 4, 2, 2, 2)
-        CFG2("256x256x2 16w(4x4)", 4, 4, 2, 2, 2)
+        CFG2("256x256x2 8w(2x4,4x2)", 2, 4, 4, 2, 2)
+        CFG2("256x256x2 8w(4x2,2x4)", 4, 2, 2, 4, 2)
         if (g.C && sh.N == 768 && sh.K == 768) {     // the two forms agree (same products; the accumulation order inside an MFMA may differ)
             std::vector<float> c1((size_t)sh.M * sh.N), c2((size_t)sh.M * sh.N);
             run<2, 2, 2, 2, 2, 0, 1>(g, 1); hipDeviceSynchronize();
