@@ -318,9 +318,11 @@ int clb_encoder_destroy(clb_encoder* e);
  * mode 2 = "bf16x6": three bf16 planes, six products, < 2^-22 per product over the whole fp32 range; mode 1 = "bf16x3": two
  * bf16 planes, three products, < 2^-15; mode 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the 16-bit rate). */
 int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
-/* Self-attention for head size 64 and up to 512 positions: mode 0 (default) = fused in registers (all score tiles
- * resident up to 64 keys, online softmax beyond), 1 = register-resident for every length, 2 = the three-kernel path
- * (scores in memory; always taken for other head sizes) -- 1 and 2 exist for comparison. */
+/* Self-attention for head size 64 and up to 512 positions: mode 0 (default) = fused in registers -- behind the f16x3 Linear
+ * layers on the 16-bit matrix pipe, on fp16 planes the Q/K/V projection writes for it (three exact products per fp32
+ * product; batches of more than 64 tokens), else fp32 MFMA (all score tiles resident up to 64 keys, online softmax beyond);
+ * 1 = fp32 MFMA, register-resident for every length; 2 = the three-kernel path (scores in memory; always taken for other head
+ * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode -- 1 to 3 exist for comparison. */
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
