@@ -206,19 +206,12 @@ def index_device_sharded(source, pid_lo: int, n_docs_total: int, backend=None, n
     sampled = np.unique(rng.integers(0, n_docs_total, size=codec.num_sampled_pids(n_docs_total)))
     mine = sampled[(sampled >= pid_lo) & (sampled < pid_lo + n_local)] - pid_lo
     n_sample = int(doclens[mine].sum())
+    # a source that can produce the embeddings of a list of passages (the encoder: indexer.EncoderSource) encodes only the
+    # sample, as the reference does (collection_indexer.jl:56-79); else they are cut out of the chunks they fall in
+    from .indexer import _sample_from_chunks
     step = int(chunksize or min(25000, 1 + n_docs_total // world))
-    sample = torch.empty((n_sample, dim), dtype=torch.float32, device=dev)
-    fill = 0
-    for start in range(0, n_local, step):
-        end = min(n_local, start + step)
-        m = mine[(mine >= start) & (mine < end)]
-        if m.size == 0:
-            continue
-        x = source.chunk(start, end)
-        rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in m])
-        sample[fill:fill + rows.size] = x[torch.from_numpy(rows).to(dev)]
-        fill += rows.size
-        del x
+    sample = source.sample(mine) if hasattr(source, "sample") else _sample_from_chunks(source, mine, step)
+    fill = int(sample.shape[0])
     assert fill == n_sample
     lrng = np.random.default_rng([seed, rank + 1])
     sample = sample[torch.from_numpy(lrng.permutation(n_sample)).to(dev)]
