@@ -155,20 +155,22 @@ class BertEncoder:
                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
         return d_out
 
-    def doc_embeddings_device(self, d_ids, d_mask, d_skiplist):
+    def doc_embeddings_device(self, d_ids, d_mask, d_skiplist, n_out: Optional[int] = None):
         """_doc_embeddings_and_doclens with torch CUDA tensors (clb_encode_docs_device): ids int32 (N, L) row-major, mask
         uint8 (N, L), skiplist int64 -> (embs float32 (n_kept, dim) CUDA tensor -- the reference's (dim, n_kept) matrix --,
-        doclens int64 (N,) CUDA tensor).  One 8-byte read-back (the compacted column count) per call."""
+        doclens int64 (N,) CUDA tensor).  `n_out`: the number of kept tokens when the caller already knows it (it follows
+        from ids, mask and skiplist alone) -- then nothing is read back and the call only enqueues; else one 8-byte
+        read-back per call."""
         import torch
         N, L = d_ids.shape
         out = torch.empty((N * L, self.dim), dtype=torch.float32, device=d_ids.device)
         doclens = torch.empty(N, dtype=torch.int64, device=d_ids.device)
-        n_out = torch.zeros(1, dtype=torch.int64, device=d_ids.device)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=d_ids.device)
         st = torch.cuda.current_stream(d_ids.device).cuda_stream
         check(lib().clb_encode_docs_device(self._h, C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_mask.data_ptr()), i64(L), i64(N),
                                            C.c_void_p(d_skiplist.data_ptr()), i64(d_skiplist.numel()), C.c_void_p(out.data_ptr()),
-                                           C.c_void_p(doclens.data_ptr()), C.c_void_p(n_out.data_ptr()), C.c_void_p(st)))
-        return out[: int(n_out.item())], doclens
+                                           C.c_void_p(doclens.data_ptr()), C.c_void_p(n_dev.data_ptr()), C.c_void_p(st)))
+        return out[: int(n_dev.item()) if n_out is None else int(n_out)], doclens
 
     def capture_query_graph(self, d_ids, d_mask, d_skiplist, d_out):
         """The ~90 launches of one `query_embeddings_device` call over STATIC buffers as a HIP graph (torch.cuda.CUDAGraph):

@@ -198,13 +198,16 @@ def _sample_from_chunks(source, pids, step: Optional[int] = None):
 
 
 class EncoderSource(DeviceEmbeddingSource):
-    """The BERT checkpoint as a device-resident source: passages are tokenised on the host in batches of index_bsize
-    (encode_passages, checkpoint.jl:159-189) and encoded, masked, normalised and compacted on the device
-    (BertEncoder.doc_embeddings_device = clb_encode_docs_device).  `doclens` needs no forward pass: a passage keeps the
-    tokens that are attended to and not in the skiplist (checkpoint.jl:37-43), which tokenisation alone decides."""
+    """The BERT checkpoint as a device-resident source.  The collection is tokenised ONCE on the host (tensorize_docs in
+    batches of index_bsize, checkpoint.jl:159-189); the token ids of every passage are kept (a few hundred bytes per
+    passage), so `doclens` -- a passage keeps the tokens that are attended to and not in the skiplist (checkpoint.jl:37-43),
+    which tokenisation alone decides -- needs no forward pass, and encoding a batch is padding + one upload + the device
+    chain forward -> mask -> normalise -> compact (BertEncoder.doc_embeddings_device = clb_encode_docs_device) without a
+    read-back: the host prepares batch i + 1 while the device encodes batch i."""
 
     def __init__(self, encoder, collection, device: int = 0):
         import torch
+        from . import tokenization
         self.encoder = encoder
         self.collection = collection
         self.dim = encoder.dim
@@ -212,42 +215,57 @@ class EncoderSource(DeviceEmbeddingSource):
         cfg = encoder.config
         self.skiplist = np.asarray(encoder.tokenizer.doc_skiplist(cfg.mask_punctuation), dtype=np.int64)
         self._d_skip = torch.from_numpy(self.skiplist).to(self.device)
-        lens = []
+        self._pad = np.int32(encoder.tokenizer.pad_id)
+        self._tokens = []                                   # per passage: its column of tensorize_docs, attended rows only
         for start in range(0, len(collection), cfg.index_bsize):
-            ids, mask = self._tensorize(collection[start:start + cfg.index_bsize])
-            lens.append((mask.astype(bool) & ~np.isin(ids, self.skiplist)).sum(axis=0))
-        self.doclens = np.concatenate(lens).astype(np.int64) if lens else np.zeros(0, np.int64)
+            ids, mask = tokenization.tensorize_docs(cfg.doc_token_id, encoder.tokenizer, collection[start:start + cfg.index_bsize],
+                                                    cfg.doc_maxlen)                 # (L, N)
+            lens = np.asarray(mask, dtype=bool).sum(axis=0)
+            self._tokens.extend(np.array(ids[:lens[j], j], dtype=np.int32) for j in range(ids.shape[1]))
+        self.doclens = np.array([int((~np.isin(t, self.skiplist)).sum()) for t in self._tokens], dtype=np.int64)
 
-    def _tensorize(self, passages):
-        from . import tokenization
-        cfg = self.encoder.config
-        return tokenization.tensorize_docs(cfg.doc_token_id, self.encoder.tokenizer, passages, cfg.doc_maxlen)   # (L, N)
+    def _tensorize(self, pids):
+        """What tensorize_docs returns for the passages `pids` as one batch, transposed to the device layout: ids int32
+        (N, L) padded with [PAD] to the longest passage of the batch, mask uint8 (N, L)."""
+        toks = [self._tokens[int(p)] for p in pids]
+        L = max(t.size for t in toks)
+        ids = np.full((len(toks), L), self._pad, dtype=np.int32)
+        mask = np.zeros((len(toks), L), dtype=np.uint8)
+        for j, t in enumerate(toks):
+            ids[j, :t.size] = t
+            mask[j, :t.size] = 1
+        return ids, mask
 
-    def encode(self, passages):
-        """encode_passages with the result left on the device -> (n, dim) float32 CUDA tensor, doclens (host)."""
+    def encode_pids(self, pids):
+        """encode_passages of the passages `pids` (batches of index_bsize, in this order) with the result left on the
+        device -> (n, dim) float32 CUDA tensor.  Only enqueues, then checks the device's doclens once."""
         import torch
+        pids = np.asarray(pids, dtype=np.int64)
+        if pids.size == 0:
+            return torch.empty((0, self.dim), dtype=torch.float32, device=self.device)
         bs = self.encoder.config.index_bsize
         parts, lens = [], []
-        for start in range(0, len(passages), bs):
-            ids, mask = self._tensorize(passages[start:start + bs])
-            d_ids = torch.from_numpy(np.ascontiguousarray(ids.T, dtype=np.int32)).to(self.device)
-            d_mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).T.astype(np.uint8))).to(self.device)
-            x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip)
+        for start in range(0, pids.size, bs):
+            batch = pids[start:start + bs]
+            ids, mask = self._tensorize(batch)
+            d_ids = torch.from_numpy(ids).to(self.device)
+            d_mask = torch.from_numpy(mask).to(self.device)
+            x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self.doclens[batch].sum()))
             parts.append(x); lens.append(dl)
+        out = torch.cat(parts) if len(parts) > 1 else parts[0]
         self.encoder.check_last_ids()
-        if not parts:
-            return torch.empty((0, self.dim), dtype=torch.float32, device=self.device), np.zeros(0, np.int64)
-        return (torch.cat(parts) if len(parts) > 1 else parts[0]), torch.cat(lens).cpu().numpy()
+        assert np.array_equal(torch.cat(lens).cpu().numpy(), self.doclens[pids])
+        return out
+
+    def encode(self, passages=None):
+        """The whole collection -> ((n, dim) CUDA tensor, doclens)."""
+        return self.encode_pids(np.arange(len(self._tokens))), self.doclens.copy()
 
     def chunk(self, start: int, end: int):
-        x, dl = self.encode(self.collection[start:end])
-        assert np.array_equal(dl, self.doclens[start:end])
-        return x
+        return self.encode_pids(np.arange(start, end))
 
     def sample(self, pids):
-        x, dl = self.encode([self.collection[int(p)] for p in pids])
-        assert np.array_equal(dl, self.doclens[np.asarray(pids, dtype=np.int64)])
-        return x
+        return self.encode_pids(pids)
 
 
 def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: int = 20, chunksize=None, seed: int = 0,

@@ -369,7 +369,7 @@ def test_index_device_resident_route_writes_the_same_files(tmp_path, tok):
             src = EncoderSource(enc, collection, 0)
             want, want_dl = enc.encode_passages(collection)
             assert np.array_equal(src.doclens, want_dl)                 # doclens from tokenisation alone
-            got, got_dl = src.encode(collection)
+            got, got_dl = src.encode()
             assert np.array_equal(got_dl, want_dl)
             assert np.array_equal(got.cpu().numpy().view(np.uint32), np.ascontiguousarray(want.T).view(np.uint32))
             x = src.sample(np.array([2, 3, 17]))

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, unsigned seed
 }
 
 template <int NLDS>
-void run(const char* name, float* out) {
-    const int iters = 4000, grid = 512 * 4;
+void run(const char* name, float* out, int grid = 512 * 4) {
+    const int iters = 4000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<NLDS>, dim3(grid), dim3(256), 0, 0, out, iters, 1u);
     hipEventRecord(e0);
@@ -62,5 +62,8 @@ int main() {
     run<0>("mfma only (again)", out);
     run<4>("mfma + 4 ds_read_b128 / 12", out);
     run<8>("mfma + 8 ds_read_b128 / 12", out);
+    // ONE work-group per CU = one wave per SIMD: what a single wave can issue (the peak column counts 256 x 4 waves)
+    run<0>("mfma only, 1 wave per SIMD", out, 256);
+    run<8>("mfma + 8 ds_read, 1 wave/SIMD", out, 256);
     return 0;
 }
