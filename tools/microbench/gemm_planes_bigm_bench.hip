@@ -74,6 +74,11 @@ int main() {
             CFG2("64x128x2 4w", 2, 2, 1, 2, 2)
             CFG2("64x128x3 4w", 2, 2, 1, 2, 3)
             CFG2("128x128x4 4w", 2, 2, 2, 2, 4)
+            CFG2("128x96x2 4w(4x1,1x3)", 4, 1, 1, 3, 2)
+            CFG2("128x96x3 4w(4x1,1x3)", 4, 1, 1, 3, 3)
+            CFG2("128x96x4 4w(4x1,1x3)", 4, 1, 1, 3, 4)
+            CFG2("96x128x3 4w(1x4,3x1)", 1, 4, 3, 1, 3)
+            CFG2("128x96x3 8w(4x2,1x?)", 4, 2, 1, 1, 3)
         }
         CFG2("128x128x2 4w", 2, 2, 2, 2, 2)
         CFG2("128x128x3 4w", 2, 2, 2, 2, 3)
