@@ -36,7 +36,21 @@ struct GemmArgs {
 constexpr int kGemmKT = 32;           // K per staged step
 constexpr int kGemmLd = kGemmKT + 1;  // LDS row stride (floats): stride-33 rows -> conflict-free column reads
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU(x) = x/2 (1 + erf(x / sqrt 2)) needs erf to an ABSOLUTE accuracy near one fp32 ulp of 1, not a relative one:
+// erf(t) = 1 - exp(q(t)) with q = log erfc as ONE degree-9 polynomial on [0, 4] (tools/fit_gelu_erf.py: max error 2.2e-9 in
+// exact arithmetic, 1.1e-7 evaluated in fp32; erfc(4) = 1.5e-8 is below half an ulp of 1), nine FMAs + one v_exp_f32 instead
+// of the two-branch library erff (~45 instructions on a divergent wave) -- the GELU epilogue of the FFN-in product of a
+// passage batch was ~2/3 of a tile's main loop in vector instructions.
+constexpr float kErfQ[10] = {2.14899565e-09f, -1.12837946f, -0.636615276f, -0.102803029f, 0.0192260593f, 4.69753249e-05f,
+                             -0.00156761205f, 0.000583863817f, -0.000105056366f, 7.94943207e-06f};
+__device__ __forceinline__ float erf_abs(float x) {
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = kErfQ[9];
+#pragma unroll
+    for (int i = 8; i >= 0; --i) q = fmaf(q, t, kErfQ[i]);
+    return copysignf(1.0f - __expf(q), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_abs(x * 0.70710678118654752440f)); }
 
 static __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ float As[64 * kGemmLd];

@@ -194,3 +194,29 @@ def test_synthetic_index_is_consistent(oracle):
     assert idx["residuals"].shape == (32, idx["doclens"].sum()) and idx["residuals"].flags.f_contiguous
     Q = clb.synthetic.make_queries(idx, 4, 3)
     assert Q.shape == (128, 32, 3) and np.allclose(np.linalg.norm(Q, axis=0), 1, atol=1e-5)
+
+
+def test_gelu_erf_polynomial_is_accurate_to_one_ulp_of_one():
+    """The encoder's GELU evaluates erf(t) = 1 - exp(q(t)), q a degree-9 fit of log erfc on [0, 4] (tools/fit_gelu_erf.py):
+    the coefficients in csrc/encoder_kernels.hpp, evaluated here in fp32 the way the kernel does (Horner with fused
+    multiply-adds, exp2 of q log2 e), stay within 1.5e-7 of erf everywhere -- and they are what the fit script produces."""
+    import math
+    import re
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(ROOT, "colbert.jl_amd", "csrc", "encoder_kernels.hpp")).read()
+    body = re.search(r"kErfQ\[10\]\s*=\s*\{([^}]*)\}", src).group(1)
+    co = [np.float32(v.strip().rstrip("f")) for v in body.split(",")]
+    assert len(co) == 10
+    x = np.linspace(-6.0, 6.0, 240001).astype(np.float32)
+    t = np.minimum(np.abs(x), np.float32(4.0))
+    q = np.full_like(t, co[9])
+    for a in co[8::-1]:
+        q = (q.astype(np.float64) * t + np.float64(a)).astype(np.float32)            # one rounding per fma
+    e = (np.float32(1) - np.exp2((q * np.float32(1.4426950408889634)).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    got = np.copysign(e, x).astype(np.float64)
+    want = np.array([math.erf(float(v)) for v in x])
+    assert np.abs(got - want).max() < 1.5e-7
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fit_gelu_erf
+    assert np.allclose(np.array(fit_gelu_erf.fit(), dtype=np.float32), np.array(co), rtol=2e-5, atol=1e-9)
