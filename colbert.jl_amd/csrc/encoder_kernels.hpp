@@ -886,10 +886,17 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
 #undef CLB_GP2_ONE
 #undef CLB_GP2_MFMA
     // D' layout: column (lane & 31) = m, row (r & 3) + 8 * (r >> 2) + 4 * h = n: four consecutive n per register group
+    const bool qkv_att = F16 && !split && (g.epi & EPI_QKV_ATT);
+    const int att_nt = qkv_att ? (g.att_L + 31) >> 5 : 0;
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
         const int m = m0 + (wr * WM + a) * 32 + i;
         if (m >= g.M) continue;
+        int64_t vrow = 0;                 // EPI_QKV_ATT: vt_index of (this token, head 0, d 0)
+        if (qkv_att) {
+            const uint32_t seq = (uint32_t)m / (uint32_t)g.att_L;
+            vrow = vt_index(seq, 0, g.att_heads, att_nt, m - (int)seq * g.att_L, 0);
+        }
 #pragma unroll
         for (int b = 0; b < WN; ++b)
 #pragma unroll
@@ -902,19 +909,17 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                     if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
                     if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                     if (g.epi & EPI_RESID) v = v + *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
-                    if (F16 && (g.epi & EPI_QKV_ATT)) {
+                    if (qkv_att) {
                         if (n < 2 * g.att_H) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
-                        else {
+                        else {            // V: (head, d) of column n - 2H; the four d of this group are 64 bytes apart in a key row
                             const int d0 = n - 2 * g.att_H;
-                            const int64_t seq = m / g.att_L;
-                            const int t = m - (int)seq * g.att_L;
+                            uint16_t* vp = g.Vt + vrow + (((int64_t)(d0 >> 6) * att_nt * 64 + (d0 & 63)) << 5);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 uint16_t hi, lo;
                                 split2_f16(v[j] * kF16ActScale, hi, lo);
-                                const int64_t at = vt_index(seq, (d0 + j) >> 6, g.att_heads, (g.att_L + 31) >> 5, t, (d0 + j) & 63);
-                                g.Vt[at] = hi;
-                                g.Vt[at + g.vt_plane] = lo;
+                                vp[32 * j] = hi;
+                                vp[32 * j + g.vt_plane] = lo;
                             }
                         }
                     } else if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
