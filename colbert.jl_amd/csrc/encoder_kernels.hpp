@@ -528,6 +528,7 @@ __device__ __forceinline__ void split3_bf16(float x, uint16_t& p0, uint16_t& p1,
 // [2^13, 2^14); the epilogue multiplies the accumulator by the product of the inverse scales.  An activation beyond the
 // range becomes Inf in the high plane and NaN downstream: the encode's epilogue reports non-finite output.
 enum { PF_BF16X2 = 2, PF_BF16X3 = 3, PF_F16X2 = 16 };
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16ActScale = 16.0f;
 __device__ __forceinline__ void split2_f16(float xs, uint16_t& h, uint16_t& l) {
     const _Float16 hh = (_Float16)xs;                       // v_cvt_f16_f32, round to nearest even
@@ -1474,7 +1475,7 @@ static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint1
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = kNegInf, l = 0.f;
-    const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale));
+    const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale)) * 1.44269504088896340736f;     // -> log2 domain
     constexpr float kPScale = 1024.0f;
     const uint16_t* vbase = vt + ((((n * heads + head) * nt) * 64 + i) << 5) + 16 * h;
     for (int jt = 0; jt < nt; ++jt) {
@@ -1508,6 +1509,8 @@ static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint1
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, ql[s]), st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, qh[s]), st, 0, 0, 0);
         }
+        // scores in the base-2 domain: s2 = s . scale . log2(e), so that a probability is ONE v_exp_f32 of a difference
+        // (exp2(-inf) = 0 covers masked keys without a second select)
         float tmax = kNegInf;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1517,24 +1520,22 @@ static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint1
             tmax = fmaxf(tmax, v);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = m > kNegInf ? expf(m - m_new) : 0.f;
+        const float m_new = fmaxf(m, tmax);                          // finite: the tile has a valid key
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);       // m = -inf (first tile): 0; maximum unchanged: 1
         float psum = 0.f;
         u32x4 ph[2], pl[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
-                uint16_t hh[2], ll[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int r = 8 * u + 2 * j2 + b;
-                    const float e = st[r] > kNegInf ? expf(st[r] - m_new) : 0.f;
-                    psum += e;
-                    split2_f16(e * kPScale, hh[b], ll[b]);
-                }
-                ph[u][j2] = hh[0] | ((uint32_t)hh[1] << 16);
-                pl[u][j2] = ll[0] | ((uint32_t)ll[1] << 16);
+                const float e0 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2] - m_new);
+                const float e1 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2 + 1] - m_new);
+                psum += e0;
+                psum += e1;
+                const f16x2 hh = {(_Float16)(e0 * kPScale), (_Float16)(e1 * kPScale)};
+                const f16x2 ll = {(_Float16)(e0 * kPScale - (float)hh[0]), (_Float16)(e1 * kPScale - (float)hh[1])};
+                ph[u][j2] = __builtin_bit_cast(uint32_t, hh);
+                pl[u][j2] = __builtin_bit_cast(uint32_t, ll);
             }
         l = l * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(m_new > m) != 0ull) {
