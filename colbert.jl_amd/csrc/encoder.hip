@@ -217,6 +217,12 @@ static bool planes_first_form() {
     return v;
 }
 
+// COLBERT_ENC_ATT_QB=1: one query block per wave in attention_f16_kernel whatever the length -- comparison runs
+static bool att_qb2() {
+    static const bool v = [] { const char* e = getenv("COLBERT_ENC_ATT_QB"); return !(e && atoi(e) == 1); }();
+    return v;
+}
+
 template <int NS, bool F16>
 bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
@@ -458,8 +464,12 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
             uint16_t* cp_ = P ? ctxp : nullptr;
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
-            if (att16)
-                hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
+            if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
+                const dim3 grid2((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)N);
+                hipLaunchKernelGGL(attention_f16_kernel<2>, grid2, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
+                                   (int)H, inv_sqrt, ctxp, hp, PF);
+            } else if (att16)
+                hipLaunchKernelGGL(attention_f16_kernel<1>, grid, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
                                    (int)H, inv_sqrt, ctxp, hp, PF);
             else if (L > 64 && e->attention_mode != 1)
                 hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF);

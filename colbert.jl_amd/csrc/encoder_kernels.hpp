@@ -1452,29 +1452,38 @@ static __global__ __launch_bounds__(64, 3) void attention_online_kernel(const fl
 // of 16 passes: the kernel is now bound by its exponentials and splits, not by the matrix pipe.  Operand scales (2^4 on Q, K
 // and V, 2^10 on P) are divided out of the scores and of the output.  Tile layout, masks, running maximum / sum and the
 // rescale are attention_online_kernel's.  grid = (ceil(L / 32), heads, N), block = 64.
-static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint16_t* __restrict__ qk, int64_t qk_plane, int64_t rows,
-                                                                     const uint16_t* __restrict__ vt, int64_t vt_plane,
-                                                                     const uint8_t* __restrict__ mask, int L, int H, float scale,
-                                                                     uint16_t* __restrict__ ctxp, int64_t c_plane, int ns) {
+// QB = query blocks of 32 per wave: 2 for long sequences -- the K / V fragments of a key tile are loaded ONCE for 64 queries
+// (the kernel is bound by those loads: 16 KB per tile and wave through L2), at two instead of three waves per SIMD.
+template <int QB>
+static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kernel(const uint16_t* __restrict__ qk, int64_t qk_plane, int64_t rows,
+                                                                                   const uint16_t* __restrict__ vt, int64_t vt_plane,
+                                                                                   const uint8_t* __restrict__ mask, int L, int H, float scale,
+                                                                                   uint16_t* __restrict__ ctxp, int64_t c_plane, int ns) {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 32, head = blockIdx.y, heads = gridDim.y;
+    const int q0 = blockIdx.x * 32 * QB, head = blockIdx.y, heads = gridDim.y;
     const int64_t n = blockIdx.z;
     const uint8_t* mk = mask + n * L;
     const int nt = (L + 31) >> 5;
-    u32x4 qh[4], ql[4];
-    {
-        const int64_t qrow = n * L + (q0 + i < L ? q0 + i : L - 1);
+    u32x4 qh[QB][4], ql[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + 32 * qb + i;
+        const int64_t qrow = n * L + (qi < L ? qi : L - 1);
         const uint16_t* qp = qk + plane_index(qrow, head * 64 + 32 * h, rows);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            qh[s] = reinterpret_cast<const u32x4*>(qp)[s];
-            ql[s] = reinterpret_cast<const u32x4*>(qp + qk_plane)[s];
+            qh[qb][s] = reinterpret_cast<const u32x4*>(qp)[s];
+            ql[qb][s] = reinterpret_cast<const u32x4*>(qp + qk_plane)[s];
         }
     }
-    f32x16 o0, o1;
+    f32x16 o0[QB], o1[QB];
+    float m[QB], l[QB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = kNegInf, l = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = kNegInf; l[qb] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[qb][r] = 0.f; o1[qb][r] = 0.f; }
+    }
     const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale)) * 1.44269504088896340736f;     // -> log2 domain
     constexpr float kPScale = 1024.0f;
     const uint16_t* vbase = vt + ((((n * heads + head) * nt) * 64 + i) << 5) + 16 * h;
@@ -1500,80 +1509,86 @@ static __global__ __launch_bounds__(64, 3) void attention_f16_kernel(const uint1
                 vh[c][u] = reinterpret_cast<const u32x4*>(vp + (c * 32 << 5))[u];
                 vl[c][u] = reinterpret_cast<const u32x4*>(vp + (c * 32 << 5) + vt_plane)[u];
             }
-        f32x16 st;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x16 st;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kl[s]), __builtin_bit_cast(f16x8, qh[s]), st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, ql[s]), st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, qh[s]), st, 0, 0, 0);
-        }
-        // scores in the base-2 domain: s2 = s . scale . log2(e), so that a probability is ONE v_exp_f32 of a difference
-        // (exp2(-inf) = 0 covers masked keys without a second select)
-        float tmax = kNegInf;
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = ((valid >> kb) & 1u) ? st[r] * sscale : kNegInf;
-            st[r] = v;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);                          // finite: the tile has a valid key
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);       // m = -inf (first tile): 0; maximum unchanged: 1
-        float psum = 0.f;
-        u32x4 ph[2], pl[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const float e0 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2] - m_new);
-                const float e1 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2 + 1] - m_new);
-                psum += e0;
-                psum += e1;
-                const f16x2 hh = {(_Float16)(e0 * kPScale), (_Float16)(e1 * kPScale)};
-                const f16x2 ll = {(_Float16)(e0 * kPScale - (float)hh[0]), (_Float16)(e1 * kPScale - (float)hh[1])};
-                ph[u][j2] = __builtin_bit_cast(uint32_t, hh);
-                pl[u][j2] = __builtin_bit_cast(uint32_t, ll);
+            for (int s = 0; s < 4; ++s) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kl[s]), __builtin_bit_cast(f16x8, qh[qb][s]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, ql[qb][s]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, qh[qb][s]), st, 0, 0, 0);
             }
-        l = l * alpha + psum;
-        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0ull) {
+            // scores in the base-2 domain: s2 = s . scale . log2(e), so that a probability is ONE v_exp_f32 of a difference
+            // (exp2(-inf) = 0 covers masked keys without a second select)
+            float tmax = kNegInf;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qa = (r & 3) + 8 * (r >> 2);
-                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa));
-                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa + 4));
-                const float a = h ? a1 : a0;
-                o0[r] *= a;
-                o1[r] *= a;
+                const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = ((valid >> kb) & 1u) ? st[r] * sscale : kNegInf;
+                st[r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m[qb], tmax);                      // finite: the tile has a valid key
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);   // m = -inf (first tile): 0; maximum unchanged: 1
+            float psum = 0.f;
+            u32x4 ph[2], pl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const float e0 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2] - m_new);
+                    const float e1 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2 + 1] - m_new);
+                    psum += e0;
+                    psum += e1;
+                    const f16x2 hh = {(_Float16)(e0 * kPScale), (_Float16)(e1 * kPScale)};
+                    const f16x2 ll = {(_Float16)(e0 * kPScale - (float)hh[0]), (_Float16)(e1 * kPScale - (float)hh[1])};
+                    ph[u][j2] = __builtin_bit_cast(uint32_t, hh);
+                    pl[u][j2] = __builtin_bit_cast(uint32_t, ll);
+                }
+            l[qb] = l[qb] * alpha + psum;
+            if (__builtin_amdgcn_ballot_w64(m_new > m[qb]) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qa = (r & 3) + 8 * (r >> 2);
+                    const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa));
+                    const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa + 4));
+                    const float a = h ? a1 : a0;
+                    o0[qb][r] *= a;
+                    o1[qb][r] *= a;
+                }
+            }
+            m[qb] = m_new;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0[qb], 0, 0, 0);
+                o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[0][u]), o0[qb], 0, 0, 0);
+                o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0[qb], 0, 0, 0);
+                o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1[qb], 0, 0, 0);
+                o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[1][u]), o1[qb], 0, 0, 0);
+                o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1[qb], 0, 0, 0);
             }
         }
-        m = m_new;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[0][u]), o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[0][u]), o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vl[1][u]), o1, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[u]), __builtin_bit_cast(f16x8, vh[1][u]), o1, 0, 0, 0);
-        }
     }
-    l += __shfl_xor(l, 32, 64);
-    const float inv = l > 0.f ? 1.0f / (l * kPScale * kF16ActScale) : 0.f;
     const int64_t rows_ = (int64_t)gridDim.z * L;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qa = (r & 3) + 8 * (r >> 2);
-        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa));
-        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa + 4));
-        const float sc = h ? s1 : s0;
-        const int q = q0 + qa + 4 * h;
-        if (q < L) {
-            const int64_t trow = n * L + q;
-            store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[r] * sc);
-            store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[r] * sc);
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const float inv = lsum > 0.f ? 1.0f / (lsum * kPScale * kF16ActScale) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qa = (r & 3) + 8 * (r >> 2);
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa + 4));
+            const float sc = h ? s1 : s0;
+            const int q = q0 + 32 * qb + qa + 4 * h;
+            if (q < L) {
+                const int64_t trow = n * L + q;
+                store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[qb][r] * sc);
+                store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[qb][r] * sc);
+            }
         }
     }
 }
