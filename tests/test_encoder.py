@@ -385,3 +385,33 @@ def test_index_device_resident_route_writes_the_same_files(tmp_path, tok):
         if n == "config.json":
             continue                                                    # holds its own index_path
         assert filecmp.cmp(os.path.join(paths["host"], n), os.path.join(paths["device"], n), shallow=False), n
+
+
+@pytest.mark.gpu
+def test_fp16_plane_attention_survives_batch_shape_changes():
+    """attention_f16_kernel reads V from a key-blocked buffer whose slots past a sequence's end are never written: one
+    encoder object run over batches of changing shape (as index() does: every batch is padded to its own longest passage)
+    returns, for every batch, the bits a fresh encoder returns."""
+    torch, cfg, bert, linear = _random_bert(hidden=128, layers=2, heads=2, inter=256, vocab=90, max_pos=512, dim=32, seed=21)
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    w = pack_weights(_state(bert, linear), bcfg, 32)
+    rng = np.random.default_rng(22)
+    shapes = [(70, 5), (45, 3), (300, 2), (33, 7), (70, 5), (129, 1)]
+    batches = []
+    for L, N in shapes:
+        ids = (rng.integers(0, cfg.vocab_size, size=(L, N)) + 1).astype(np.int32)
+        mask = np.zeros((L, N), bool)
+        for n in range(N):
+            mask[: rng.integers(1, L + 1), n] = True
+        mask[:, 0] = True
+        batches.append((ids, mask))
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3")
+    got = [enc.doc(ids, mask) for ids, mask in batches]
+    enc.close()
+    for (ids, mask), g in zip(batches, got):
+        fresh = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3")
+        want = fresh.doc(ids, mask)
+        fresh.close()
+        assert np.array_equal(g.view(np.uint32)[:, mask], want.view(np.uint32)[:, mask]), ids.shape
+        assert np.isfinite(g).all()
