@@ -295,7 +295,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     }
     if (!part || K % (c.ks * 32) != 0) c.ks = 1;
     GemmPArgs g{Ap, Wp, a_plane, e->wp_plane, C, bias, R, Cp, c_plane, M, N, K, N, epi, c.ks, out_scale};
-    if (att) {      // Q | K planes and key-blocked V instead of an fp32 matrix (part is null: never split over K)
+    if (att) {      // Q | K planes and key-blocked V instead of an fp32 matrix (split over K: written by the reduce pass)
         g.C = nullptr; g.Cp = att->qk; g.c_plane = att->qk_plane; g.epi |= EPI_QKV_ATT;
         g.Vt = att->vt; g.vt_plane = att->vt_plane; g.att_L = att->L; g.att_H = att->H; g.att_heads = att->heads;
     }
@@ -319,6 +319,11 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
                                    out_scale, epi, ln->gamma, ln->beta, ln->eps, Cp, c_plane, fmt);
             return;
         }
+        if (att)
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, c.ks, (int64_t)M, N,
+                               (float*)nullptr, bias, R, out_scale, epi, att->qk, att->qk_plane, fmt, att->vt, att->vt_plane, att->L, att->H,
+                               att->heads);
+        else
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, c.ks, (int64_t)M, N,
                            C, bias, R, out_scale, epi, ln ? (uint16_t*)nullptr : Cp, c_plane, fmt);
     }
@@ -411,7 +416,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     const int PF = plane_format(e->gemm_mode);
     if (P && e->wp_fmt != PF) CLB_TRY(split_weights(e, PF));
     // attention on fp16 planes: the Q/K/V projection writes them (second GEMM form, never split over K)
-    const bool att16 = P && PF == PF_F16X2 && fused && e->attention_mode == 0 && T > 64 && H % 4 == 0 && !planes_first_form();
+    const bool att16 = P && PF == PF_F16X2 && fused && e->attention_mode == 0 && H % 4 == 0 && !planes_first_form();
     const int64_t ntile = (L + 31) / 32, qk_plane = T * 2 * H, vt_plane = N * heads * ntile * 64 * 32;
     if (att16) {
         CLB_TRY(e->qkp.ensure(sizeof(uint16_t) * 2 * qk_plane));

@@ -936,7 +936,9 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
                                                                        const float* __restrict__ bias,
                                                                        const float* __restrict__ R, float scale, int epi,
                                                                        uint16_t* __restrict__ Cp = nullptr, int64_t c_plane = 0,
-                                                                       int ns = 0) {
+                                                                       int ns = 0, uint16_t* __restrict__ Vt = nullptr,
+                                                                       int64_t vt_plane = 0, int att_L = 0, int att_H = 0,
+                                                                       int att_heads = 0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int n = (int)(idx % N);
@@ -954,6 +956,20 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
     if (epi & EPI_GELU) v = gelu_erf(v);
     if (epi & EPI_RESID) v += R[idx];
     if (C) C[idx] = v;
+    if (Vt) {      // EPI_QKV_ATT (PF_F16X2): Q | K planes of a (M x 2 att_H) matrix, V key-blocked -- attention_f16_kernel's operands
+        const int64_t m = idx / N;
+        if (n < 2 * att_H) store_planes(Cp + plane_index(m, n, M), c_plane, PF_F16X2, v);
+        else {
+            const int d0 = n - 2 * att_H;
+            const int64_t seq = m / att_L;
+            uint16_t hi, lo;
+            split2_f16(v * kF16ActScale, hi, lo);
+            const int64_t at = vt_index(seq, d0 >> 6, att_heads, (att_L + 31) >> 5, (int)(m - seq * att_L), d0 & 63);
+            Vt[at] = hi;
+            Vt[at + vt_plane] = lo;
+        }
+        return;
+    }
     if (Cp) store_planes(Cp + plane_index(idx / N, n, M), c_plane, ns, v);   // the bf16 planes the next Linear reads
 }
 

@@ -397,7 +397,7 @@ def test_fp16_plane_attention_survives_batch_shape_changes():
     bcfg = cfg.to_dict()
     w = pack_weights(_state(bert, linear), bcfg, 32)
     rng = np.random.default_rng(22)
-    shapes = [(70, 5), (45, 3), (300, 2), (33, 7), (70, 5), (129, 1)]
+    shapes = [(70, 5), (45, 3), (300, 2), (20, 3), (33, 7), (70, 5), (64, 1), (129, 1)]     # 20 x 3, 64 x 1: the one-query (split-K) plans
     batches = []
     for L, N in shapes:
         ids = (rng.integers(0, cfg.vocab_size, size=(L, N)) + 1).astype(np.int32)
