@@ -239,7 +239,7 @@ bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     CLB_GP_CASE(64, 128, 2, 2, 2, 1, 2) CLB_GP_CASE(64, 128, 3, 2, 2, 1, 2)
     CLB_GP_CASE(128, 64, 2, 2, 2, 2, 1) CLB_GP_CASE(128, 64, 3, 2, 2, 2, 1)
     CLB_GP_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GP_CASE(128, 128, 3, 2, 2, 2, 2)
-    if (NS == 2) { CLB_GP_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GP_CASE(256, 256, 2, 4, 2, 2, 4) }   // eight waves, two planes (96 / 128 KB)
+    if (NS == 2) { CLB_GP_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GP_CASE(128, 256, 3, 2, 4, 2, 2) CLB_GP_CASE(256, 256, 2, 4, 2, 2, 4) }   // eight waves, two planes (96 / 144 / 128 KB)
 #undef CLB_GP_CASE
     return false;
 }
