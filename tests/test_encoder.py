@@ -415,3 +415,32 @@ def test_fp16_plane_attention_survives_batch_shape_changes():
         fresh.close()
         assert np.array_equal(g.view(np.uint32)[:, mask], want.view(np.uint32)[:, mask]), ids.shape
         assert np.isfinite(g).all()
+
+
+@pytest.mark.gpu
+def test_passage_batch_plans_with_an_odd_number_of_heads():
+    """A batch long enough for the passage-batch tile plans (128 x 256 / 256 x 256 work-group tiles) on a model with three
+    heads: 2H = 384 is not a multiple of the 256-wide tile, so one tile of the Q/K/V projection holds K columns and V
+    columns side by side (EPI_QKV_ATT switches layout inside it), and N = 576 / 192 end in partial tiles."""
+    torch, cfg, bert, linear = _random_bert(hidden=192, layers=1, heads=3, inter=320, vocab=90, max_pos=512, dim=64, seed=31)
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    w = pack_weights(_state(bert, linear), bcfg, 64)
+    rng = np.random.default_rng(32)
+    N, L = 56, 300
+    ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
+    mask = np.zeros((N, L), bool)
+    for n in range(N):
+        mask[n, : rng.integers(1, L + 1)] = True
+    mask[0, :] = True
+    with torch.no_grad():
+        ref = linear(bert(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state).numpy()
+    outs = {}
+    for attention in ("fused", "fused_f32"):
+        enc = clb.BertEncoder(w, bcfg, dim=64, gemm="f16x3", attention=attention)
+        outs[attention] = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+        enc.close()
+        err = np.abs(outs[attention].transpose(2, 1, 0) - ref)[mask].max()
+        print(f"[passage-batch plans, 3 heads, {attention}] max |got - torch fp32| = {err:.3g}")
+        assert err < 1e-4, (attention, err)
+    assert np.abs(outs["fused"] - outs["fused_f32"]).transpose(2, 1, 0)[mask].max() < 5e-5
