@@ -207,7 +207,6 @@ class EncoderSource(DeviceEmbeddingSource):
 
     def __init__(self, encoder, collection, device: int = 0):
         import torch
-        from . import tokenization
         self.encoder = encoder
         self.collection = collection
         self.dim = encoder.dim
@@ -216,13 +215,20 @@ class EncoderSource(DeviceEmbeddingSource):
         self.skiplist = np.asarray(encoder.tokenizer.doc_skiplist(cfg.mask_punctuation), dtype=np.int64)
         self._d_skip = torch.from_numpy(self.skiplist).to(self.device)
         self._pad = np.int32(encoder.tokenizer.pad_id)
-        self._tokens = []                                   # per passage: its column of tensorize_docs, attended rows only
-        for start in range(0, len(collection), cfg.index_bsize):
-            ids, mask = tokenization.tensorize_docs(cfg.doc_token_id, encoder.tokenizer, collection[start:start + cfg.index_bsize],
-                                                    cfg.doc_maxlen)                 # (L, N)
-            lens = np.asarray(mask, dtype=bool).sum(axis=0)
-            self._tokens.extend(np.array(ids[:lens[j], j], dtype=np.int32) for j in range(ids.shape[1]))
-        self.doclens = np.array([int((~np.isin(t, self.skiplist)).sum()) for t in self._tokens], dtype=np.int64)
+        # per passage: its column of tensorize_docs (doc_tokenization.jl:143-156), attended rows only -- [CLS] [D] w1 .. wn
+        # [SEP], 1-based ids, truncated to doc_maxlen.  Tokenised in large slices on the tokenizer's thread pool.
+        marker = np.int32(encoder.tokenizer.lookup(cfg.doc_token_id))
+        self._tokens = []
+        for start in range(0, len(collection), 8192):
+            for e in encoder.tokenizer.tok.encode_batch(list(collection[start:start + 8192]), add_special_tokens=True):
+                ids = np.asarray(e.ids[:cfg.doc_maxlen - 1], dtype=np.int32) + 1
+                self._tokens.append(np.concatenate([ids[:1], [marker], ids[1:]]).astype(np.int32))
+        if self._tokens:                                    # every passage holds at least [CLS] [D] [SEP]: no empty segment
+            starts = np.concatenate([[0], np.cumsum([t.size for t in self._tokens])[:-1]])
+            keep = ~np.isin(np.concatenate(self._tokens), self.skiplist)
+            self.doclens = np.add.reduceat(keep.astype(np.int64), starts)
+        else:
+            self.doclens = np.zeros(0, np.int64)
 
     def _tensorize(self, pids):
         """What tensorize_docs returns for the passages `pids` as one batch, transposed to the device layout: ids int32

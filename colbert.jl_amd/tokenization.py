@@ -41,10 +41,8 @@ class WordPieceTokenizer:
         `max_tokens` (:tail), padded with [PAD] to max_tokens (queries: trunc_or_pad) or to the longest
         sequence of the batch (documents: trunc_and_pad).  Returns (integer_ids Int32 (len, batch) 1-based,
         bitmask Bool (len, batch))."""
-        seqs = []
-        for t in batch_text:
-            e = self.tok.encode(t, add_special_tokens=True).ids
-            seqs.append(e[:max_tokens])
+        # encode_batch: the same ids as one encode() per text, tokenised on the library's thread pool
+        seqs = [e.ids[:max_tokens] for e in self.tok.encode_batch(list(batch_text), add_special_tokens=True)]
         width = max_tokens if pad_to_max else max(len(e) for e in seqs)
         ids = np.full((width, len(seqs)), self.pad_id, dtype=np.int32, order="F")
         mask = np.zeros((width, len(seqs)), dtype=bool, order="F")
