@@ -298,7 +298,7 @@ def encoder_l2_operand_bytes(M, N, Kd, gemm="f16x3"):
     def wgs(bm, bn):
         return -(-N // bn) * -(-M // bm)
     bytes_per_el = {"f16x3": 4, "bf16x3": 4, "bf16x6": 6}.get(gemm, 4)
-    if wgs(128, 128) >= 512:         # passage batches (a GELU epilogue keeps 128 x 128: not modelled here)
+    if wgs(128, 128) >= 256:         # passage batches (a GELU epilogue keeps 128 x 128: not modelled here)
         wide = bytes_per_el == 4 and N % 4 == 0
         bm, bn, ks = (256, 256, 1) if wide and wgs(256, 256) >= 200 else (128, 256, 1) if wide and wgs(128, 256) >= 384 else (128, 128, 1)
     else:

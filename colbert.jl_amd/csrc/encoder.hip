@@ -267,7 +267,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         const int tn = (N + 63) / 64;
         while (c.ks < 32 && K % (c.ks * 2 * 32) == 0 && K / (c.ks * 2) >= 96 && tn * c.ks * 2 <= 1024) c.ks *= 2;
     }
-    else if (wgs(128, 128) >= 512)
+    else if (wgs(128, 128) >= 256)      // one 128 x 128 tile per CU and more (sweeps at M = 2 560 ... 19 200: r04_encoder_plan_sweeps.txt)
         // long activations (passage batches; tools/microbench/gemm_planes_bigm_bench.hip): enough tiles to fill the chip, the
         // widest tile that still leaves two waves per SIMD -- 256 x 256 on eight waves of 64 x 128 (two planes: 128 KB of LDS;
         // half the operand bytes of 128 x 128 through L2; not behind the Q/K/V projection, whose epilogue scatters V), 128 x 256, else 128 x 128.
