@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "codec_kernels.hpp"
+#include "sort.hpp"
 #include "encoder_kernels.hpp"
 
 using namespace clb;
@@ -34,7 +35,7 @@ struct clb_encoder {
     std::vector<float> wscale;  // PF_F16X2: the power of two every weight matrix was multiplied by (4 per layer + projection)
     bool planes = false;        // the Linear layers read pre-split bf16 planes (gemm_planes_kernel); COLBERT_ENCODER_PLANES=0: off
     // workspace
-    DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part;
+    DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part, pkeep, prank, scan_tmp;
     DevBuf xp, ctxp, tmpp, hbp; // bf16 planes of the activations the Linear layers read (written by their producers)
     DevBuf qkp, vtp;            // attention_f16_kernel's operands: Q | K planes (T x 2H, K-blocked) and V key-blocked (vt_index)
     int64_t vt_L = 0, vt_N = 0; // the shape vtp was last cleared for (key slots past L are never written: they must stay finite)
@@ -180,7 +181,9 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
 
 // ---- Linear layers on pre-split bf16 planes (gemm_planes_kernel) ----------------------------------------------------
 struct PlanCfg { int bm, bn, stages, ks; };
-struct AttOut { uint16_t* qk; int64_t qk_plane; uint16_t* vt; int64_t vt_plane; int L, H, heads; };   // EPI_QKV_ATT targets
+struct AttOut { uint16_t* qk; int64_t qk_plane; uint16_t* vt; int64_t vt_plane; int L, H, heads; const int32_t* seq; const int32_t* pos; };   // EPI_QKV_ATT targets
+// a packed batch: N sequences back to back without padding rows (device arrays: position and sequence of every row, row offsets)
+struct Packed { const int32_t* pos; const int32_t* seq; const int32_t* cu; int64_t rows; };
 enum LinRole { LR_QKV = 0, LR_ATTN_OUT, LR_FFN_IN, LR_FFN_OUT, LR_PROJ, LR_COUNT };
 // COLBERT_ENC_PLAN="qkv=64x128x3x1,attn_out=64x64x3x4,...": tile / ring depth / K split per Linear role (tuning runs)
 static const PlanCfg* plan_override(int role) {
@@ -298,6 +301,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     if (att) {      // Q | K planes and key-blocked V instead of an fp32 matrix (split over K: written by the reduce pass)
         g.C = nullptr; g.Cp = att->qk; g.c_plane = att->qk_plane; g.epi |= EPI_QKV_ATT;
         g.Vt = att->vt; g.vt_plane = att->vt_plane; g.att_L = att->L; g.att_H = att->H; g.att_heads = att->heads;
+        g.att_seq = att->seq; g.att_pos = att->pos;
     }
     // an output that is normalised next keeps its planes for the LayerNorm kernel to write
     if (ln) g.Cp = nullptr;
@@ -322,7 +326,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         if (att)
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, c.ks, (int64_t)M, N,
                                (float*)nullptr, bias, R, out_scale, epi, att->qk, att->qk_plane, fmt, att->vt, att->vt_plane, att->L, att->H,
-                               att->heads);
+                               att->heads, att->seq, att->pos);
         else
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks_for((int64_t)M * N)), dim3(256), 0, st, part, c.ks, (int64_t)M, N,
                            C, bias, R, out_scale, epi, ln ? (uint16_t*)nullptr : Cp, c_plane, fmt);
@@ -391,9 +395,10 @@ int split_weights(clb_encoder* e, int fmt) {
 
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
 // sync = false: everything is only enqueued on `st` (an out-of-vocabulary id is then clamped silently).
+// pk (packed batch): d_ids holds pk->rows token ids, L is the longest sequence, d_mask is unused; needs the fp16-plane attention.
 int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t* d_ids, const uint8_t* d_mask,
-            bool sync = true) {
-    const int64_t T = L * N, H = e->H, I = e->I, heads = e->heads, dh = H / heads;
+            bool sync = true, const Packed* pk = nullptr) {
+    const int64_t T = pk ? pk->rows : L * N, H = e->H, I = e->I, heads = e->heads, dh = H / heads;
     const float* W = e->weights.as<float>();
     CLB_TRY(e->x.ensure(sizeof(float) * T * H));
     CLB_TRY(e->qkv.ensure(sizeof(float) * T * 3 * H));
@@ -418,16 +423,20 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     // attention on fp16 planes: the Q/K/V projection writes them (second GEMM form, never split over K)
     const bool att16 = P && PF == PF_F16X2 && fused && e->attention_mode == 0 && H % 4 == 0 && !planes_first_form();
     const int64_t ntile = (L + 31) / 32, qk_plane = T * 2 * H, vt_plane = N * heads * ntile * 64 * 32;
+    if (pk && !att16)
+        return fail(CLB_EARGUMENT, "a packed batch needs the fp16-plane attention (head size 64, f16x3 Linear layers, attention mode 0)");
     if (att16) {
         CLB_TRY(e->qkp.ensure(sizeof(uint16_t) * 2 * qk_plane));
         const void* before = e->vtp.p;
         CLB_TRY(e->vtp.ensure(sizeof(uint16_t) * 2 * vt_plane));
-        if (e->vtp.p != before || e->vt_L != L || e->vt_N != N) {
+        // packed: the key slots between a sequence's end and Lmax are never written either -- cleared per call (~20 us)
+        if (pk || e->vtp.p != before || e->vt_L != L || e->vt_N != N) {
             CLB_HIP(hipMemsetAsync(e->vtp.p, 0, sizeof(uint16_t) * 2 * vt_plane, st));
             e->vt_L = L; e->vt_N = N;
         }
     }
-    const AttOut att_out{e->qkp.as<uint16_t>(), qk_plane, e->vtp.as<uint16_t>(), vt_plane, (int)L, (int)H, (int)heads};
+    const AttOut att_out{e->qkp.as<uint16_t>(), qk_plane, e->vtp.as<uint16_t>(), vt_plane, (int)L, (int)H, (int)heads, pk ? pk->seq : nullptr,
+                         pk ? pk->pos : nullptr};
     uint16_t* xp = e->xp.as<uint16_t>(); uint16_t* ctxp = e->ctxp.as<uint16_t>();
     uint16_t* tmpp = e->tmpp.as<uint16_t>(); uint16_t* hbp = e->hbp.as<uint16_t>();
     const uint16_t* WP = e->wplanes.as<uint16_t>();
@@ -446,7 +455,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         EncTimed tm(e, ES_EMBED, st);
         hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks_for(T, 4)), dim3(256), 0, st, d_ids, T, (int)L,
                            (int)H, (int)e->vocab, W + e->o_word, W + e->o_pos, W + e->o_type, W + e->o_eg, W + e->o_eb, e->eps,
-                           e->x.as<float>(), e->err.as<int>(), P ? xp : (uint16_t*)nullptr, hp, PF);
+                           e->x.as<float>(), e->err.as<int>(), P ? xp : (uint16_t*)nullptr, hp, PF, pk ? pk->pos : nullptr);
     }
     float* x = e->x.as<float>();
     float* qkv = e->qkv.as<float>();
@@ -472,10 +481,10 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
                 const dim3 grid2((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)N);
                 hipLaunchKernelGGL(attention_f16_kernel<2>, grid2, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
-                                   (int)H, inv_sqrt, ctxp, hp, PF);
+                                   (int)H, inv_sqrt, ctxp, hp, PF, pk ? pk->cu : nullptr);
             } else if (att16)
                 hipLaunchKernelGGL(attention_f16_kernel<1>, grid, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
-                                   (int)H, inv_sqrt, ctxp, hp, PF);
+                                   (int)H, inv_sqrt, ctxp, hp, PF, pk ? pk->cu : nullptr);
             else if (L > 64 && e->attention_mode != 1)
                 hipLaunchKernelGGL(attention_online_kernel, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF);
             else if (L <= 32) CLB_ATT(1); else if (L <= 64) CLB_ATT(2); else if (L <= 128) CLB_ATT(4); else if (L <= 192) CLB_ATT(6);
@@ -534,6 +543,37 @@ int finish_checked(clb_encoder* e, hipStream_t st) {
     if (herr & 2) return fail(CLB_EDOMAIN, "non-finite encoder output (an activation outside the range of the f16 operand split? "
                                            "clb_encoder_set_gemm_mode(e, 2) selects the bf16x6 split)");
     return CLB_OK;
+}
+
+// ---- the document epilogue of a PACKED batch (checkpoint.jl:37-52): every row is an attended token; kept rows (id not in the
+// skiplist) are normalised and written to their rank among the kept rows -- the sequences follow one another, so the global
+// rank IS the compacted column -- and doclens are differences of that rank at the sequence boundaries
+__global__ void packed_keep_kernel(const int32_t* __restrict__ ids, int64_t rows, const int64_t* __restrict__ skip, int nskip,
+                                   uint32_t* __restrict__ keep) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= rows) return;
+    const int64_t id = ids[j];
+    bool k = true;
+    for (int s = 0; s < nskip; ++s) k = k && (id != skip[s]);
+    keep[j] = k ? 1u : 0u;
+}
+__global__ void packed_doclens_kernel(const uint32_t* __restrict__ rank /*rows + 1*/, const int32_t* __restrict__ cu, int N,
+                                      int64_t* __restrict__ doclens, int64_t* __restrict__ n_out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) doclens[n] = (int64_t)rank[cu[n + 1]] - (int64_t)rank[cu[n]];
+    if (n == 0) *n_out = (int64_t)rank[cu[N]];
+}
+__global__ void packed_normalize_kernel(const float* __restrict__ D, int dim, int64_t rows, const uint32_t* __restrict__ keep,
+                                        const uint32_t* __restrict__ rank, float* __restrict__ out, int* __restrict__ err) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= rows) return;
+    const float* x = D + j * dim;
+    const float n2 = sumsq_canonical(x, dim);
+    if (!(n2 <= FLT_MAX)) atomicOr(err, 2);
+    if (!keep[j]) return;
+    float* o = out + (size_t)rank[j] * dim;
+    const float den = sqrtf(n2) + FLT_EPSILON;              // epilogue_normalize_kernel's arithmetic
+    for (int d = 0; d < dim; ++d) o[d] = x[d] / den;
 }
 
 int upload_inputs(clb_encoder* e, const int32_t* ids, const uint8_t* mask, int64_t L, int64_t N) {
@@ -739,6 +779,32 @@ int clb_encode_docs_device(clb_encoder* e, const int32_t* d_integer_ids, const u
         hipLaunchKernelGGL(doclens_scan_kernel, dim3(1), dim3(64), 0, st, d_doclens, (int)N, e->qlens.as<int64_t>(), d_n_out);
         hipLaunchKernelGGL(epilogue_normalize_kernel, dim3(blocks_for(L * N, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim,
                            (int)L, (int)N, e->qmask.as<uint8_t>(), e->qlens.as<int64_t>(), d_out_embs, e->err.as<int>());
+    }
+    CLB_HIP(hipGetLastError());
+    return CLB_OK;
+}
+
+int clb_encode_docs_packed_device(clb_encoder* e, const int32_t* d_ids, const int32_t* d_pos, const int32_t* d_seq, const int32_t* d_cu,
+                                  int64_t N, int64_t Lmax, int64_t rows, const int64_t* d_skiplist, int64_t n_skip, float* d_out_embs,
+                                  int64_t* d_doclens, int64_t* d_n_out, void* hip_stream) {
+    if (!e || !d_ids || !d_pos || !d_seq || !d_cu || !d_out_embs || !d_doclens || !d_n_out) return fail(CLB_EARGUMENT, "null argument");
+    if (N < 1 || Lmax < 1 || rows < N || rows > N * Lmax) return fail(CLB_EARGUMENT, "packed batch: N >= 1, N <= rows <= N * Lmax");
+    if (Lmax > e->max_pos) return fail(CLB_EBOUNDS, "sequence length %lld exceeds max_position_embeddings %lld", (long long)Lmax, (long long)e->max_pos);
+    CLB_TRY(use_device(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * rows));
+    CLB_TRY(e->prank.ensure(sizeof(uint32_t) * (rows + 1)));
+    const Packed pk{d_pos, d_seq, d_cu, rows};
+    CLB_TRY(forward(e, Lmax, N, st, d_ids, nullptr, /*sync=*/false, &pk));
+    {
+        EncTimed tm(e, ES_EPILOGUE, st);
+        hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, st, d_ids, rows, d_skiplist, (int)n_skip,
+                           e->pkeep.as<uint32_t>());
+        CLB_TRY(exclusive_scan_u32(e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), (size_t)rows, st, &e->scan_tmp));
+        hipLaunchKernelGGL(packed_doclens_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->prank.as<uint32_t>(), d_cu, (int)N, d_doclens,
+                           d_n_out);
+        hipLaunchKernelGGL(packed_normalize_kernel, dim3(blocks_for(rows, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim, rows,
+                           e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), d_out_embs, e->err.as<int>());
     }
     CLB_HIP(hipGetLastError());
     return CLB_OK;

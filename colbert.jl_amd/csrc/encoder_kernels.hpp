@@ -487,6 +487,9 @@ struct GemmPArgs {
     // vt_index; no fp32 copy exists
     uint16_t* Vt = nullptr; int64_t vt_plane = 0;
     int att_L = 0, att_H = 0, att_heads = 0;
+    // packed batches (sequences of different lengths back to back, no padding rows): the sequence and the position of
+    // every row; null: row m = sequence m / att_L, position m % att_L
+    const int32_t* att_seq = nullptr; const int32_t* att_pos = nullptr;
 };
 
 // V for attention_f16_kernel: [sequence][head][tile of 32 keys][d = 0..63][32 keys], the keys of a tile in the order in which
@@ -895,8 +898,8 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
         if (m >= g.M) continue;
         int64_t vrow = 0;                 // EPI_QKV_ATT: vt_index of (this token, head 0, d 0)
         if (qkv_att) {
-            const uint32_t seq = (uint32_t)m / (uint32_t)g.att_L;
-            vrow = vt_index(seq, 0, g.att_heads, att_nt, m - (int)seq * g.att_L, 0);
+            const uint32_t seq = g.att_seq ? (uint32_t)g.att_seq[m] : (uint32_t)m / (uint32_t)g.att_L;
+            vrow = vt_index(seq, 0, g.att_heads, att_nt, g.att_pos ? g.att_pos[m] : m - (int)seq * g.att_L, 0);
         }
 #pragma unroll
         for (int b = 0; b < WN; ++b)
@@ -938,7 +941,8 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
                                                                        uint16_t* __restrict__ Cp = nullptr, int64_t c_plane = 0,
                                                                        int ns = 0, uint16_t* __restrict__ Vt = nullptr,
                                                                        int64_t vt_plane = 0, int att_L = 0, int att_H = 0,
-                                                                       int att_heads = 0) {
+                                                                       int att_heads = 0, const int32_t* __restrict__ att_seq = nullptr,
+                                                                       const int32_t* __restrict__ att_pos = nullptr) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int n = (int)(idx % N);
@@ -961,10 +965,10 @@ static __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const fl
         if (n < 2 * att_H) store_planes(Cp + plane_index(m, n, M), c_plane, PF_F16X2, v);
         else {
             const int d0 = n - 2 * att_H;
-            const int64_t seq = m / att_L;
+            const int64_t seq = att_seq ? att_seq[m] : m / att_L;
             uint16_t hi, lo;
             split2_f16(v * kF16ActScale, hi, lo);
-            const int64_t at = vt_index(seq, d0 >> 6, att_heads, (att_L + 31) >> 5, (int)(m - seq * att_L), d0 & 63);
+            const int64_t at = vt_index(seq, d0 >> 6, att_heads, (att_L + 31) >> 5, att_pos ? att_pos[m] : (int)(m - seq * att_L), d0 & 63);
             Vt[at] = hi;
             Vt[at + vt_plane] = lo;
         }
@@ -1125,13 +1129,13 @@ static __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32
                                                                     const float* __restrict__ beta, float eps,
                                                                     float* __restrict__ out, int* __restrict__ err,
                                                                     uint16_t* __restrict__ outp = nullptr, int64_t o_plane = 0,
-                                                                    int ns = 0) {
+                                                                    int ns = 0, const int32_t* __restrict__ tok_pos = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= n_tok) return;
     int id = ids[t] - 1;
     if (id < 0 || id >= vocab) { if (lane == 0) atomicOr(err, 1); id = 0; }
-    const int l = (int)(t % L);
+    const int l = tok_pos ? tok_pos[t] : (int)(t % L);       // packed batches carry every token's position
     if (H <= 64 * 16) {      // the row stays in registers between the three passes (it was written and re-read twice: 17 us)
         float v[16];
         float sum = 0.f;
@@ -1474,17 +1478,26 @@ template <int QB>
 static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kernel(const uint16_t* __restrict__ qk, int64_t qk_plane, int64_t rows,
                                                                                    const uint16_t* __restrict__ vt, int64_t vt_plane,
                                                                                    const uint8_t* __restrict__ mask, int L, int H, float scale,
-                                                                                   uint16_t* __restrict__ ctxp, int64_t c_plane, int ns) {
+                                                                                   uint16_t* __restrict__ ctxp, int64_t c_plane, int ns,
+                                                                                   const int32_t* __restrict__ cu = nullptr) {
+    // cu (packed batches): sequence n owns rows cu[n] .. cu[n + 1] - 1, every one of them attended (no mask array); the
+    // key-blocked V buffer keeps its per-sequence stride of ceil(Lmax / 32) tiles (L = Lmax here)
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 32 * QB, head = blockIdx.y, heads = gridDim.y;
     const int64_t n = blockIdx.z;
-    const uint8_t* mk = mask + n * L;
+    const int nt_layout = (L + 31) >> 5;
+    const int64_t row0 = cu ? (int64_t)cu[n] : n * L;
+    if (cu) {
+        L = cu[n + 1] - cu[n];
+        if (q0 >= L) return;
+    }
+    const uint8_t* mk = cu ? nullptr : mask + n * L;
     const int nt = (L + 31) >> 5;
     u32x4 qh[QB][4], ql[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + 32 * qb + i;
-        const int64_t qrow = n * L + (qi < L ? qi : L - 1);
+        const int64_t qrow = row0 + (qi < L ? qi : L - 1);
         const uint16_t* qp = qk + plane_index(qrow, head * 64 + 32 * h, rows);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1502,13 +1515,13 @@ static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kern
     }
     const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale)) * 1.44269504088896340736f;     // -> log2 domain
     constexpr float kPScale = 1024.0f;
-    const uint16_t* vbase = vt + ((((n * heads + head) * nt) * 64 + i) << 5) + 16 * h;
+    const uint16_t* vbase = vt + ((((n * heads + head) * nt_layout) * 64 + i) << 5) + 16 * h;
     for (int jt = 0; jt < nt; ++jt) {
         const int key = 32 * jt + i;
         const int krow = key < L ? key : L - 1;
-        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && mk[krow] != 0);
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && (!mk || mk[krow] != 0));
         if (valid == 0u) continue;
-        const uint16_t* kp = qk + plane_index(n * L + krow, H + head * 64 + 32 * h, rows);
+        const uint16_t* kp = qk + plane_index(row0 + krow, H + head * 64 + 32 * h, rows);
         u32x4 kh[4], kl[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1588,7 +1601,7 @@ static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kern
             }
         }
     }
-    const int64_t rows_ = (int64_t)gridDim.z * L;
+    const int64_t rows_ = rows;                         // the ctx planes have as many rows as the Q | K planes
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
@@ -1601,7 +1614,7 @@ static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kern
             const float sc = h ? s1 : s0;
             const int q = q0 + 32 * qb + qa + 4 * h;
             if (q < L) {
-                const int64_t trow = n * L + q;
+                const int64_t trow = row0 + q;
                 store_planes(ctxp + plane_index(trow, head * 64 + i, rows_), c_plane, ns, o0[qb][r] * sc);
                 store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows_), c_plane, ns, o1[qb][r] * sc);
             }

@@ -172,6 +172,23 @@ class BertEncoder:
                                            C.c_void_p(doclens.data_ptr()), C.c_void_p(n_dev.data_ptr()), C.c_void_p(st)))
         return out[: int(n_dev.item()) if n_out is None else int(n_out)], doclens
 
+    def doc_embeddings_packed_device(self, d_ids, d_pos, d_seq, d_cu, Lmax: int, d_skiplist, n_out: Optional[int] = None):
+        """_doc_embeddings_and_doclens for a PACKED batch (clb_encode_docs_packed_device): the N passages follow one another
+        without padding rows -- ids / pos / seq int32 (rows,), cu int32 (N + 1,) row offsets, Lmax the longest passage.
+        Same outputs as doc_embeddings_device.  Raises ArgumentError when the encoder cannot run packed batches (head size
+        other than 64, a GEMM mode other than f16x3): pad then."""
+        import torch
+        rows, N = int(d_ids.numel()), int(d_cu.numel()) - 1
+        out = torch.empty((rows, self.dim), dtype=torch.float32, device=d_ids.device)
+        doclens = torch.empty(N, dtype=torch.int64, device=d_ids.device)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=d_ids.device)
+        st = torch.cuda.current_stream(d_ids.device).cuda_stream
+        check(lib().clb_encode_docs_packed_device(self._h, C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_pos.data_ptr()),
+                                                  C.c_void_p(d_seq.data_ptr()), C.c_void_p(d_cu.data_ptr()), i64(N), i64(Lmax), i64(rows),
+                                                  C.c_void_p(d_skiplist.data_ptr()), i64(d_skiplist.numel()), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(doclens.data_ptr()), C.c_void_p(n_dev.data_ptr()), C.c_void_p(st)))
+        return out[: int(n_dev.item()) if n_out is None else int(n_out)], doclens
+
     def capture_query_graph(self, d_ids, d_mask, d_skiplist, d_out):
         """The ~90 launches of one `query_embeddings_device` call over STATIC buffers as a HIP graph (torch.cuda.CUDAGraph):
         write the next batch's ids into `d_ids` (and `d_mask`), `graph.replay()`, read `d_out`.  The library enqueues only

@@ -205,8 +205,9 @@ class EncoderSource(DeviceEmbeddingSource):
     chain forward -> mask -> normalise -> compact (BertEncoder.doc_embeddings_device = clb_encode_docs_device) without a
     read-back: the host prepares batch i + 1 while the device encodes batch i."""
 
-    def __init__(self, encoder, collection, device: int = 0):
+    def __init__(self, encoder, collection, device: int = 0, packed: bool = True):
         import torch
+        self.packed = packed          # batches without padding rows (clb_encode_docs_packed_device) where the encoder can
         self.encoder = encoder
         self.collection = collection
         self.dim = encoder.dim
@@ -242,6 +243,30 @@ class EncoderSource(DeviceEmbeddingSource):
             mask[j, :t.size] = 1
         return ids, mask
 
+    def _encode_packed(self, batch):
+        """The batch with its passages back to back and no padding rows: tensorize_docs pads to the batch's longest passage
+        with [PAD] tokens that the attention mask hides and the skiplist drops -- rows that never reach the output.  One
+        int32 upload (ids | positions | passage of every row | row offsets).  (None, None) if the encoder cannot (then the
+        caller pads, and no further batch tries)."""
+        import torch
+        from ._lib import ArgumentError
+        toks = [self._tokens[int(p)] for p in batch]
+        lens = np.array([t.size for t in toks], dtype=np.int32)
+        rows = int(lens.sum())
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        buf = np.empty(3 * rows + cu.size, dtype=np.int32)
+        buf[:rows] = np.concatenate(toks)
+        buf[rows:2 * rows] = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+        buf[2 * rows:3 * rows] = np.repeat(np.arange(lens.size, dtype=np.int32), lens)
+        buf[3 * rows:] = cu
+        d = torch.from_numpy(buf).to(self.device)
+        try:
+            return self.encoder.doc_embeddings_packed_device(d[:rows], d[rows:2 * rows], d[2 * rows:3 * rows], d[3 * rows:], int(lens.max()),
+                                                             self._d_skip, n_out=int(self.doclens[batch].sum()))
+        except ArgumentError:
+            self.packed = False
+            return None, None
+
     def encode_pids(self, pids):
         """encode_passages of the passages `pids` (batches of index_bsize, in this order) with the result left on the
         device -> (n, dim) float32 CUDA tensor.  Only enqueues, then checks the device's doclens once."""
@@ -253,10 +278,14 @@ class EncoderSource(DeviceEmbeddingSource):
         parts, lens = [], []
         for start in range(0, pids.size, bs):
             batch = pids[start:start + bs]
-            ids, mask = self._tensorize(batch)
-            d_ids = torch.from_numpy(ids).to(self.device)
-            d_mask = torch.from_numpy(mask).to(self.device)
-            x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self.doclens[batch].sum()))
+            x = None
+            if self.packed:
+                x, dl = self._encode_packed(batch)
+            if x is None:
+                ids, mask = self._tensorize(batch)
+                d_ids = torch.from_numpy(ids).to(self.device)
+                d_mask = torch.from_numpy(mask).to(self.device)
+                x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self.doclens[batch].sum()))
             parts.append(x); lens.append(dl)
         out = torch.cat(parts) if len(parts) > 1 else parts[0]
         self.encoder.check_last_ids()

@@ -349,6 +349,16 @@ int clb_encode_queries_device(clb_encoder* e, const int32_t* d_integer_ids, cons
 int clb_encode_docs_device(clb_encoder* e, const int32_t* d_integer_ids, const uint8_t* d_bitmask, int64_t L, int64_t N,
                            const int64_t* d_skiplist, int64_t n_skip, float* d_out_embs, int64_t* d_doclens,
                            int64_t* d_n_out, void* hip_stream);
+/* The same for a PACKED batch -- N passages back to back without padding rows: d_ids[rows] token ids (1-based), d_pos[rows]
+ * the position of every token in its passage (0-based), d_seq[rows] its passage (0..N-1), d_cu[N + 1] the row offsets
+ * (d_cu[N] = rows), Lmax the longest passage.  tensorize_docs (doc_tokenization.jl:143-156) pads a batch to its longest
+ * passage with [PAD], which the attention mask hides and the skiplist drops (checkpoint.jl:37-43): the padding rows never
+ * reach the output, and with passages of ~80 tokens in batches padded to ~160 they are half of the encoder's work.  Here
+ * they are not computed.  Every row counts as attended.  Needs the fp16-plane attention (head size 64, GEMM mode 3,
+ * attention mode 0): CLB_EARGUMENT otherwise -- the caller then pads.  Outputs as clb_encode_docs_device. */
+int clb_encode_docs_packed_device(clb_encoder* e, const int32_t* d_ids, const int32_t* d_pos, const int32_t* d_seq,
+                                  const int32_t* d_cu, int64_t N, int64_t Lmax, int64_t rows, const int64_t* d_skiplist,
+                                  int64_t n_skip, float* d_out_embs, int64_t* d_doclens, int64_t* d_n_out, void* hip_stream);
 /* The asynchronous device path cannot report an id outside the vocabulary when it is enqueued (it clamps): this call
  * waits for the device and returns the BoundsError of ANY device-path encode since the previous check (the flag is
  * sticky: set by the kernels, cleared by this call), or CLB_EDOMAIN when an encode produced non-finite embeddings (the

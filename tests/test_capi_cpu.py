@@ -112,6 +112,7 @@ def test_round4_entry_points_check_their_arguments_first():
     assert l.clb_build_ivf_device(0, None, i64(5), i64(4), None, None, None) == 4                          # null arrays
     assert l.clb_kmeans_shard_get_assignments(null, None) == 4
     assert l.clb_encode_docs_device(null, None, None, i64(8), i64(2), None, i64(0), None, None, None, None) == 4
+    assert l.clb_encode_docs_packed_device(null, None, None, None, None, i64(2), i64(8), i64(12), None, i64(0), None, None, None, None) == 4
     assert l.clb_kmeans_shard_create_device(0, None, i64(128), i64(5), i64(0), i64(1000), C.byref(out)) == 1   # K < 1
     if l.clb_device_count() == 0:      # valid arguments reach the device check: HIP error, nothing computed on the host
         assert l.clb_codec_create(0, i64(128), 2, i64(4), p(cent), p(cut), i64(3), C.byref(out)) == 10

@@ -444,3 +444,39 @@ def test_passage_batch_plans_with_an_odd_number_of_heads():
         print(f"[passage-batch plans, 3 heads, {attention}] max |got - torch fp32| = {err:.3g}")
         assert err < 1e-4, (attention, err)
     assert np.abs(outs["fused"] - outs["fused_f32"]).transpose(2, 1, 0)[mask].max() < 5e-5
+
+
+@pytest.mark.gpu
+def test_packed_passage_batches_match_padded_ones(tok):
+    """EncoderSource encodes a batch without its padding rows (clb_encode_docs_packed_device): the same doclens and, per kept
+    token, the embedding of the padded batch up to the rounding of a different tile plan; an encoder that cannot run packed
+    batches (here: the bf16x6 Linear layers) falls back to padding, bit for bit."""
+    torch, cfg, bert, linear = _random_bert(hidden=128, layers=2, heads=2, inter=256, vocab=len(VOCAB), max_pos=64, dim=64, seed=41)
+    from colbert_jl_amd.encoder import pack_weights
+    from colbert_jl_amd.indexer import EncoderSource
+    bcfg = cfg.to_dict()
+    words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with", "many", "words", "query", "colbert"]
+    rng = np.random.default_rng(42)
+    collection = [" ".join(rng.choice(words, size=rng.integers(1, 30))) + rng.choice([".", "!", "", " , ok"]) for _ in range(37)]
+    config = clb.ColBERTConfig(index_path="unused", doc_maxlen=40, query_maxlen=12, index_bsize=8, nbits=2)
+    w = pack_weights(_state(bert, linear), bcfg, 64)
+    enc = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config)
+    packed = EncoderSource(enc, collection, 0, packed=True)
+    padded = EncoderSource(enc, collection, 0, packed=False)
+    order = np.arange(len(collection))
+    a = packed.encode_pids(order)
+    assert packed.packed is True                                     # head size 64, f16x3: the packed path ran
+    b = padded.encode_pids(order)
+    assert a.shape == b.shape == (int(packed.doclens.sum()), 64)
+    assert float((a - b).abs().max()) < 5e-5
+    assert torch.allclose(a.norm(dim=1), torch.ones(a.shape[0], device=a.device), atol=1e-5)
+    some = np.array([3, 4, 20, 36])
+    assert float((packed.sample(some) - padded.sample(some)).abs().max()) < 5e-5
+    enc.close()
+    enc6 = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, gemm="bf16x6")
+    fallback = EncoderSource(enc6, collection, 0, packed=True)
+    c = fallback.encode_pids(order)
+    assert fallback.packed is False
+    d = EncoderSource(enc6, collection, 0, packed=False).encode_pids(order)
+    assert torch.equal(c, d)
+    enc6.close()
