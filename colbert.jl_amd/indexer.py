@@ -205,9 +205,10 @@ class EncoderSource(DeviceEmbeddingSource):
     chain forward -> mask -> normalise -> compact (BertEncoder.doc_embeddings_device = clb_encode_docs_device) without a
     read-back: the host prepares batch i + 1 while the device encodes batch i."""
 
-    def __init__(self, encoder, collection, device: int = 0, packed: bool = True):
+    def __init__(self, encoder, collection, device: int = 0, packed: bool = True, pack_batches: int = 4):
         import torch
         self.packed = packed          # batches without padding rows (clb_encode_docs_packed_device) where the encoder can
+        self.pack_batches = int(os.environ.get("COLBERT_PACK_BATCHES", pack_batches))
         self.encoder = encoder
         self.collection = collection
         self.dim = encoder.dim
@@ -274,7 +275,8 @@ class EncoderSource(DeviceEmbeddingSource):
         pids = np.asarray(pids, dtype=np.int64)
         if pids.size == 0:
             return torch.empty((0, self.dim), dtype=torch.float32, device=self.device)
-        bs = self.encoder.config.index_bsize
+        # packed batches need no common length: several index_bsize batches go into one call (rows, not passages, fill the chip)
+        bs = self.encoder.config.index_bsize * (self.pack_batches if self.packed else 1)
         parts, lens = [], []
         for start in range(0, pids.size, bs):
             batch = pids[start:start + bs]
