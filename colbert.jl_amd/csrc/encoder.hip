@@ -183,7 +183,9 @@ bool linear_split(hipStream_t st, Gemm3Args g, float* part, const LnArgs* ln) {
 struct PlanCfg { int bm, bn, stages, ks; };
 struct AttOut { uint16_t* qk; int64_t qk_plane; uint16_t* vt; int64_t vt_plane; int L, H, heads; const int32_t* seq; const int32_t* pos; };   // EPI_QKV_ATT targets
 // a packed batch: N sequences back to back without padding rows (device arrays: position and sequence of every row, row offsets)
-struct Packed { const int32_t* pos; const int32_t* seq; const int32_t* cu; int64_t rows; };
+// `pos`: index of the position embedding; `rank` (null = pos): the row's rank inside its sequence, which is what the attention
+// kernel and the key-blocked V buffer go by -- they differ when a mask has holes (host path), not for prefix masks
+struct Packed { const int32_t* pos; const int32_t* seq; const int32_t* cu; int64_t rows; const int32_t* rank = nullptr; };
 enum LinRole { LR_QKV = 0, LR_ATTN_OUT, LR_FFN_IN, LR_FFN_OUT, LR_PROJ, LR_COUNT };
 // COLBERT_ENC_PLAN="qkv=64x128x3x1,attn_out=64x64x3x4,...": tile / ring depth / K split per Linear role (tuning runs)
 static const PlanCfg* plan_override(int role) {
@@ -395,6 +397,13 @@ int split_weights(clb_encoder* e, int fmt) {
 
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
 // sync = false: everything is only enqueued on `st` (an out-of-vocabulary id is then clamped silently).
+// whether a batch of at most `rows_max` rows and sequences up to L can run packed (the conditions of the fp16-plane attention)
+static bool can_pack(const clb_encoder* e, int64_t L, int64_t rows_max = 0) {
+    const int64_t H = e->H, I = e->I;
+    return e->planes && e->gemm_mode == 3 && H % 32 == 0 && I % 32 == 0 && e->heads > 0 && H / e->heads == 64 && L <= 512 &&
+           e->attention_mode == 0 && !planes_first_form() && rows_max * std::max(H, I) * 6 < ((int64_t)1 << 31);
+}
+
 // pk (packed batch): d_ids holds pk->rows token ids, L is the longest sequence, d_mask is unused; needs the fp16-plane attention.
 int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t* d_ids, const uint8_t* d_mask,
             bool sync = true, const Packed* pk = nullptr) {
@@ -436,7 +445,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         }
     }
     const AttOut att_out{e->qkp.as<uint16_t>(), qk_plane, e->vtp.as<uint16_t>(), vt_plane, (int)L, (int)H, (int)heads, pk ? pk->seq : nullptr,
-                         pk ? pk->pos : nullptr};
+                         pk ? (pk->rank ? pk->rank : pk->pos) : nullptr};
     uint16_t* xp = e->xp.as<uint16_t>(); uint16_t* ctxp = e->ctxp.as<uint16_t>();
     uint16_t* tmpp = e->tmpp.as<uint16_t>(); uint16_t* hbp = e->hbp.as<uint16_t>();
     const uint16_t* WP = e->wplanes.as<uint16_t>();
@@ -689,8 +698,79 @@ int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmas
     return CLB_OK;
 }
 
+// The host entry point packs its batch itself when it may: every unattended token must be one the skiplist drops (the [PAD]
+// padding of tensorize_docs is; a caller's own mask need not be) and the encoder must be able to (can_pack) -- then the rows
+// the output never sees are not computed.  Attended tokens keep their positions, so any mask shape packs, not only prefixes.
+static int encode_docs_packed_host(clb_encoder* e, const int32_t* ids, const uint8_t* mask, int64_t L, int64_t N, const int64_t* skiplist,
+                                   int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out, bool* done) {
+    *done = false;
+    if (L * N < 1) return CLB_OK;
+    std::vector<int32_t> buf;            // ids | positions | sequence of every attended row | row offsets
+    std::vector<int32_t> pid, ppos, pseq, cu((size_t)N + 1, 0);
+    pid.reserve((size_t)L * N); ppos.reserve((size_t)L * N); pseq.reserve((size_t)L * N);
+    int64_t lmax = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        int64_t last = -1;
+        for (int64_t l = 0; l < L; ++l) {
+            const int32_t id = ids[n * L + l];
+            if (mask[n * L + l]) { pid.push_back(id); ppos.push_back((int32_t)l); pseq.push_back((int32_t)n); last = l; continue; }
+            bool dropped = false;
+            for (int64_t k = 0; k < n_skip; ++k) dropped = dropped || (int64_t)id == skiplist[k];
+            if (!dropped) return CLB_OK;             // an unattended token the reference keeps: the padded path computes it
+        }
+        if (last < 0) return CLB_OK;                 // a sequence without attended tokens: padded path
+        cu[(size_t)n + 1] = (int32_t)pid.size();
+        lmax = std::max(lmax, last + 1);
+    }
+    const int64_t rows = (int64_t)pid.size();
+    // positions are those of the padded layout, but the key-blocked V buffer is indexed by the RANK of a token in its sequence
+    // (attention_f16_kernel walks a sequence's rows): re-number per sequence for V / attention, keep `ppos` for the embeddings
+    std::vector<int32_t> prank((size_t)rows);
+    int64_t longest = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        for (int32_t r = cu[(size_t)n]; r < cu[(size_t)n + 1]; ++r) prank[(size_t)r] = r - cu[(size_t)n];
+        longest = std::max<int64_t>(longest, cu[(size_t)n + 1] - cu[(size_t)n]);
+    }
+    (void)lmax;
+    hipStream_t st = e->stream;
+    DevBuf dIds, dPos, dRank, dSeq, dCu, dSkip, dOut, dLens, dN;
+    CLB_TRY(upload(dIds, pid.data(), sizeof(int32_t) * rows, st));
+    CLB_TRY(upload(dPos, ppos.data(), sizeof(int32_t) * rows, st));
+    CLB_TRY(upload(dRank, prank.data(), sizeof(int32_t) * rows, st));
+    CLB_TRY(upload(dSeq, pseq.data(), sizeof(int32_t) * rows, st));
+    CLB_TRY(upload(dCu, cu.data(), sizeof(int32_t) * (N + 1), st));
+    CLB_TRY(upload(dSkip, skiplist, sizeof(int64_t) * std::max<int64_t>(n_skip, 1), st));
+    CLB_TRY(dOut.alloc(sizeof(float) * e->dim * rows));
+    CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
+    CLB_TRY(dN.alloc(sizeof(int64_t)));
+    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * rows));
+    CLB_TRY(e->prank.ensure(sizeof(uint32_t) * (rows + 1)));
+    const Packed pk{dPos.as<int32_t>(), dSeq.as<int32_t>(), dCu.as<int32_t>(), rows, dRank.as<int32_t>()};
+    CLB_TRY(forward(e, longest, N, st, dIds.as<int32_t>(), nullptr, /*sync=*/true, &pk));
+    hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, st, dIds.as<int32_t>(), rows, dSkip.as<int64_t>(),
+                       (int)n_skip, e->pkeep.as<uint32_t>());
+    CLB_TRY(exclusive_scan_u32(e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), (size_t)rows, st, &e->scan_tmp));
+    hipLaunchKernelGGL(packed_doclens_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->prank.as<uint32_t>(), dCu.as<int32_t>(), (int)N,
+                       dLens.as<int64_t>(), dN.as<int64_t>());
+    hipLaunchKernelGGL(packed_normalize_kernel, dim3(blocks_for(rows, 64)), dim3(64), 0, st, e->out.as<float>(), (int)e->dim, rows,
+                       e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), dOut.as<float>(), e->err.as<int>());
+    CLB_HIP(hipGetLastError());
+    CLB_HIP(hipMemcpyAsync(doclens, dLens.p, sizeof(int64_t) * N, hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipMemcpyAsync(n_out, dN.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (*n_out > 0) CLB_HIP(hipMemcpyAsync(out_embs, dOut.p, sizeof(float) * e->dim * (*n_out), hipMemcpyDeviceToHost, st));
+    *done = true;
+    return finish_checked(e, st);
+}
+
 int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
                     const int64_t* skiplist, int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out) {
+    if (e && integer_ids && bitmask && skiplist && out_embs && doclens && n_out && L >= 1 && N >= 1 && L <= e->max_pos && can_pack(e, L, L * N)) {
+        CLB_TRY(use_device(e->device));
+        bool done = false;
+        CLB_TRY(encode_docs_packed_host(e, integer_ids, bitmask, L, N, skiplist, n_skip, out_embs, doclens, n_out, &done));
+        if (done) return CLB_OK;
+    }
     CLB_TRY(upload_inputs(e, integer_ids, bitmask, L, N));
     CLB_TRY(forward(e, L, N, e->stream, e->ids.as<int32_t>(), e->mask.as<uint8_t>()));
     hipStream_t st = e->stream;

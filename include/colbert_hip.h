@@ -328,7 +328,11 @@ int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
 int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out);
 /* _doc_embeddings_and_doclens  (checkpoint.jl:27-52): forward, clear skiplist tokens, normalise, doclens,
- * compaction.  out_embs (dim, <= L*N); doclens Int64[N]; *n_out = kept columns. */
+ * compaction.  out_embs (dim, <= L*N); doclens Int64[N]; *n_out = kept columns.
+ * When every unattended token (bitmask 0) is one the skiplist drops -- the [PAD] padding of tensorize_docs is -- and the
+ * encoder runs the fp16-plane attention, the rows the output never sees are not computed (the batch is packed on the way to
+ * the device, attended tokens keep their positions): same outputs up to the rounding of a different tile plan, about twice
+ * the throughput on batches padded to their longest passage.  Otherwise the whole (L, N) batch is computed. */
 int clb_encode_docs(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N,
                     const int64_t* skiplist, int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out);
 /* _query_embeddings  (checkpoint.jl:54-71): forward, clear skiplist tokens, normalise.  out (dim, L, N). */

@@ -472,6 +472,28 @@ def test_packed_passage_batches_match_padded_ones(tok):
     assert torch.allclose(a.norm(dim=1), torch.ones(a.shape[0], device=a.device), atol=1e-5)
     some = np.array([3, 4, 20, 36])
     assert float((packed.sample(some) - padded.sample(some)).abs().max()) < 5e-5
+    # the host entry point (clb_encode_docs: what the Julia shim calls) packs by itself -- also a mask with holes, whose
+    # attended tokens keep their positions; reference: the same call on an encoder that cannot pack (fp32-MFMA attention)
+    ref_enc = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_f32")
+    hd, hl = enc.encode_passages(collection)
+    rd, rl = ref_enc.encode_passages(collection)
+    assert np.array_equal(hl, rl) and np.array_equal(hl, packed.doclens) and hd.shape == rd.shape
+    assert np.abs(hd - rd).max() < 5e-5
+    ids, mask = tokenization.tensorize_docs(config.doc_token_id, tok, collection[:8], config.doc_maxlen)
+    ids = np.array(ids); mask = np.array(mask, dtype=bool)
+    holes = (rng.random(ids.shape) < 0.2) & mask
+    holes[:2, :] = False
+    ids[holes] = tok.pad_id; mask[holes] = False
+    skip = tok.doc_skiplist(True)
+    g_e, g_l = enc.doc_embeddings_and_doclens(skip, ids, mask)
+    r_e, r_l = ref_enc.doc_embeddings_and_doclens(skip, ids, mask)
+    assert np.array_equal(g_l, r_l) and g_e.shape == r_e.shape and np.abs(g_e - r_e).max() < 5e-5
+    # an unattended token the skiplist does NOT drop must be computed: the call then takes the padded path
+    ids2 = ids.copy(); ids2[holes] = tok.lookup("hello")
+    g_e, g_l = enc.doc_embeddings_and_doclens(skip, ids2, mask)
+    r_e, r_l = ref_enc.doc_embeddings_and_doclens(skip, ids2, mask)
+    assert np.array_equal(g_l, r_l) and np.abs(g_e - r_e).max() < 5e-5
+    ref_enc.close()
     enc.close()
     enc6 = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, gemm="bf16x6")
     fallback = EncoderSource(enc6, collection, 0, packed=True)
