@@ -112,21 +112,27 @@ def _index_through_device(indexer: Indexer) -> str:
     """index() over index_device: the encoder's output, the sample, the codes and the residuals stay in HBM; what is
     written is the reference's directory (sample, sample_heldout, plan.json, config.json, the codec, per chunk codes /
     residuals / doclens / metadata, ivf, ivf_lengths -- indexing.jl:84-147)."""
+    import time
     cfg = indexer.config
     path = cfg.index_path
+    t0 = time.time()
     source = EncoderSource(indexer.encoder, indexer.collection, indexer.device)
+    t_tok = time.time() - t0
     os.makedirs(path)
-    state = {}
+    state = {"write_s": 0.0}
 
     def on_sample(sample, heldout, plan):
+        t1 = time.time()
         storage._save(os.path.join(path, "sample"), np.asfortranarray(sample.cpu().numpy().T))
         storage._save(os.path.join(path, "sample_heldout"), np.asfortranarray(heldout.cpu().numpy().T))
         storage.save_json(path, "plan.json", plan)
         cfg.save(path)
         state["plan"] = plan
+        state["write_s"] += time.time() - t1
 
-    ix, _ = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
-                         nranks=cfg.nranks, on_sample=on_sample)
+    ix, rec = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
+                           nranks=cfg.nranks, on_sample=on_sample)
+    t_w = time.time()
     plan = state["plan"]
     storage.save_codec(path, np.asfortranarray(ix["centroids"].cpu().numpy().T), ix["bucket_cutoffs"], ix["bucket_weights"],
                        ix["avg_residual"])
@@ -150,6 +156,9 @@ def _index_through_device(indexer: Indexer) -> str:
     storage._save(os.path.join(path, "ivf"), ix["ivf"].cpu().numpy())
     storage._save(os.path.join(path, "ivf_lengths"), np.asarray(ix["ivf_lengths"]))
     assert storage.check_all_files_are_saved(path)
+    # seconds per stage of this build (tools/bench_index_with_encoder.py): sample_and_split_s and chunks_s are encoder time
+    rec.update({"tokenize_s": round(t_tok, 3), "write_sample_s": round(state["write_s"], 3), "write_index_s": round(time.time() - t_w, 3)})
+    indexer.last_build_record = rec
     return path
 
 

@@ -60,6 +60,7 @@ def main():
     torch.cuda.synchronize()
     rec["index_s"] = round(time.time() - t0, 2)
     rec["index_passages_per_s"] = round(args.docs / rec["index_s"], 1)
+    rec["stages"] = {k: v for k, v in getattr(indexer, "last_build_record", {}).items() if k.endswith("_s")}
     rec["index_bytes"] = sum(os.path.getsize(os.path.join(config.index_path, f)) for f in os.listdir(config.index_path))
     searcher = clb.Searcher(config.index_path, encoder=enc)
     pids, scores = clb.search(searcher, collection[17], 10)
