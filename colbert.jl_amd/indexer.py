@@ -59,7 +59,9 @@ def train(sample, heldout, num_partitions: int, nbits: int, kmeans_niters: int, 
 def index(indexer: Indexer, device_resident: Optional[bool] = None) -> Optional[str]:
     """index(indexer) (indexing.jl:63-147).  With an encoder that can leave its embeddings on the device
     (BertEncoder.doc_embeddings_device) the build runs through index_device -- no embedding crosses PCIe -- and writes the
-    same files (`device_resident=False` forces the host-buffer route; both draw the same numbers from indexer.rng)."""
+    same files (`device_resident=False` forces the host-buffer route; both draw the same numbers from indexer.rng): byte for
+    byte when the encoder pads its batches, up to the rounding of different tile plans when it packs them (head size 64 with
+    the f16x3 Linear layers: the device route packs 256 passages per call, the host entry point one batch)."""
     cfg = indexer.config
     path = cfg.index_path
     if os.path.isdir(path):                                  # indexing.jl:64-67
