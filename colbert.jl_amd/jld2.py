@@ -140,30 +140,35 @@ def save_object(path: str, obj) -> None:
     if a.dtype.byteorder == ">":
         a = a.astype(a.dtype.newbyteorder("<"))
     dtmsg = _datatype_message(a.dtype)
-    raw = np.asfortranarray(a).tobytes(order="F")       # column-major element order == Julia's memory
+    # column-major element order == Julia's memory.  Large arrays (the fp32 sample of a 1 M-passage index is 6.6 GB) are
+    # written from the array's own buffer: no bytes object of the whole file is ever assembled
+    af = np.asfortranarray(a)
+    flat = af.ravel(order="K") if a.ndim else af.reshape(1)        # a view: the array is contiguous in memory
+    nbytes = int(flat.nbytes)
     if a.ndim == 0:
         dataspace = struct.pack("<BBBB", 2, 0, 0, 0)    # version 2, rank 0, flags 0, type 0 = scalar
     else:
         dims = tuple(reversed(a.shape))                 # HDF5 is row-major: fastest dimension last
         dataspace = struct.pack("<BBBB", 2, len(dims), 0, 1) + b"".join(struct.pack("<Q", int(d)) for d in dims)
-    compact = len(raw) < COMPACT_LIMIT
+    compact = nbytes < COMPACT_LIMIT
     base = FILE_HEADER_LENGTH
     superblock_size = 48
     ds_addr = superblock_size                            # addresses are relative to the base address
     msgs = [_header_message(HM_DATASPACE, dataspace), _header_message(HM_DATATYPE, dtmsg, flags=1)]
     if compact:
-        layout = struct.pack("<BBH", 3, 0, len(raw)) + raw
+        layout = struct.pack("<BBH", 3, 0, nbytes) + flat.tobytes()
         msgs.append(_header_message(HM_LAYOUT, layout))
         dataset = _object_header(msgs)
-        data_addr, tail = None, b""
+        gap, tail_len = b"", 0
     else:
         # the header's size does not depend on the address, so it can be sized first
-        probe = _object_header(msgs + [_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, 0, len(raw)))])
+        probe = _object_header(msgs + [_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, 0, nbytes))])
         data_addr = (ds_addr + len(probe) + 7) // 8 * 8
-        msgs.append(_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, data_addr, len(raw))))
+        msgs.append(_header_message(HM_LAYOUT, struct.pack("<BBQQ", 3, 1, data_addr, nbytes)))
         dataset = _object_header(msgs)
-        tail = b"\x00" * (data_addr - ds_addr - len(dataset)) + raw
-    root_addr = (ds_addr + len(dataset) + len(tail) + 7) // 8 * 8
+        gap = b"\x00" * (data_addr - ds_addr - len(dataset))
+        tail_len = len(gap) + nbytes
+    root_addr = (ds_addr + len(dataset) + tail_len + 7) // 8 * 8
     name = OBJECT_NAME.encode()
     link = struct.pack("<BBB", 1, 0x00, len(name)) + name + struct.pack("<Q", ds_addr)   # hard link, 1-byte name length
     root = _object_header([
@@ -175,11 +180,13 @@ def save_object(path: str, obj) -> None:
     sb += struct.pack("<I", lookup3(sb))
     assert len(sb) == superblock_size
     text = (REQUIRED_FILE_HEADER + FORMAT_VERSION + b"\x00 (colbert.jl_amd python writer, 64-bit little-endian)")
-    body = sb + dataset + tail
-    body += b"\x00" * (root_addr - len(body)) + root
     with open(path, "wb") as f:
         f.write(text + b"\x00" * (FILE_HEADER_LENGTH - len(text)))
-        f.write(body)
+        f.write(sb + dataset)
+        if not compact:
+            f.write(gap)
+            f.write(memoryview(flat).cast("B"))
+        f.write(b"\x00" * (root_addr - (len(sb) + len(dataset) + tail_len)) + root)
 
 
 # ---------------------------------------------------------------------------------------------------
