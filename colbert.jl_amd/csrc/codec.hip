@@ -26,6 +26,7 @@ struct Stream {
 // Scratch of the bf16x3 nearest-centroid path, kept across calls (k-means calls it once per iteration).
 struct NearestScratch {
     DevBuf hi, lo, bias, partial, cn;
+    DevBuf ovf_list, ovf_count;      // points whose candidate lists overflowed (mass ties): re-scored against all centroids
 };
 
 // device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means.
@@ -55,6 +56,8 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
         const int n_tiles = (K + 31) / 32;
         const int64_t chunk_max = (int64_t)1 << 22;                     // points per launch: 256 MB of group lists
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)((std::min(n, chunk_max) + 31) / 32) * 2 * 32 * kTopPartial));
+        CLB_TRY(w.ovf_list.ensure(sizeof(uint32_t) * (size_t)std::min(n, chunk_max)));
+        CLB_TRY(w.ovf_count.ensure(sizeof(unsigned int)));
         const size_t lds = 2 * 2 * 32 * kRowBytes16;
         for (int64_t p0 = 0; p0 < n; p0 += chunk_max) {
             const int64_t m = std::min(chunk_max, n - p0);
@@ -70,9 +73,14 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
                                    w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), dX + (size_t)p0 * kDim,
                                    w.partial.as<ValIdx>(), (uint32_t*)nullptr, K, 32, groups32, n_tiles,
                                    (const float*)nullptr, m);
+            CLB_HIP(hipMemsetAsync(w.ovf_count.p, 0, sizeof(unsigned int), st));
             hipLaunchKernelGGL(nearest_refine_kernel<MODE>, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st,
                                w.partial.as<ValIdx>(), dC, dc2, dX + (size_t)p0 * kDim, m, K, w.cn.as<unsigned int>(),
-                               dOut + p0);
+                               dOut + p0, w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>());
+            // the overflow list (normally empty: the launch reads a zero and ends) on the fp32 MFMA, all K centroids per point
+            hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3((unsigned)std::min<int64_t>(2048, (m + 63) / 64)), dim3(128),
+                               2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX + (size_t)p0 * kDim,
+                               w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), dOut + p0);
         }
     } else if (dim == kDim) {
         const int64_t ptiles = (n + 31) / 32;

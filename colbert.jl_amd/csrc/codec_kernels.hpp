@@ -469,13 +469,91 @@ static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const 
 // one) with the canonical arithmetic.  A full list whose last entry qualifies triggers the exhaustive scan.
 // grid = ceil(n / 16), block = 256 (4 waves x 4 points).
 // -------------------------------------------------------------------------------------------------------------
+// nearest_centroid_mfma_kernel over a LIST of points (the overflow list of nearest_refine_kernel; `count` lives on the device):
+// the same exact arithmetic and tie rule, 32 listed points per wave, the grid loops over the list.
+template <int MODE>
+static __global__ __launch_bounds__(128) void nearest_centroid_mfma_list_kernel(const float* __restrict__ C,
+                                                                         const float* __restrict__ c2, int K,
+                                                                         const float* __restrict__ X,
+                                                                         const uint32_t* __restrict__ list,
+                                                                         const unsigned int* __restrict__ count_p,
+                                                                         uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    float* my = lds + wave * (32 * kCentTileStride);
+    const int64_t count = (int64_t)*count_p;
+    for (int64_t ptile = (int64_t)blockIdx.x * 2 + wave; ptile * 32 < count; ptile += (int64_t)gridDim.x * 2) {
+        const int64_t slot = ptile * 32 + i;
+        const int64_t pt = list[slot < count ? slot : count - 1];
+        const float* xrow = X + (size_t)pt * kDim;
+        float qf[64];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            float4 v = *reinterpret_cast<const float4*>(xrow + 4 * m);
+            qf[2 * m] = h ? v.y : v.x;
+            qf[2 * m + 1] = h ? v.w : v.z;
+        }
+        float x2 = 0.f;
+        if (MODE == 1) x2 = sumsq_canonical(xrow, kDim);
+        float bestv = 0.f;
+        int best = 0x7fffffff;
+        const int n_tiles = (K + 31) / 32;
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int c0 = tile * 32;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int row = 2 * m + h;
+                int c = c0 + row;
+                c = c < K ? c : K - 1;
+                float4 v = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 4 * i);
+                *reinterpret_cast<float4*>(my + row * kCentTileStride + 4 * i) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                float4 a4 = *reinterpret_cast<const float4*>(my + i * kCentTileStride + 4 * m);
+                const float a0 = h ? a4.y : a4.x;
+                const float a1 = h ? a4.w : a4.z;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qf[2 * m], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qf[2 * m + 1], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (c < K) {
+                    float v = acc[r];
+                    if (MODE == 1) {
+                        v = -2.0f * v;
+                        v = v + c2[c];
+                        v = v + x2;
+                        if (best == 0x7fffffff || v < bestv || (v == bestv && c < best)) { bestv = v; best = c; }
+                    } else {
+                        if (best == 0x7fffffff || v > bestv || (v == bestv && c < best)) { bestv = v; best = c; }
+                    }
+                }
+            }
+        }
+        const float ov = __shfl_xor(bestv, 32, 64);
+        const int oi = __shfl_xor(best, 32, 64);
+        const bool take = MODE == 1 ? (ov < bestv || (ov == bestv && oi < best)) : (ov > bestv || (ov == bestv && oi < best));
+        if (oi != 0x7fffffff && (best == 0x7fffffff || take)) { bestv = ov; best = oi; }
+        if (h == 0 && slot < count) out[pt] = (uint32_t)(best + 1);
+    }
+}
 template <int MODE>
 static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx* __restrict__ partial,
                                                                    const float* __restrict__ C,
                                                                    const float* __restrict__ c2,
                                                                    const float* __restrict__ X, int64_t n, int K,
                                                                    const unsigned int* __restrict__ cn_max_bits,
-                                                                   uint32_t* __restrict__ out) {
+                                                                   uint32_t* __restrict__ out,
+                                                                   uint32_t* __restrict__ ovf_list = nullptr,
+                                                                   unsigned int* __restrict__ ovf_count = nullptr) {
     const int lane = threadIdx.x & 63, sub = lane & 15;
     const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const int64_t pp = p < n ? p : n - 1;                       // idle quarters shadow the last point
@@ -531,6 +609,12 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
             const int c = (gid >> 1) * 32 + (sub & 3) + 8 * (sub >> 2) + 4 * (gid & 1);
             if (c < K) consider(c);
         }
+    } else if (ovf_list) {
+        // mass ties (identical or nearly degenerate centroids: more qualifying groups than a list holds): the point is handed
+        // to nearest_centroid_mfma_list_kernel, which scores it against ALL centroids on the fp32 MFMA -- 16 lanes walking K
+        // centroids here took ~2 ms per point, and a sample whose embeddings are nearly degenerate sends thousands this way
+        if (sub == 0 && p < n) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
+        return;                                                       // uniform over the point's 16 lanes; no shuffle below is shared
     } else {
         for (int c = sub; c < K; c += 16) consider(c);
     }

@@ -128,6 +128,24 @@ def test_compress_ties_pick_first_centroid(oracle):
     assert np.all(codec.compress_into_codes(cent, embs) == 38)
 
 
+def test_nearest_centroid_mass_ties_take_the_list_path(oracle):
+    """Nearly degenerate data (what a random-weight encoder produces): hundreds of identical or almost identical centroids,
+    so that a point's candidate lists overflow and it is re-scored against ALL centroids (nearest_centroid_mfma_list_kernel)
+    -- k-means assignments, centroids and compress codes still equal the oracle's, first index on ties."""
+    rng = np.random.default_rng(77)
+    base = oracle.normalize_array(rng.normal(size=(128, 6)).astype(np.float32))
+    data = base[:, rng.integers(0, 6, size=5000)] + 1e-6 * rng.normal(size=(128, 5000)).astype(np.float32)
+    data = np.asfortranarray(oracle.normalize_array(data.astype(np.float32)))
+    K = 400
+    init = np.asfortranarray(data[:, rng.permutation(5000)[:K]])          # ~67 near-copies of each of the 6 directions
+    c, a, it = codec.kmeans(data, init, max_iters=3)
+    rc, ra, rit = oracle.kmeans(data, init, max_iters=3)
+    assert it == rit and np.array_equal(a, ra) and np.array_equal(c.view(np.uint32), rc.view(np.uint32))
+    assert np.array_equal(codec.compress_into_codes(init, data), oracle.compress_into_codes(init, data))
+    dup = np.asfortranarray(np.repeat(base, 50, axis=1))                      # 300 centroids, 50 exact copies of each
+    assert np.array_equal(codec.compress_into_codes(dup, data), oracle.compress_into_codes(dup, data))
+
+
 @pytest.mark.parametrize("dim,n,K,bsize", [(128, 3000, 40, 1000), (128, 700, 64, 100), (16, 500, 9, 1000),
                                              (128, 6000, 200, 1000)])
 def test_kmeans_bit_exact(oracle, dim, n, K, bsize):
