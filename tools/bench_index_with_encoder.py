@@ -65,6 +65,15 @@ def main():
     searcher = clb.Searcher(config.index_path, encoder=enc)
     pids, scores = clb.search(searcher, collection[17], 10)
     rec["query_is_its_own_top_hit"] = bool(pids[0] == 18)
+    ts = searcher.text_search(10, graph=False)                     # a few text queries through the serving session
+    lat = []
+    for i in range(30):
+        t1 = time.perf_counter()
+        ts(collection[(37 * i) % args.docs])
+        lat.append(time.perf_counter() - t1)
+    ts.close()
+    rec["text_query_p50_ms"] = round(float(np.median(lat[5:])) * 1e3, 3)
+    rec["text_query_max_ms"] = round(float(np.max(lat[5:])) * 1e3, 3)
     searcher.close(); enc.close()
     shutil.rmtree(tmp, ignore_errors=True)
     print(json.dumps(rec))
