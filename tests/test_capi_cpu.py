@@ -221,3 +221,21 @@ def test_gelu_erf_polynomial_is_accurate_to_one_ulp_of_one():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fit_gelu_erf
     assert np.allclose(np.array(fit_gelu_erf.fit(), dtype=np.float32), np.array(co), rtol=2e-5, atol=1e-9)
+
+
+def test_key_blocked_v_layout_matches_the_accumulator_order():
+    """Host restatement of vt_index (csrc/encoder_kernels.hpp): inside a tile of 32 keys, key t sits at the position at
+    which attention_f16_kernel's lanes expect it -- lane half h, MFMA step u, slot j holds key 16u + 8(j>>2) + 4h + (j&3)
+    (the rows of the 32 x 32 score accumulator a lane owns) and reads position 16h + 8u + j; the map is a bijection."""
+    def pos_of(t):
+        u, w = (t >> 4) & 1, t & 15
+        return 16 * ((w >> 2) & 1) + 8 * u + 4 * (w >> 3) + (w & 3)
+    assert sorted(pos_of(t) for t in range(32)) == list(range(32))
+    for h in range(2):
+        for u in range(2):
+            for j in range(8):
+                key = 16 * u + 8 * (j >> 2) + 4 * h + (j & 3)
+                assert pos_of(key) == 16 * h + 8 * u + j
+                # ... and that key is the accumulator row of register r = 8u + j in lane half h
+                r = 8 * u + j
+                assert key == (r & 3) + 8 * (r >> 2) + 4 * h
