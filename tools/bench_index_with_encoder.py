@@ -53,6 +53,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.time() - t0
     rec["encode_only_passages_per_s"] = round(min(args.docs, 6400) / dt, 1)
+    t0 = time.time()
+    enc.encode_passages(collection[: min(args.docs, 6400)])     # the host entry point (clb_encode_docs per batch of 64: what the Julia shim calls)
+    rec["encode_only_host_route_passages_per_s"] = round(min(args.docs, 6400) / (time.time() - t0), 1)
     del x, src
     indexer = clb.Indexer(config, encoder=enc, collection=collection, seed=3)
     t0 = time.time()
