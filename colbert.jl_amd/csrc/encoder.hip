@@ -705,10 +705,8 @@ static int encode_docs_packed_host(clb_encoder* e, const int32_t* ids, const uin
                                    int64_t n_skip, float* out_embs, int64_t* doclens, int64_t* n_out, bool* done) {
     *done = false;
     if (L * N < 1) return CLB_OK;
-    std::vector<int32_t> buf;            // ids | positions | sequence of every attended row | row offsets
-    std::vector<int32_t> pid, ppos, pseq, cu((size_t)N + 1, 0);
+    std::vector<int32_t> pid, ppos, pseq, cu((size_t)N + 1, 0);      // ids, positions and sequence of every attended row; row offsets
     pid.reserve((size_t)L * N); ppos.reserve((size_t)L * N); pseq.reserve((size_t)L * N);
-    int64_t lmax = 0;
     for (int64_t n = 0; n < N; ++n) {
         int64_t last = -1;
         for (int64_t l = 0; l < L; ++l) {
@@ -720,7 +718,6 @@ static int encode_docs_packed_host(clb_encoder* e, const int32_t* ids, const uin
         }
         if (last < 0) return CLB_OK;                 // a sequence without attended tokens: padded path
         cu[(size_t)n + 1] = (int32_t)pid.size();
-        lmax = std::max(lmax, last + 1);
     }
     const int64_t rows = (int64_t)pid.size();
     // positions are those of the padded layout, but the key-blocked V buffer is indexed by the RANK of a token in its sequence
@@ -731,7 +728,6 @@ static int encode_docs_packed_host(clb_encoder* e, const int32_t* ids, const uin
         for (int32_t r = cu[(size_t)n]; r < cu[(size_t)n + 1]; ++r) prank[(size_t)r] = r - cu[(size_t)n];
         longest = std::max<int64_t>(longest, cu[(size_t)n + 1] - cu[(size_t)n]);
     }
-    (void)lmax;
     hipStream_t st = e->stream;
     DevBuf dIds, dPos, dRank, dSeq, dCu, dSkip, dOut, dLens, dN;
     CLB_TRY(upload(dIds, pid.data(), sizeof(int32_t) * rows, st));
