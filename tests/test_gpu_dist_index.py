@@ -208,3 +208,56 @@ def test_index_device_sharded_two_rank_processes_one_gpu(oracle):
         assert np.array_equal(res[r]["codes"], codes) and np.array_equal(res[r]["residuals"], rr)
         ivf, lens = oracle.build_ivf(codes, K)
         assert np.array_equal(res[r]["ivf"], ivf) and np.array_equal(res[r]["ivf_lengths"], lens)
+
+
+def test_index_device_sharded_with_the_encoder_as_source(oracle, tmp_path):
+    """index_device_sharded over RCCL (world 1) with indexer.EncoderSource -- the BERT encoder's packed batches -- as the
+    embedding source: only the sample is encoded for training, the chunks are encoded once; k-means, statistics, codes,
+    residuals and IVF equal the oracle's on the embeddings the source yields."""
+    torch = pytest.importorskip("torch")
+    transformers = pytest.importorskip("transformers")
+    import torch.distributed as dist
+    from colbert_jl_amd.distributed_index import index_device_sharded
+    from colbert_jl_amd.encoder import pack_weights
+    from colbert_jl_amd.indexer import EncoderSource, index_to_host
+    from colbert_jl_amd.tokenization import WordPieceTokenizer
+    words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with", "many", "words", "query", "colbert"]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(20)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]", ".", ",", "!"] + words
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(vocab) + "\n")
+    tok = WordPieceTokenizer(str(vf))
+    torch.manual_seed(51)
+    cfg = transformers.BertConfig(vocab_size=len(vocab), hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                                  max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bert = transformers.BertModel(cfg, add_pooling_layer=False).eval()
+    linear = torch.nn.Linear(128, 128, bias=True).eval()
+    with torch.no_grad():
+        for p in bert.parameters():
+            p.mul_(4.0)
+    state = {k: v.detach().float().numpy() for k, v in bert.state_dict().items()}
+    state["linear.weight"] = linear.weight.detach().numpy(); state["linear.bias"] = linear.bias.detach().numpy()
+    rng = np.random.default_rng(52)
+    collection = [" ".join(rng.choice(words, size=rng.integers(2, 25))) + "." for _ in range(300)]
+    config = clb.ColBERTConfig(index_path="unused", doc_maxlen=40, query_maxlen=12, index_bsize=16, nbits=2)
+    enc = clb.BertEncoder(pack_weights(state, cfg.to_dict(), 128), cfg.to_dict(), dim=128, tokenizer=tok, config=config)
+    src = EncoderSource(enc, collection, 0)
+    store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="file://" + store.name, rank=0, world_size=1, device_id=dev)
+    try:
+        keep = {}
+        index, rec = index_device_sharded(src, 0, len(collection), HipBackend(0), nbits=2, kmeans_niters=3, seed=53, chunksize=120, keep=keep)
+    finally:
+        dist.destroy_process_group()
+    assert src.packed is True
+    host = index_to_host(index)
+    sample = np.asfortranarray(keep["sample"].cpu().numpy().T)
+    rc, rit = _oracle_sharded_kmeans(oracle, [sample], keep["init"], 3)
+    assert host["kmeans_iters"] == rit and np.array_equal(bits(host["centroids"]), bits(rc))
+    embs = np.asfortranarray(torch.cat([src.chunk(s, min(s + 120, 300)) for s in range(0, 300, 120)]).cpu().numpy().T)
+    assert embs.shape[1] == int(src.doclens.sum()) == host["codes"].size
+    codes, res = oracle.compress(rc, host["bucket_cutoffs"], 128, 2, embs)
+    assert np.array_equal(host["codes"], codes) and np.array_equal(host["residuals"], res)
+    ivf, lens = oracle.build_ivf(codes, rec["K"])
+    assert np.array_equal(host["ivf"], ivf) and np.array_equal(host["ivf_lengths"], lens)
+    enc.close()
