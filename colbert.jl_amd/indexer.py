@@ -118,7 +118,7 @@ def _index_through_device(indexer: Indexer) -> str:
     cfg = indexer.config
     path = cfg.index_path
     t0 = time.time()
-    source = EncoderSource(indexer.encoder, indexer.collection, indexer.device)
+    source = EncoderSource(indexer.encoder, indexer.collection, indexer.device, lazy=True)    # the tokenizer overlaps the device
     t_tok = time.time() - t0
     os.makedirs(path)
     state = {"write_s": 0.0}
@@ -216,32 +216,69 @@ class EncoderSource(DeviceEmbeddingSource):
     chain forward -> mask -> normalise -> compact (BertEncoder.doc_embeddings_device = clb_encode_docs_device) without a
     read-back: the host prepares batch i + 1 while the device encodes batch i."""
 
-    def __init__(self, encoder, collection, device: int = 0, packed: bool = True, pack_batches: int = 4):
+    def __init__(self, encoder, collection, device: int = 0, packed: bool = True, pack_batches: int = 4, lazy: bool = False):
         import torch
         self.packed = packed          # batches without padding rows (clb_encode_docs_packed_device) where the encoder can
         self.pack_batches = int(os.environ.get("COLBERT_PACK_BATCHES", pack_batches))
         self.encoder = encoder
         self.collection = collection
+        self.n_docs = len(collection)
         self.dim = encoder.dim
         self.device = torch.device("cuda", device)
         cfg = encoder.config
         self.skiplist = np.asarray(encoder.tokenizer.doc_skiplist(cfg.mask_punctuation), dtype=np.int64)
         self._d_skip = torch.from_numpy(self.skiplist).to(self.device)
         self._pad = np.int32(encoder.tokenizer.pad_id)
-        # per passage: its column of tensorize_docs (doc_tokenization.jl:143-156), attended rows only -- [CLS] [D] w1 .. wn
-        # [SEP], 1-based ids, truncated to doc_maxlen.  Tokenised in large slices on the tokenizer's thread pool.
-        marker = np.int32(encoder.tokenizer.lookup(cfg.doc_token_id))
-        self._tokens = []
-        for start in range(0, len(collection), 8192):
-            for e in encoder.tokenizer.tok.encode_batch(list(collection[start:start + 8192]), add_special_tokens=True):
-                ids = np.asarray(e.ids[:cfg.doc_maxlen - 1], dtype=np.int32) + 1
-                self._tokens.append(np.concatenate([ids[:1], [marker], ids[1:]]).astype(np.int32))
-        if self._tokens:                                    # every passage holds at least [CLS] [D] [SEP]: no empty segment
-            starts = np.concatenate([[0], np.cumsum([t.size for t in self._tokens])[:-1]])
-            keep = ~np.isin(np.concatenate(self._tokens), self.skiplist)
-            self.doclens = np.add.reduceat(keep.astype(np.int64), starts)
-        else:
-            self.doclens = np.zeros(0, np.int64)
+        self._marker = np.int32(encoder.tokenizer.lookup(cfg.doc_token_id))
+        self._maxlen = int(cfg.doc_maxlen)
+        self._tokens = [None] * self.n_docs
+        self._doclens = None
+        self._worker = None
+        # lazy (index_device): only the sampled passages are tokenised before the device starts on the sample
+        # (prepare_sample); the rest follows on a host thread while the device encodes the sample and runs k-means
+        if not lazy:
+            self._tokenize(range(self.n_docs))
+
+    def _tokenize(self, pids):
+        """Per passage its column of tensorize_docs (doc_tokenization.jl:143-156), attended rows only -- [CLS] [D] w1 .. wn
+        [SEP], 1-based ids, truncated to doc_maxlen -- in large slices on the tokenizer's thread pool (the GIL is released)."""
+        pids = list(pids)
+        tok = self.encoder.tokenizer.tok
+        for start in range(0, len(pids), 8192):
+            part = pids[start:start + 8192]
+            for p, e in zip(part, tok.encode_batch([self.collection[p] for p in part], add_special_tokens=True)):
+                ids = np.asarray(e.ids[:self._maxlen - 1], dtype=np.int32) + 1
+                self._tokens[p] = np.concatenate([ids[:1], [self._marker], ids[1:]]).astype(np.int32)
+
+    def prepare_sample(self, pids):
+        """Tokenise the passages `pids` now and everything else on a background thread."""
+        import threading
+        if self._doclens is not None or self._worker is not None:
+            return
+        self._tokenize(int(p) for p in pids)
+        done = set(int(p) for p in pids)
+        self._worker = threading.Thread(target=self._tokenize, args=([p for p in range(self.n_docs) if p not in done],), daemon=True)
+        self._worker.start()
+
+    def _doclens_of(self, pids):
+        """Kept tokens (attended and not in the skiplist, checkpoint.jl:37-43) of the passages `pids` -- from their tokens alone."""
+        toks = [self._tokens[int(p)] for p in pids]
+        if not toks:
+            return np.zeros(0, np.int64)
+        starts = np.concatenate([[0], np.cumsum([t.size for t in toks])[:-1]])        # every passage holds [CLS] [D] [SEP]: no empty segment
+        return np.add.reduceat((~np.isin(np.concatenate(toks), self.skiplist)).astype(np.int64), starts)
+
+    @property
+    def doclens(self):
+        if self._doclens is None:
+            if self._worker is not None:
+                self._worker.join()
+                self._worker = None
+            missing = [p for p in range(self.n_docs) if self._tokens[p] is None]
+            if missing:
+                self._tokenize(missing)
+            self._doclens = self._doclens_of(range(self.n_docs))
+        return self._doclens
 
     def _tensorize(self, pids):
         """What tensorize_docs returns for the passages `pids` as one batch, transposed to the device layout: ids int32
@@ -274,10 +311,13 @@ class EncoderSource(DeviceEmbeddingSource):
         d = torch.from_numpy(buf).to(self.device)
         try:
             return self.encoder.doc_embeddings_packed_device(d[:rows], d[rows:2 * rows], d[2 * rows:3 * rows], d[3 * rows:], int(lens.max()),
-                                                             self._d_skip, n_out=int(self.doclens[batch].sum()))
+                                                             self._d_skip, n_out=int(self._expected(batch).sum()))
         except ArgumentError:
             self.packed = False
             return None, None
+
+    def _expected(self, pids):
+        return self._doclens[np.asarray(pids, dtype=np.int64)] if self._doclens is not None else self._doclens_of(pids)
 
     def encode_pids(self, pids):
         """encode_passages of the passages `pids` (batches of index_bsize, in this order) with the result left on the
@@ -298,16 +338,16 @@ class EncoderSource(DeviceEmbeddingSource):
                 ids, mask = self._tensorize(batch)
                 d_ids = torch.from_numpy(ids).to(self.device)
                 d_mask = torch.from_numpy(mask).to(self.device)
-                x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self.doclens[batch].sum()))
+                x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self._expected(batch).sum()))
             parts.append(x); lens.append(dl)
         out = torch.cat(parts) if len(parts) > 1 else parts[0]
         self.encoder.check_last_ids()
-        assert np.array_equal(torch.cat(lens).cpu().numpy(), self.doclens[pids])
+        assert np.array_equal(torch.cat(lens).cpu().numpy(), self._expected(pids))
         return out
 
     def encode(self, passages=None):
         """The whole collection -> ((n, dim) CUDA tensor, doclens)."""
-        return self.encode_pids(np.arange(len(self._tokens))), self.doclens.copy()
+        return self.encode_pids(np.arange(self.n_docs)), self.doclens.copy()
 
     def chunk(self, start: int, end: int):
         return self.encode_pids(np.arange(start, end))
@@ -327,14 +367,14 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     import time
 
     import torch
-    doclens = np.ascontiguousarray(source.doclens, dtype=np.int64)
-    n_docs = doclens.size
+    # a source that derives its doclens from work still in flight (EncoderSource(lazy=True): the tokenizer runs on a host thread
+    # while the device encodes the sample and trains) names its size; its doclens are read after k-means
+    lazy = hasattr(source, "prepare_sample") and hasattr(source, "n_docs")
+    n_docs = int(source.n_docs) if lazy else int(np.asarray(source.doclens).size)
     dim = source.dim
     dev = source.device
     rng = np.random.default_rng(seed) if rng is None else rng
-    off = np.concatenate([[0], np.cumsum(doclens)])
-    n_emb = int(off[-1])
-    rec = {"passages": int(n_docs), "embeddings": n_emb}
+    rec = {"passages": int(n_docs)}
     sync = lambda: torch.cuda.synchronize(dev)
 
     def tick(name, t0):
@@ -347,10 +387,11 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     t0 = time.time()
     n_s = codec.num_sampled_pids(n_docs)
     sampled = np.unique(rng.integers(0, n_docs, size=n_s))
-    n_sample = int(doclens[sampled].sum())
+    if lazy:
+        source.prepare_sample(sampled)
     sample = source.sample(sampled) if hasattr(source, "sample") else _sample_from_chunks(source, sampled, chunksize)
-    assert sample.shape[0] == n_sample
-    avg_doclen_est = float(np.float32(doclens[sampled].sum() / max(sampled.size, 1)))
+    n_sample = int(sample.shape[0])                          # = doclens[sampled].sum()
+    avg_doclen_est = float(np.float32(n_sample / max(sampled.size, 1)))
     # held-out split (collection_indexer.jl:81-91): shuffle the columns, the last heldout_size go to the held-out set
     perm = torch.from_numpy(rng.permutation(n_sample)).to(dev)
     sample = sample[perm]
@@ -382,6 +423,11 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
 
     # chunk loop (collection_indexer.jl:271-297)
     t0 = time.time()
+    doclens = np.ascontiguousarray(source.doclens, dtype=np.int64)
+    assert doclens.size == n_docs and int(doclens[sampled].sum()) == n_sample
+    off = np.concatenate([[0], np.cumsum(doclens)])
+    n_emb = int(off[-1])
+    rec["embeddings"] = n_emb
     rows = dim // 8 * nbits
     codes = torch.empty(n_emb, dtype=torch.int32, device=dev)
     residuals = torch.empty((n_emb, rows), dtype=torch.uint8, device=dev)
