@@ -264,6 +264,34 @@ class Codec:
             pass
 
 
+def gather_rows_device(src, rows, out=None):
+    """out[i, :] = src[rows[i], :] on the device (clb_gather_rows_device): the sampled / shuffled columns of the reference's
+    (dim, n) matrices (`sample[:, randperm(...)]`, the sampled passages' embeddings -- collection_indexer.jl:56-91) cut out
+    without torch indexing.  src: contiguous CUDA tensor (n_src, ...); rows: int64 CUDA tensor or numpy array, 0-based;
+    out: optional contiguous destination (a slice of a larger buffer will do).  BoundsError for an index outside src."""
+    import torch
+    s_ = _dev_rows(src)
+    if not _is_tensor(rows):
+        rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(s_.device)
+    r_ = _dev_rows(rows, torch.int64)
+    n = int(r_.numel())
+    row_bytes = int(s_[0].numel() * s_.element_size()) if s_.shape[0] else int(np.prod(s_.shape[1:]) * s_.element_size())
+    if out is None:
+        out = torch.empty((n,) + tuple(s_.shape[1:]), dtype=s_.dtype, device=s_.device)
+    o_ = _dev_rows(out, s_.dtype)
+    assert o_.numel() * o_.element_size() == n * row_bytes, "gather_rows_device: destination size"
+    check(lib().clb_gather_rows_device(s_.device.index, C.c_void_p(s_.data_ptr()), i64(s_.shape[0]), i64(row_bytes),
+                                       C.c_void_p(r_.data_ptr()), i64(n), C.c_void_p(o_.data_ptr()), _stream_of(s_)))
+    return out
+
+
+def device_memory(device: int = 0):
+    """(free, total) bytes of HBM on `device` (clb_device_memory)."""
+    f, t = i64(0), i64(0)
+    check(lib().clb_device_memory(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 def build_ivf_device(codes, num_partitions: int):
     """_build_ivf  (collection_indexer.jl:349-353) over a device array: codes int32/uint32 CUDA tensor [n] (1-based) ->
     (ivf int64 CUDA tensor [n] 1-based, ivf_lengths int64 CUDA tensor [K])."""

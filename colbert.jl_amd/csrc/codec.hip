@@ -694,6 +694,81 @@ int clb_build_ivf_device(int device, const uint32_t* d_codes, int64_t n, int64_t
     return build_ivf_core((hipStream_t)hip_stream, d_codes, n, K, d_ivf, d_ivf_lengths);
 }
 
+// ---- plain device arrays for hosts without their own (include/colbert_hip.h) ------------------------------------------
+int clb_device_malloc(int device, int64_t bytes, void** d_out) {
+    if (!d_out || bytes < 0) return fail(CLB_EARGUMENT, "clb_device_malloc: null output or negative size");
+    *d_out = nullptr;
+    CLB_TRY(use_device(device));
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) return fail(CLB_ENOMEM, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    *d_out = p;
+    return CLB_OK;
+}
+
+int clb_device_free(int device, void* d_ptr) {
+    if (!d_ptr) return CLB_OK;
+    CLB_TRY(use_device(device));
+    CLB_HIP(hipFree(d_ptr));
+    return CLB_OK;
+}
+
+int clb_device_upload(int device, void* d_dst, const void* src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!d_dst || !src))) return fail(CLB_EARGUMENT, "clb_device_upload: null pointer or negative size");
+    CLB_TRY(use_device(device));
+    if (bytes) CLB_HIP(hipMemcpy(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return CLB_OK;
+}
+
+int clb_device_download(int device, void* dst, const void* d_src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !d_src))) return fail(CLB_EARGUMENT, "clb_device_download: null pointer or negative size");
+    CLB_TRY(use_device(device));
+    if (bytes) CLB_HIP(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return CLB_OK;
+}
+
+int clb_device_synchronize(int device) {
+    CLB_TRY(use_device(device));
+    CLB_HIP(hipDeviceSynchronize());
+    return CLB_OK;
+}
+
+int clb_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(device));
+    size_t f = 0, t = 0;
+    CLB_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return CLB_OK;
+}
+
+int clb_gather_rows_device(int device, const void* d_src, int64_t n_src, int64_t row_bytes, const int64_t* d_rows, int64_t n,
+                           void* d_dst, void* hip_stream) {
+    if (n < 0 || n_src < 0 || row_bytes < 4 || row_bytes % 4) return fail(CLB_EARGUMENT, "gather: sizes must be >= 0 and row_bytes a positive multiple of 4");
+    if (n == 0) return CLB_OK;
+    if (!d_src || !d_rows || !d_dst) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    DevBuf dErr;
+    CLB_TRY(dErr.alloc(sizeof(int)));
+    CLB_HIP(hipMemsetAsync(dErr.p, 0, sizeof(int), st));
+    const bool wide = row_bytes % 16 == 0 && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0);
+    const int64_t per_row = wide ? row_bytes / 16 : row_bytes / 4;            // 16-byte (else 4-byte) pieces per row
+    const int64_t total = n * per_row;
+    if (wide)
+        hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(blocks_for(total)), dim3(256), 0, st, (const uint4*)d_src, n_src, per_row,
+                           d_rows, n, (uint4*)d_dst, dErr.as<int>());
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks_for(total)), dim3(256), 0, st, (const uint32_t*)d_src, n_src, per_row,
+                           d_rows, n, (uint32_t*)d_dst, dErr.as<int>());
+    CLB_HIP(hipGetLastError());
+    int herr = 0;
+    CLB_HIP(hipMemcpyAsync(&herr, dErr.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CLB_HIP(hipStreamSynchronize(st));
+    if (herr) return fail(CLB_EBOUNDS, "gather: a row index lies outside 0..%lld", (long long)(n_src - 1));
+    return CLB_OK;
+}
+
 int clb_doc_epilogue(int device, const float* D, int64_t dim, int64_t L, int64_t N, const int32_t* integer_ids,
                      const int64_t* skiplist, int64_t n_skip, float* out, int64_t* doclens, int64_t* n_out) {
     CLB_TRY(use_device(device));

@@ -353,6 +353,26 @@ static __global__ void widen_u32_i64_kernel(const uint32_t* __restrict__ in, int
     if (i < n) out[i] = (int64_t)in[i];
 }
 
+// dst[i, :] = src[rows[i], :] -- the sampled / shuffled columns of the reference's (dim, n) matrices
+// (collection_indexer.jl:56-91) cut out on the device; a row is `per_row` pieces of type P (16 or 4 bytes), one thread per
+// piece: consecutive threads copy consecutive pieces of a row (coalesced on both sides).  An index outside [0, n_src)
+// zeroes the destination row and raises the flag.
+template <class P>
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const P* __restrict__ src, int64_t n_src, int64_t per_row,
+                                                                 const int64_t* __restrict__ rows, int64_t n, P* __restrict__ dst,
+                                                                 int* __restrict__ err) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * per_row) return;
+    const int64_t i = t / per_row, j = t - i * per_row;
+    const int64_t r = rows[i];
+    if (r < 0 || r >= n_src) {
+        if (j == 0) atomicOr(err, 1);
+        dst[t] = P{};
+        return;
+    }
+    dst[t] = src[r * per_row + j];
+}
+
 static __global__ void iota_kernel(uint32_t* __restrict__ v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;

@@ -540,6 +540,10 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     CLB_HIP(hipMemsetAsync(e->err.p, 0, sizeof(int), st));
     CLB_HIP(hipStreamSynchronize(st));
     if (herr & 1) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
+    // bit 2 can only have been left by an EARLIER asynchronous encode nobody has checked yet (this call's epilogue has not run):
+    // it was read and cleared with bit 1 above, so it is reported here rather than dropped
+    if (herr & 2) return fail(CLB_EDOMAIN, "non-finite encoder output in an earlier asynchronous encode on this handle (an activation "
+                                           "outside the range of the f16 operand split? clb_encoder_set_gemm_mode(e, 2) selects bf16x6)");
     return CLB_OK;
 }
 
@@ -560,6 +564,7 @@ int finish_checked(clb_encoder* e, hipStream_t st) {
 __global__ void packed_keep_kernel(const int32_t* __restrict__ ids, int64_t rows, const int64_t* __restrict__ skip, int nskip,
                                    uint32_t* __restrict__ keep) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == rows) keep[j] = 0u;       // the pad slot exclusive_scan_u32 reads (it scans rows + 1 inputs: out[rows] = total)
     if (j >= rows) return;
     const int64_t id = ids[j];
     bool k = true;
@@ -739,11 +744,11 @@ static int encode_docs_packed_host(clb_encoder* e, const int32_t* ids, const uin
     CLB_TRY(dOut.alloc(sizeof(float) * e->dim * rows));
     CLB_TRY(dLens.alloc(sizeof(int64_t) * N));
     CLB_TRY(dN.alloc(sizeof(int64_t)));
-    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * rows));
+    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * (rows + 1)));
     CLB_TRY(e->prank.ensure(sizeof(uint32_t) * (rows + 1)));
     const Packed pk{dPos.as<int32_t>(), dSeq.as<int32_t>(), dCu.as<int32_t>(), rows, dRank.as<int32_t>()};
     CLB_TRY(forward(e, longest, N, st, dIds.as<int32_t>(), nullptr, /*sync=*/true, &pk));
-    hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, st, dIds.as<int32_t>(), rows, dSkip.as<int64_t>(),
+    hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows + 1, 256)), dim3(256), 0, st, dIds.as<int32_t>(), rows, dSkip.as<int64_t>(),
                        (int)n_skip, e->pkeep.as<uint32_t>());
     CLB_TRY(exclusive_scan_u32(e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), (size_t)rows, st, &e->scan_tmp));
     hipLaunchKernelGGL(packed_doclens_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->prank.as<uint32_t>(), dCu.as<int32_t>(), (int)N,
@@ -868,13 +873,13 @@ int clb_encode_docs_packed_device(clb_encoder* e, const int32_t* d_ids, const in
     if (Lmax > e->max_pos) return fail(CLB_EBOUNDS, "sequence length %lld exceeds max_position_embeddings %lld", (long long)Lmax, (long long)e->max_pos);
     CLB_TRY(use_device(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * rows));
+    CLB_TRY(e->pkeep.ensure(sizeof(uint32_t) * (rows + 1)));
     CLB_TRY(e->prank.ensure(sizeof(uint32_t) * (rows + 1)));
     const Packed pk{d_pos, d_seq, d_cu, rows};
     CLB_TRY(forward(e, Lmax, N, st, d_ids, nullptr, /*sync=*/false, &pk));
     {
         EncTimed tm(e, ES_EPILOGUE, st);
-        hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, st, d_ids, rows, d_skiplist, (int)n_skip,
+        hipLaunchKernelGGL(packed_keep_kernel, dim3(blocks_for(rows + 1, 256)), dim3(256), 0, st, d_ids, rows, d_skiplist, (int)n_skip,
                            e->pkeep.as<uint32_t>());
         CLB_TRY(exclusive_scan_u32(e->pkeep.as<uint32_t>(), e->prank.as<uint32_t>(), (size_t)rows, st, &e->scan_tmp));
         hipLaunchKernelGGL(packed_doclens_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, st, e->prank.as<uint32_t>(), d_cu, (int)N, d_doclens,
@@ -897,6 +902,17 @@ int clb_encoder_check_last_ids(clb_encoder* e) {
     if (herr & 1) return fail(CLB_EBOUNDS, "token id outside the vocabulary (ids are 1-based, 1..%lld)", (long long)e->vocab);
     if (herr & 2) return fail(CLB_EDOMAIN, "non-finite encoder output (an activation outside the range of the f16 operand split? "
                                            "clb_encoder_set_gemm_mode(e, 2) selects the bf16x6 split)");
+    return CLB_OK;
+}
+
+int clb_encoder_error_flag_device(clb_encoder* e, void** d_flag) {
+    if (!e || !d_flag) return fail(CLB_EARGUMENT, "null argument");
+    CLB_TRY(use_device(e->device));
+    if (!e->err.p) {
+        CLB_TRY(e->err.ensure(sizeof(int)));
+        CLB_HIP(hipMemset(e->err.p, 0, sizeof(int)));
+    }
+    *d_flag = e->err.p;
     return CLB_OK;
 }
 

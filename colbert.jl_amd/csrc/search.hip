@@ -63,6 +63,7 @@ struct Workspace {
     int64_t Ttuned = 0;         // largest query length <= 128 this slot has seen (what the tuned-path buffers are sized for)
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
+    bool stats_keep = false;    // set for the 2nd, 3rd ... sub-batch of one call: the work counters accumulate over the call
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
@@ -621,7 +622,8 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     if (phase != 2) {
     CLB_TRY(run_retrieve(s, w, st, dQ, B, T, nprobe));
     if (s->prof.counters) {
-        CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
+        // one set of counters per CALL: the sub-batches of a large batch add onto those of the sub-batches before them
+        if (!w.stats_keep) CLB_HIP(hipMemsetAsync(w.stats.p, 0, sizeof(unsigned long long) * 8, st));
         s->prof.chain = nullptr;
     }
     if (two_pass) {
@@ -1074,8 +1076,11 @@ int clb_search_batch_device_slot(clb_searcher* s, int slot, const float* d_Q, in
     for (int64_t b0 = 0; b0 < B; b0 += kSubBatch) {
         const int64_t bn = std::min<int64_t>(kSubBatch, B - b0);
         CLB_TRY(ensure_workspace(s, w, bn, T, nprobe, k));
-        CLB_TRY(run_search(s, w, st, d_Q + (size_t)b0 * T * s->dim, (int)bn, (int)T, (int)nprobe, (int)k, d_out_pids + (size_t)b0 * k,
-                           d_out_scores + (size_t)b0 * k, d_n_cand ? d_n_cand + b0 : nullptr));
+        w.stats_keep = b0 > 0;
+        const int rc = run_search(s, w, st, d_Q + (size_t)b0 * T * s->dim, (int)bn, (int)T, (int)nprobe, (int)k, d_out_pids + (size_t)b0 * k,
+                                  d_out_scores + (size_t)b0 * k, d_n_cand ? d_n_cand + b0 : nullptr);
+        w.stats_keep = false;
+        if (rc) return rc;
     }
     return CLB_OK;
 }
@@ -1143,8 +1148,10 @@ int clb_search_batch(clb_searcher* s, const float* Q, int64_t T, int64_t B, int6
         const int64_t bn = std::min<int64_t>(kSubBatch, B - b0);
         CLB_TRY(ensure_workspace(s, w, bn, T, nprobe, k));
         CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q + (size_t)b0 * T * s->dim, sizeof(float) * bn * T * s->dim, hipMemcpyHostToDevice, st));
-        CLB_TRY(run_search(s, w, st, w.Qdev.as<float>(), (int)bn, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(),
-                           w.outs.as<float>()));
+        w.stats_keep = b0 > 0;
+        const int rc = run_search(s, w, st, w.Qdev.as<float>(), (int)bn, (int)T, (int)nprobe, (int)k, w.outp.as<int64_t>(), w.outs.as<float>());
+        w.stats_keep = false;
+        if (rc) return rc;
         CLB_HIP(hipMemcpyAsync(out_pids + (size_t)b0 * k, w.outp.p, sizeof(int64_t) * bn * k, hipMemcpyDeviceToHost, st));
         CLB_HIP(hipMemcpyAsync(out_scores + (size_t)b0 * k, w.outs.p, sizeof(float) * bn * k, hipMemcpyDeviceToHost, st));
         CLB_HIP(hipMemcpyAsync(nc.data() + b0, w.ncand.p, sizeof(int) * bn, hipMemcpyDeviceToHost, st));

@@ -214,7 +214,7 @@ def index_device_sharded(source, pid_lo: int, n_docs_total: int, backend=None, n
     fill = int(sample.shape[0])
     assert fill == n_sample
     lrng = np.random.default_rng([seed, rank + 1])
-    sample = sample[torch.from_numpy(lrng.permutation(n_sample)).to(dev)]
+    sample = codec.gather_rows_device(sample.contiguous(), lrng.permutation(n_sample))      # the shuffle, through the C ABI
     tot_sample, tot_sampled_docs = all_sum([n_sample, int(mine.size)])
     h = codec.heldout_size(tot_sample)
     heldout = None

@@ -155,7 +155,7 @@ class BertEncoder:
                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(st)))
         return d_out
 
-    def doc_embeddings_device(self, d_ids, d_mask, d_skiplist, n_out: Optional[int] = None):
+    def doc_embeddings_device(self, d_ids, d_mask, d_skiplist, n_out: Optional[int] = None, out=None):
         """_doc_embeddings_and_doclens with torch CUDA tensors (clb_encode_docs_device): ids int32 (N, L) row-major, mask
         uint8 (N, L), skiplist int64 -> (embs float32 (n_kept, dim) CUDA tensor -- the reference's (dim, n_kept) matrix --,
         doclens int64 (N,) CUDA tensor).  `n_out`: the number of kept tokens when the caller already knows it (it follows
@@ -163,7 +163,10 @@ class BertEncoder:
         read-back per call."""
         import torch
         N, L = d_ids.shape
-        out = torch.empty((N * L, self.dim), dtype=torch.float32, device=d_ids.device)
+        if out is None:      # `out` (with n_out known): a contiguous (>= n_out, dim) slice of the caller's buffer -- only kept rows are written
+            out = torch.empty((N * L, self.dim), dtype=torch.float32, device=d_ids.device)
+        else:
+            assert n_out is not None and out.is_contiguous() and out.shape[0] >= n_out and out.shape[1] == self.dim
         doclens = torch.empty(N, dtype=torch.int64, device=d_ids.device)
         n_dev = torch.zeros(1, dtype=torch.int64, device=d_ids.device)
         st = torch.cuda.current_stream(d_ids.device).cuda_stream
@@ -172,14 +175,17 @@ class BertEncoder:
                                            C.c_void_p(doclens.data_ptr()), C.c_void_p(n_dev.data_ptr()), C.c_void_p(st)))
         return out[: int(n_dev.item()) if n_out is None else int(n_out)], doclens
 
-    def doc_embeddings_packed_device(self, d_ids, d_pos, d_seq, d_cu, Lmax: int, d_skiplist, n_out: Optional[int] = None):
+    def doc_embeddings_packed_device(self, d_ids, d_pos, d_seq, d_cu, Lmax: int, d_skiplist, n_out: Optional[int] = None, out=None):
         """_doc_embeddings_and_doclens for a PACKED batch (clb_encode_docs_packed_device): the N passages follow one another
         without padding rows -- ids / pos / seq int32 (rows,), cu int32 (N + 1,) row offsets, Lmax the longest passage.
         Same outputs as doc_embeddings_device.  Raises ArgumentError when the encoder cannot run packed batches (head size
         other than 64, a GEMM mode other than f16x3): pad then."""
         import torch
         rows, N = int(d_ids.numel()), int(d_cu.numel()) - 1
-        out = torch.empty((rows, self.dim), dtype=torch.float32, device=d_ids.device)
+        if out is None:
+            out = torch.empty((rows, self.dim), dtype=torch.float32, device=d_ids.device)
+        else:
+            assert n_out is not None and out.is_contiguous() and out.shape[0] >= n_out and out.shape[1] == self.dim
         doclens = torch.empty(N, dtype=torch.int64, device=d_ids.device)
         n_dev = torch.zeros(1, dtype=torch.int64, device=d_ids.device)
         st = torch.cuda.current_stream(d_ids.device).cuda_stream
@@ -210,6 +216,13 @@ class BertEncoder:
         """Raise BoundsError if the last (asynchronous, device-resident) encode saw a token id outside the vocabulary --
         query_embeddings_device clamps such ids because it cannot report them when it is enqueued."""
         check(lib().clb_encoder_check_last_ids(self._h))
+
+    def error_flag_ptr(self) -> int:
+        """Device address of the encoder's sticky int32 error flag (clb_encoder_error_flag_device): a serving loop copies it
+        back with its results and calls check_last_ids() only when it is non-zero."""
+        p = C.c_void_p(0)
+        check(lib().clb_encoder_error_flag_device(self._h, C.byref(p)))
+        return int(p.value)
 
     # -- profiling (bench.py) -----------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

@@ -67,9 +67,16 @@ def index(indexer: Indexer, device_resident: Optional[bool] = None) -> Optional[
     if os.path.isdir(path):                                  # indexing.jl:64-67
         return None
     if device_resident is None:
-        device_resident = hasattr(indexer.encoder, "doc_embeddings_device")
+        device_resident = hasattr(indexer.encoder, "doc_embeddings_device") and _device_route_fits(indexer)
     if device_resident:
-        return _index_through_device(indexer)
+        try:
+            return _index_through_device(indexer)
+        except BaseException:
+            # a build that dies half-way must not leave a directory behind: index() would take it for a finished index
+            # (the isdir test above, indexing.jl:64-67) and return without building
+            import shutil
+            shutil.rmtree(path, ignore_errors=True)
+            raise
     n_docs = len(indexer.collection)
     # sample -> embeddings (collection_indexer.jl:17-24, 56-79)
     n_s = codec.num_sampled_pids(n_docs)
@@ -110,6 +117,23 @@ def index(indexer: Indexer, device_resident: Optional[bool] = None) -> Optional[
     return path
 
 
+def _device_route_fits(indexer: Indexer) -> bool:
+    """Whether the device-resident route's footprint fits the free HBM: it keeps the codes of the WHOLE collection for the
+    IVF (4 B per embedding + 8 B of Int64 ivf + ~16 B of sort scratch), one chunk's embeddings (512 B each) and residuals, and
+    the training sample.  Upper bound from doc_maxlen tokens per passage; the host route streams chunk by chunk instead."""
+    cfg = indexer.config
+    n_docs = len(indexer.collection)
+    maxlen = int(getattr(indexer.encoder.config, "doc_maxlen", cfg.doc_maxlen))
+    chunk = int(cfg.chunksize or min(25000, 1 + n_docs))
+    need = n_docs * maxlen * 28 + min(chunk, n_docs) * maxlen * (4 * cfg.dim + cfg.dim // 8 * cfg.nbits) \
+        + codec.num_sampled_pids(n_docs) * maxlen * 4 * cfg.dim * 2
+    try:
+        free, _ = codec.device_memory(indexer.device)
+    except Exception:
+        return True
+    return need < 0.8 * free
+
+
 def _index_through_device(indexer: Indexer) -> str:
     """index() over index_device: the encoder's output, the sample, the codes and the residuals stay in HBM; what is
     written is the reference's directory (sample, sample_heldout, plan.json, config.json, the codec, per chunk codes /
@@ -132,21 +156,25 @@ def _index_through_device(indexer: Indexer) -> str:
         state["plan"] = plan
         state["write_s"] += time.time() - t1
 
+    counts = []
+
+    def on_codec(centroids, cut, w, avg):
+        t1 = time.time()
+        storage.save_codec(path, np.asfortranarray(centroids.cpu().numpy().T), cut, w, avg)
+        state["write_s"] += time.time() - t1
+
+    def on_chunk(ci, start, end, codes, residuals, doclens):
+        # a chunk's files are written as soon as it is compressed (collection_indexer.jl:271-297): a failure later on leaves
+        # nothing half-described, and only the codes (for the IVF) outlive the chunk on the device
+        t1 = time.time()
+        storage.save_chunk(path, codes.cpu().numpy().view(np.uint32), np.asfortranarray(residuals.cpu().numpy().T), ci, start + 1, doclens)
+        counts.append(int(codes.numel()))
+        state["write_chunks_s"] = state.get("write_chunks_s", 0.0) + time.time() - t1
+
     ix, rec = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
-                           nranks=cfg.nranks, on_sample=on_sample)
+                           nranks=cfg.nranks, on_sample=on_sample, on_codec=on_codec, on_chunk=on_chunk, keep_residuals=False)
     t_w = time.time()
     plan = state["plan"]
-    storage.save_codec(path, np.asfortranarray(ix["centroids"].cpu().numpy().T), ix["bucket_cutoffs"], ix["bucket_weights"],
-                       ix["avg_residual"])
-    n_docs = len(indexer.collection)
-    off = np.concatenate([[0], np.cumsum(ix["doclens"])])
-    counts = []
-    for ci, start in enumerate(range(0, n_docs, plan["chunksize"]), start=1):
-        end = min(n_docs, start + plan["chunksize"])
-        a, b = int(off[start]), int(off[end])
-        storage.save_chunk(path, ix["codes"][a:b].cpu().numpy().view(np.uint32),
-                           np.asfortranarray(ix["residuals"][a:b].cpu().numpy().T), ci, start + 1, ix["doclens"][start:end])
-        counts.append(b - a)
     total, offsets = codec.collect_embedding_id_offset(counts)
     plan["num_embeddings"] = total
     plan["embeddings_offsets"] = [int(o) for o in offsets]
@@ -159,7 +187,8 @@ def _index_through_device(indexer: Indexer) -> str:
     storage._save(os.path.join(path, "ivf_lengths"), np.asarray(ix["ivf_lengths"]))
     assert storage.check_all_files_are_saved(path)
     # seconds per stage of this build (tools/bench_index_with_encoder.py): sample_and_split_s and chunks_s are encoder time
-    rec.update({"tokenize_s": round(t_tok, 3), "write_sample_s": round(state["write_s"], 3), "write_index_s": round(time.time() - t_w, 3)})
+    rec.update({"tokenize_s": round(t_tok, 3), "write_sample_s": round(state["write_s"], 3),
+                "write_index_s": round(time.time() - t_w + state.get("write_chunks_s", 0.0), 3)})
     indexer.last_build_record = rec
     return path
 
@@ -201,7 +230,7 @@ def _sample_from_chunks(source, pids, step: Optional[int] = None):
             continue
         x = source.chunk(start, end)
         rows = np.concatenate([np.arange(off[p] - off[start], off[p + 1] - off[start]) for p in mine])
-        out[fill:fill + rows.size] = x[torch.from_numpy(rows).to(source.device)]
+        codec.gather_rows_device(x.contiguous(), rows, out=out[fill:fill + rows.size])
         fill += rows.size
         del x
     assert fill == out.shape[0]
@@ -234,6 +263,7 @@ class EncoderSource(DeviceEmbeddingSource):
         self._tokens = [None] * self.n_docs
         self._doclens = None
         self._worker = None
+        self.lazy = bool(lazy)
         # lazy (index_device): only the sampled passages are tokenised before the device starts on the sample
         # (prepare_sample); the rest follows on a host thread while the device encodes the sample and runs k-means
         if not lazy:
@@ -253,8 +283,8 @@ class EncoderSource(DeviceEmbeddingSource):
     def prepare_sample(self, pids):
         """Tokenise the passages `pids` now and everything else on a background thread."""
         import threading
-        if self._doclens is not None or self._worker is not None:
-            return
+        if not self.lazy or self._doclens is not None or self._worker is not None:
+            return                       # everything is (being) tokenised already
         self._tokenize(int(p) for p in pids)
         done = set(int(p) for p in pids)
         self._worker = threading.Thread(target=self._tokenize, args=([p for p in range(self.n_docs) if p not in done],), daemon=True)
@@ -292,11 +322,11 @@ class EncoderSource(DeviceEmbeddingSource):
             mask[j, :t.size] = 1
         return ids, mask
 
-    def _encode_packed(self, batch):
+    def _encode_packed(self, batch, dst, n_out):
         """The batch with its passages back to back and no padding rows: tensorize_docs pads to the batch's longest passage
         with [PAD] tokens that the attention mask hides and the skiplist drops -- rows that never reach the output.  One
-        int32 upload (ids | positions | passage of every row | row offsets).  (None, None) if the encoder cannot (then the
-        caller pads, and no further batch tries)."""
+        int32 upload (ids | positions | passage of every row | row offsets).  Writes the n_out kept rows into `dst` and
+        returns the device doclens; None if the encoder cannot (then the caller pads, and no further batch tries)."""
         import torch
         from ._lib import ArgumentError
         toks = [self._tokens[int(p)] for p in batch]
@@ -311,10 +341,10 @@ class EncoderSource(DeviceEmbeddingSource):
         d = torch.from_numpy(buf).to(self.device)
         try:
             return self.encoder.doc_embeddings_packed_device(d[:rows], d[rows:2 * rows], d[2 * rows:3 * rows], d[3 * rows:], int(lens.max()),
-                                                             self._d_skip, n_out=int(self._expected(batch).sum()))
+                                                             self._d_skip, n_out=n_out, out=dst)[1]
         except ArgumentError:
             self.packed = False
-            return None, None
+            return None
 
     def _expected(self, pids):
         return self._doclens[np.asarray(pids, dtype=np.int64)] if self._doclens is not None else self._doclens_of(pids)
@@ -328,21 +358,26 @@ class EncoderSource(DeviceEmbeddingSource):
             return torch.empty((0, self.dim), dtype=torch.float32, device=self.device)
         # packed batches need no common length: several index_bsize batches go into one call (rows, not passages, fill the chip)
         bs = self.encoder.config.index_bsize * (self.pack_batches if self.packed else 1)
-        parts, lens = [], []
+        # ONE output buffer: every batch's kept rows are written by the encoder's epilogue straight into its slice (what a
+        # batch keeps follows from its tokens alone), no concatenation afterwards
+        expected = self._expected(pids)
+        out = torch.empty((int(expected.sum()), self.dim), dtype=torch.float32, device=self.device)
+        lens, fill = [], 0
         for start in range(0, pids.size, bs):
             batch = pids[start:start + bs]
-            x = None
+            n_b = int(expected[start:start + bs].sum())
+            dst = out[fill:fill + n_b]
+            dl = None
             if self.packed:
-                x, dl = self._encode_packed(batch)
-            if x is None:
+                dl = self._encode_packed(batch, dst, n_b)
+            if dl is None:
                 ids, mask = self._tensorize(batch)
                 d_ids = torch.from_numpy(ids).to(self.device)
                 d_mask = torch.from_numpy(mask).to(self.device)
-                x, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=int(self._expected(batch).sum()))
-            parts.append(x); lens.append(dl)
-        out = torch.cat(parts) if len(parts) > 1 else parts[0]
+                _, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=n_b, out=dst)
+            lens.append(dl); fill += n_b
         self.encoder.check_last_ids()
-        assert np.array_equal(torch.cat(lens).cpu().numpy(), self._expected(pids))
+        assert np.array_equal(torch.cat(lens).cpu().numpy(), expected)
         return out
 
     def encode(self, passages=None):
@@ -357,19 +392,24 @@ class EncoderSource(DeviceEmbeddingSource):
 
 
 def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: int = 20, chunksize=None, seed: int = 0,
-                 num_partitions=None, log=None, rng=None, nranks: int = 1, on_sample=None):
+                 num_partitions=None, log=None, rng=None, nranks: int = 1, on_sample=None, on_codec=None, on_chunk=None,
+                 keep_residuals: bool = True):
     """The array stages of index() (src/indexing.jl:63-147) with the sample, the codes, the residuals and the IVF kept in
     HBM: sample pids -> gather their embeddings -> shuffle, held-out split -> setup -> k-means (the device-resident shard
     handle) -> codec statistics -> per chunk: compress (resident codec) -> _build_ivf.  Returns (index, record): `index`
     holds CUDA tensors (centroids (K, dim), codes int32 [n] 1-based, residuals uint8 (n, dim/8*nbits), ivf int64 [n]) and
     host arrays (doclens, ivf_lengths, bucket_cutoffs, bucket_weights) -- what Searcher(index=...) takes; `record` the
-    seconds per stage.  RNG-dependent draws use numpy's generator (module docstring)."""
+    seconds per stage.  RNG-dependent draws use numpy's generator (module docstring).  torch is used for ALLOCATION only:
+    every row gather / shuffle goes through clb_gather_rows_device, the same calls a host without torch makes
+    (julia/ColBERT/src/indexing.jl).  `on_codec(centroids, cutoffs, weights, avg)` / `on_chunk(ci, start, end, codes,
+    residuals, doclens)` let index() write the codec and each chunk's files as they are produced; `keep_residuals=False`
+    then keeps only the codes (for the IVF) on the device, one chunk of residuals at a time."""
     import time
 
     import torch
     # a source that derives its doclens from work still in flight (EncoderSource(lazy=True): the tokenizer runs on a host thread
     # while the device encodes the sample and trains) names its size; its doclens are read after k-means
-    lazy = hasattr(source, "prepare_sample") and hasattr(source, "n_docs")
+    lazy = bool(getattr(source, "lazy", False)) and hasattr(source, "prepare_sample")
     n_docs = int(source.n_docs) if lazy else int(np.asarray(source.doclens).size)
     dim = source.dim
     dev = source.device
@@ -393,9 +433,7 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     n_sample = int(sample.shape[0])                          # = doclens[sampled].sum()
     avg_doclen_est = float(np.float32(n_sample / max(sampled.size, 1)))
     # held-out split (collection_indexer.jl:81-91): shuffle the columns, the last heldout_size go to the held-out set
-    perm = torch.from_numpy(rng.permutation(n_sample)).to(dev)
-    sample = sample[perm]
-    del perm
+    sample = codec.gather_rows_device(sample.contiguous(), rng.permutation(n_sample))
     h = codec.heldout_size(n_sample)
     heldout = sample[n_sample - h:]
     sample = sample[:n_sample - h]
@@ -403,7 +441,7 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     K = int(num_partitions or plan["num_partitions"])
     if on_sample is not None:                                # index(): the files written before training (indexing.jl:84-96)
         on_sample(sample, heldout, plan)
-    init = sample[torch.from_numpy(rng.permutation(sample.shape[0])[:K]).to(dev)].contiguous()
+    init = codec.gather_rows_device(sample, rng.permutation(sample.shape[0])[:K])
     rec.update({"sample_points": int(sample.shape[0]), "heldout": int(h), "K": K, "chunksize": plan["chunksize"]})
     tick("sample_and_split_s", t0)
 
@@ -420,6 +458,8 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     cut, w, avg, _ = codec.compute_avg_residuals(nbits, cent_host, np.asfortranarray(heldout.cpu().numpy().T), device=dev.index)
     tick("codec_stats_s", t0)
     del sample, heldout, init
+    if on_codec is not None:
+        on_codec(centroids, cut, w, avg)
 
     # chunk loop (collection_indexer.jl:271-297)
     t0 = time.time()
@@ -430,10 +470,10 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
     rec["embeddings"] = n_emb
     rows = dim // 8 * nbits
     codes = torch.empty(n_emb, dtype=torch.int32, device=dev)
-    residuals = torch.empty((n_emb, rows), dtype=torch.uint8, device=dev)
+    residuals = torch.empty((n_emb, rows), dtype=torch.uint8, device=dev) if keep_residuals else None
     cdc = codec.Codec(centroids, cut, dim, nbits)
-    t_src = 0.0
-    for start in range(0, n_docs, plan["chunksize"]):
+    t_src = t_cb = 0.0
+    for ci, start in enumerate(range(0, n_docs, plan["chunksize"]), start=1):
         end = min(n_docs, start + plan["chunksize"])
         t1 = time.time()
         x = source.chunk(start, end)
@@ -441,13 +481,19 @@ def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: i
         t_src += time.time() - t1
         a, b = int(off[start]), int(off[end])
         assert x.shape[0] == b - a
-        cdc.compress_device(x, codes[a:b], residuals[a:b])
+        res = residuals[a:b] if keep_residuals else torch.empty((b - a, rows), dtype=torch.uint8, device=dev)
+        cdc.compress_device(x, codes[a:b], res)
         sync()
         del x
+        if on_chunk is not None:
+            t1 = time.time()
+            on_chunk(ci, start, end, codes[a:b], res, doclens[start:end])
+            t_cb += time.time() - t1
+        del res
     cdc.close()
     tick("chunks_s", t0)
     rec["generate_chunks_s"] = round(t_src, 3)
-    rec["compress_s"] = round(rec["chunks_s"] - t_src, 3)
+    rec["compress_s"] = round(rec["chunks_s"] - t_src - t_cb, 3)
     rec["compress_Membeddings_per_s"] = round(n_emb / max(rec["compress_s"], 1e-9) / 1e6, 2)
     t0 = time.time()
     ivf, ivf_lengths = codec.build_ivf_device(codes, K)

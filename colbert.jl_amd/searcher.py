@@ -238,6 +238,11 @@ class TextSearch:
         self.run = DeviceSearch(searcher, self.T, 1, self.k, int(nprobe or searcher.config.nprobe))
         self.h_out = torch.empty(self.run.packed.numel(), dtype=torch.uint8).pin_memory()
         self.h_ncand = torch.empty(1, dtype=torch.int64).pin_memory()
+        self.h_err = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # the encoder's sticky error flag (a 4-byte device word owned by the library) as a tensor view: copied back with every result
+        flag = type("_Flag", (), {"__cuda_array_interface__": {"shape": (1,), "typestr": "<i4", "version": 2,
+                                                                "data": (self.enc.error_flag_ptr(), False)}})()
+        self.d_err = torch.as_tensor(flag, device=self.dev)
         self.stream = torch.cuda.Stream(self.dev)
         self.graph = None
         # a first pass sizes every workspace (allocations cannot be captured)
@@ -272,7 +277,10 @@ class TextSearch:
                 self._enqueue()
             self.h_out.copy_(self.run.packed, non_blocking=True)
             self.h_ncand.copy_(self.run.ncand, non_blocking=True)
+            self.h_err.copy_(self.d_err, non_blocking=True)
         self.stream.synchronize()
+        if int(self.h_err[0]) != 0:       # id outside the vocabulary / non-finite embeddings: raises (and clears the flag)
+            self.enc.check_last_ids()
         n = int(self.h_ncand[0])
         self.s.last_num_candidates = n
         if n < self.k:                                                            # searching.jl:127

@@ -171,7 +171,9 @@ int clb_merge_topk_packed_device(int device, const void* d_packed, int64_t k, in
 int clb_profile_enable(clb_searcher* s, int on);
 int clb_profile_read(clb_searcher* s, const char** names, double* total_ms, int64_t* launches, int cap);
 /* per-kernel work counters of the last batch: candidate passages / candidate embeddings summed over
- * the batch, and embeddings re-scored by the exact pass */
+ * the WHOLE batch of the last call (a batch above 64 queries runs as 64-query sub-batches inside the call: the counters
+ * add up over them; the per-query flag / candidate-count scratch of a workspace slot holds the last sub-batch only), and
+ * embeddings re-scored by the exact pass */
 int clb_last_batch_stats(clb_searcher* s, int64_t* cand_docs, int64_t* cand_embs, int64_t* rescored_docs,
                          int64_t* rescored_embs);
 
@@ -267,6 +269,29 @@ int clb_codec_create(int device, int64_t dim, int nbits, int64_t K, const float*
 int clb_codec_destroy(clb_codec* c);
 int clb_codec_compress_device(clb_codec* c, const float* d_embs, int64_t n, uint32_t* d_codes, uint8_t* d_residuals,
                               void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device arrays for a host that has none of its own (the Julia shim; Python uses torch tensors for the same purpose).
+ * The device-resident route of index() (src/indexing.jl:63-147 with the sample, the codes and the residuals kept in HBM:
+ * clb_encode_docs_packed_device -> clb_gather_rows_device -> clb_kmeans_shard_create_device -> clb_codec_compress_device ->
+ * clb_build_ivf_device -> clb_searcher_create_device) needs to allocate, fill and read back plain device buffers and to
+ * cut the sampled / shuffled rows out of a device matrix -- the reference's `sample[:, randperm(...)]` and
+ * `embs[:, sampled columns]` (collection_indexer.jl:56-91) -- without the embeddings crossing PCIe.
+ * ---------------------------------------------------------------------------------------------- */
+int clb_device_malloc(int device, int64_t bytes, void** d_out);
+int clb_device_free(int device, void* d_ptr);
+/* blocking copies between host memory and a buffer of clb_device_malloc (any device pointer on `device` will do) */
+int clb_device_upload(int device, void* d_dst, const void* src, int64_t bytes);
+int clb_device_download(int device, void* dst, const void* d_src, int64_t bytes);
+int clb_device_synchronize(int device);
+/* free / total bytes of HBM on `device` (index() picks the device-resident route only if its footprint fits) */
+int clb_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
+/* d_dst[i, :] = d_src[d_rows[i], :] for i < n: rows of `row_bytes` bytes (a multiple of 4; column j of Julia's (dim, n_src)
+ * Float32 matrix is row j here), d_rows Int64[n] on the device, 0-BASED, each in [0, n_src).  Runs on `hip_stream` and
+ * waits for it: an index outside the range is CLB_EBOUNDS (nothing is read outside d_src; the destination row is zeroed).
+ * d_dst must not overlap d_src. */
+int clb_gather_rows_device(int device, const void* d_src, int64_t n_src, int64_t row_bytes, const int64_t* d_rows,
+                           int64_t n, void* d_dst, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Exchange step of the sharded search / index build on RCCL  (the reference is single-GPU)
@@ -368,6 +393,13 @@ int clb_encode_docs_packed_device(clb_encoder* e, const int32_t* d_ids, const in
  * sticky: set by the kernels, cleared by this call), or CLB_EDOMAIN when an encode produced non-finite embeddings (the
  * f16x3 split's range).  The host-buffer entry points report both themselves. */
 int clb_encoder_check_last_ids(clb_encoder* e);
+/* The sticky flag itself: *d_flag receives the device address of the int32 the encode kernels OR their findings into
+ * (bit 0: id outside the vocabulary, bit 1: non-finite output).  A serving loop copies its 4 bytes back together with the
+ * results of a query (search(searcher, query::String, k), src/searching.jl:93-127) and calls clb_encoder_check_last_ids only
+ * when it is non-zero -- an asynchronous encode whose activations leave the f16 split's range would otherwise hand NaN
+ * scores to the caller without an error.  The address is stable for the life of the handle; valid after the first encode
+ * or this call (which allocates and clears the flag if no encode has run yet). */
+int clb_encoder_error_flag_device(clb_encoder* e, void** d_flag);
 /* Per-stage HIP-event timing of the encoder forward (bench.py's encoder roofline; the stages are the Linear layers of
  * `doc`, src/modelling/checkpoint.jl:21-25, by role).  enable, run encodes, then read: names[i] (static strings), total
  * milliseconds and stage executions since the last read.  Returns the number of entries written (<= cap), -1 on error. */

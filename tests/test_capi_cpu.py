@@ -124,6 +124,32 @@ def test_round4_entry_points_check_their_arguments_first():
                                             None, p(il), i64(0), C.byref(out)) == 10
 
 
+def test_round5_entry_points_check_their_arguments_first():
+    """Round 5: plain device arrays + the row gather for hosts without their own (the Julia shim's device-resident index()),
+    and the encoder's sticky error flag: argument contracts first, then the device check -- no CPU fallback."""
+    import ctypes as C
+    l = clb.lib()
+    i64 = C.c_int64
+    out = C.c_void_p()
+    f, t = i64(0), i64(0)
+    assert l.clb_device_malloc(0, i64(16), None) == 4
+    assert l.clb_device_malloc(0, i64(-1), C.byref(out)) == 4
+    assert l.clb_device_free(0, None) == 0                                        # freeing nothing is fine
+    assert l.clb_device_upload(0, None, None, i64(8)) == 4
+    assert l.clb_device_download(0, None, None, i64(8)) == 4
+    assert l.clb_device_memory(0, None, None) == 4
+    assert l.clb_gather_rows_device(0, None, i64(4), i64(6), None, i64(2), None, None) == 4      # row_bytes % 4
+    assert l.clb_gather_rows_device(0, None, i64(4), i64(512), None, i64(2), None, None) == 4    # null arrays
+    assert l.clb_gather_rows_device(0, None, i64(4), i64(512), None, i64(0), None, None) == 0    # nothing to do
+    assert l.clb_encoder_error_flag_device(None, C.byref(out)) == 4
+    if l.clb_device_count() == 0:
+        assert l.clb_device_malloc(0, i64(16), C.byref(out)) == 10
+        assert l.clb_device_memory(0, C.byref(f), C.byref(t)) == 10
+        assert l.clb_device_synchronize(0) == 10
+        x = np.zeros(4, np.float32)
+        assert l.clb_device_upload(0, C.c_void_p(16), x.ctypes.data_as(C.c_void_p), i64(16)) == 10
+
+
 def test_plane_layout_and_xcd_tile_mapping():
     """Host restatement of two pieces of the encoder's plane GEMM (csrc/encoder_kernels.hpp): the K-blocked plane index is
     a bijection onto [0, rows * K), and the XCD-aware work-group -> tile map covers every (K slice, n tile, m tile) exactly

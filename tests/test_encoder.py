@@ -302,7 +302,7 @@ SAMPLE_COLLECTION = ["hello world", "thank yo!", "a", "this is some longer text,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["synthetic", "sample_collection"])
-def test_text_to_search_end_to_end(tmp_path, tok, which):
+def test_text_to_search_end_to_end(tmp_path, tok, which, monkeypatch):
     """BASELINE config 1 (a handful of passages through Indexer + Searcher with a text query): the API plumbing of
     examples/indexing.jl + examples/searching.jl with a randomly initialised encoder (no checkpoint is on disk) -- on
     synthetic sentences and on the text of the reference's examples/sample_collection.tsv."""
@@ -345,6 +345,23 @@ def test_text_to_search_end_to_end(tmp_path, tok, which):
         ts.close()
     with pytest.raises(clb.BoundsError):
         searcher.text_search(n + 1, graph=False)(query)
+    # the session copies the encoder's sticky error flag back with every result (clb_encoder_error_flag_device): what the
+    # asynchronous encode can only clamp -- here an id outside the vocabulary -- is reported by that very call, and cleared
+    import colbert_jl_amd.tokenization as tkz
+    real = tkz.tensorize_queries
+
+    def bad(*a, **k):
+        ids, mask = real(*a, **k)
+        ids = ids.copy(); ids[2, 0] = 10 ** 6
+        return ids, mask
+    ts = searcher.text_search(3, graph=True)
+    monkeypatch.setattr(tkz, "tensorize_queries", bad)
+    with pytest.raises(clb.BoundsError):
+        ts(query)
+    monkeypatch.setattr(tkz, "tensorize_queries", real)
+    got = ts(query)
+    assert np.array_equal(got[0], pids) and np.array_equal(got[1].view(np.uint32), scores.view(np.uint32))
+    ts.close()
     searcher.close(); enc.close()
 
 

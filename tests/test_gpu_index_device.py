@@ -131,3 +131,40 @@ def test_index_device_end_to_end(oracle):
             p, sc = s.search_embeddings(Q[:, :, j], k=100)
             assert np.array_equal(p, rp) and np.array_equal(bits(sc), bits(rs))
     sd.close(); sh.close()
+
+
+def test_gather_rows_and_plain_device_arrays():
+    """clb_gather_rows_device (the sample / shuffle gathers of the device-resident build) against numpy, 16-byte and
+    4-byte row pieces, into a slice of a larger buffer; an index outside the source is BoundsError.  clb_device_malloc /
+    upload / download / memory: what a host without device arrays of its own (the Julia shim) drives the same route with."""
+    import ctypes as C
+    torch, dev = _torch()
+    rng = np.random.default_rng(3)
+    for cols in (128, 33):                       # 512-byte rows (uint4 pieces) and 132-byte rows (dword pieces)
+        x = rng.standard_normal((1000, cols)).astype(np.float32)
+        rows = rng.integers(0, 1000, size=2500)
+        dx = torch.from_numpy(x).to(dev)
+        got = codec.gather_rows_device(dx, rows)
+        assert np.array_equal(got.cpu().numpy(), x[rows])
+        big = torch.zeros((3000, cols), dtype=torch.float32, device=dev)
+        codec.gather_rows_device(dx, rows[:700], out=big[100:800])
+        b = big.cpu().numpy()
+        assert np.array_equal(b[100:800], x[rows[:700]]) and not b[:100].any() and not b[800:].any()
+    with pytest.raises(clb.BoundsError):
+        codec.gather_rows_device(dx, np.array([0, 1000], dtype=np.int64))
+    with pytest.raises(clb.BoundsError):
+        codec.gather_rows_device(dx, np.array([-1], dtype=np.int64))
+    # plain device arrays
+    l = clb.lib()
+    i64 = C.c_int64
+    p = C.c_void_p()
+    assert l.clb_device_malloc(0, i64(4096), C.byref(p)) == 0 and p.value
+    src = rng.integers(0, 255, size=4096, dtype=np.uint8)
+    back = np.zeros_like(src)
+    assert l.clb_device_upload(0, p, src.ctypes.data_as(C.c_void_p), i64(4096)) == 0
+    assert l.clb_device_download(0, back.ctypes.data_as(C.c_void_p), p, i64(4096)) == 0
+    assert np.array_equal(src, back)
+    assert l.clb_device_synchronize(0) == 0
+    assert l.clb_device_free(0, p) == 0
+    free, total = codec.device_memory(0)
+    assert 0 < free <= total
