@@ -161,7 +161,8 @@ def _device_worker(rank, world, store, q):
     from colbert_jl_amd.indexer import index_to_host
     dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
-    n_total, n_local = 2400, 1200
+    n_local = 1200
+    n_total = n_local * world
     src = synthetic.DeviceMixtureSource(seed=90 + rank, n_docs=n_local, device=dev, block=500, n_components=64)
     keep = {}
     index, rec = index_device_sharded(src, rank * n_local, n_total, HipBackend(0), nbits=2, kmeans_niters=3, seed=91,
@@ -178,29 +179,31 @@ def _device_worker(rank, world, store, q):
     dist.destroy_process_group()
 
 
-def test_index_device_sharded_two_rank_processes_one_gpu(oracle):
-    """Two rank processes on this box's GPU, exchanges staged over gloo: sample rule, init all-gather, device k-means
+@pytest.mark.parametrize("world", [2, 4])
+def test_index_device_sharded_rank_processes_one_gpu(oracle, world):
+    """Two / four rank processes on this box's GPU, exchanges staged over gloo: sample rule, init all-gather, device k-means
     shards, statistics broadcast, resident codec, device IVF.  Against the oracle's sharded restatement, bit for bit."""
     import torch.multiprocessing as mp
     store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_device_worker, args=(r, 2, store.name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_device_worker, args=(r, world, store.name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = dict(q.get(timeout=400) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     K = res[0]["K"]
-    assert K == res[1]["K"] == 4096
-    assert np.array_equal(res[0]["init"], res[1]["init"])                       # identical on every rank
-    per = K // 2
-    assert np.array_equal(res[0]["init"][:, :per], res[0]["sample"][:, :per])   # rank r's share, rank order
-    assert np.array_equal(res[0]["init"][:, per:], res[1]["sample"][:, :per])
-    rc, rit = _oracle_sharded_kmeans(oracle, [res[0]["sample"], res[1]["sample"]], res[0]["init"], 3)
+    assert all(res[r]["K"] == K for r in range(world)) and K == (4096 if world == 2 else K)
+    per = -(-K // world)
+    for r in range(world):
+        assert np.array_equal(res[0]["init"], res[r]["init"])                   # identical on every rank
+        hi = min(K, (r + 1) * per)
+        assert np.array_equal(res[0]["init"][:, r * per:hi], res[r]["sample"][:, :hi - r * per])   # rank r's share, rank order
+    rc, rit = _oracle_sharded_kmeans(oracle, [res[r]["sample"] for r in range(world)], res[0]["init"], 3)
     rcut, rw, _ravg, _ = oracle.compute_avg_residuals(2, rc, res[0]["heldout"])
-    for r in (0, 1):
+    for r in range(world):
         assert res[r]["pid_offset"] == r * 1200
         assert res[r]["kmeans_iters"] == rit and np.array_equal(bits(res[r]["centroids"]), bits(rc))
         assert np.array_equal(bits(res[r]["bucket_cutoffs"]), bits(rcut)) and np.array_equal(bits(res[r]["bucket_weights"]), bits(rw))

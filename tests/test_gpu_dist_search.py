@@ -68,18 +68,20 @@ def _worker(rank, world, store, k, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [100, 700])
-def test_two_rank_processes_hip_search_both_protocols(oracle, k):
+# world 4 (round 5): four rank processes on the box's one GPU (the pool allows six GPU processes at once) -- the shape of
+# the driver's 4-GPU job, with shards short enough that some hold fewer than k candidates
+@pytest.mark.parametrize("world,k", [(2, 100), (2, 700), (4, 700)])
+def test_rank_processes_hip_search_both_protocols(oracle, world, k):
     import torch.multiprocessing as mp
 
     import colbert_jl_amd as clb
     store = tempfile.NamedTemporaryFile(prefix="clb_pg_", delete=False); store.close(); os.unlink(store.name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, store.name, k, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, store.name, k, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -88,7 +90,7 @@ def test_two_rank_processes_hip_search_both_protocols(oracle, k):
     oidx = dict(idx, emb2pid=oracle.build_emb2pid(idx["doclens"]))
     for b in range(Qs.shape[2]):
         rp, rs, _ = oracle.search(oidx, Qs[:, :, b], 2, k)
-        for r in (0, 1):                                            # the merged result is identical on every rank
+        for r in range(world):                                      # the merged result is identical on every rank
             for proto in ("single", "two_phase"):
                 p, sc = res[r][proto]
                 assert np.array_equal(p[b], rp), (r, proto, b)
