@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0        # ... and the copy rate the guide measures on this part (the practical ceiling of a stream)
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak
 BYTES_PER_EMB = 36.0         # 4-B code + 32-B packed residual
@@ -100,13 +101,40 @@ def roofline_of(kname, prof, stats, mode, T, K, B):
         alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
         ach = alg_bytes / (ms_launch * 1e-3) / 1e9
         r = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4)}
+             "frac": round(ach / HBM_PEAK_GBS, 4), "measured_copy_rate": HBM_COPY_GBS,
+             "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4)}
     r["ms_per_launch"] = round(ms_launch, 4)
     r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
     return r
 
 
-def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_queries, dev, in_flight=2, T=32):
+def traffic_from_pmc(pmc_file, dom, stats, roof):
+    """roofline.traffic from a committed rocprofv3 --pmc summary (tools/gpu_profile.sh -> tools/pmc_summary.py) of THIS
+    workload: counters cannot be read in-process.  The summary records the sha256 of the kernel sources it was measured
+    on; a summary taken on different sources leaves traffic null."""
+    if not os.path.exists(pmc_file):
+        roof["traffic_source"] = f"null: no {os.path.relpath(pmc_file, ROOT)}"
+        return
+    from tools.pmc_summary import csrc_hash
+    pmc_all = json.load(open(pmc_file))
+    pmc = pmc_all.get("kernels", {}).get(dom, {})
+    if pmc_all.get("csrc_sha256") != csrc_hash() or "hbm_read_bytes" not in pmc:
+        roof["traffic_source"] = f"null: {os.path.relpath(pmc_file, ROOT)} was measured on different kernel sources"
+        return
+    raw = pmc["hbm_read_bytes_uncorrected"]
+    if dom == "score_approx":
+        # FETCH_SIZE counts this kernel's contiguous streams (residual 32 B + one 4-B code|inv_norm word per
+        # embedding) at half their bytes and its 64-B score-row gathers in full (fetch_calib.hip)
+        stream = 36.0 * stats["cand_embs"]
+        roof["traffic"] = int(raw + 0.5 * stream + pmc.get("hbm_write_bytes", 0))
+        roof["traffic_split"] = {"stream_bytes": int(stream), "gather_miss_bytes": int(raw - 0.5 * stream)}
+    else:
+        roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
+    roof["traffic_source"] = (f"{os.path.relpath(pmc_file, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "workload; " + pmc_all.get("correction", ""))
+
+
+def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_queries, dev, in_flight=2, T=32, pmc_key=None):
     """A short single-GPU measurement of one workload (the sub-records of the line): sustained queries/s with
     `in_flight` batches in flight, the per-kernel HIP-event times of a one-batch-at-a-time pass with the roofline of
     pass 1, candidates per query, and `cpu_queries` queries checked against the CPU oracle (pids identical, scores
@@ -157,7 +185,10 @@ def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_q
         dom = "score_approx" if "score_approx" in prof and prof["score_approx"]["launches"] else max(prof.items(), key=lambda kv: kv[1]["ms"])[0]
         roof = roofline_of(dom, prof, stats, s.mode, T, K, B)
         roof["traffic"] = None
-        roof["traffic_source"] = "null: profiles/pmc_summary.json is measured on the headline workload only"
+        if pmc_key:      # profiles/pmc_summary_<workload>.json: the PMC passes of this sub-record's workload (tools/gpu_profile.sh)
+            traffic_from_pmc(os.path.join(ROOT, "profiles", f"pmc_summary_{pmc_key}.json"), dom, stats, roof)
+        else:
+            roof["traffic_source"] = "null: no PMC summary is kept for this workload"
         roof["all_kernels_ms_per_step"] = {kn: round(v["ms"] / max(steps, 1), 4) for kn, v in prof.items()}
         rec["roofline"] = roof
     if cpu_queries > 0:
@@ -902,24 +933,8 @@ def main():
                             and k == 1000 and args.nprobe == 2 and args.mode < 0)
         if world == 1 and not default_workload:
             roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on the default workload, not this one"
-        elif world == 1 and os.path.exists(pmc_file):
-            from tools.pmc_summary import csrc_hash
-            pmc_all = json.load(open(pmc_file))
-            pmc = pmc_all.get("kernels", {}).get(dom, {})
-            if pmc_all.get("csrc_sha256") == csrc_hash() and "hbm_read_bytes" in pmc:
-                raw = pmc["hbm_read_bytes_uncorrected"]
-                if dom == "score_approx":
-                    # FETCH_SIZE counts this kernel's contiguous streams (residual 32 B + one 4-B code|inv_norm word per
-                    # embedding) at half their bytes and its 64-B score-row gathers in full (fetch_calib.hip)
-                    stream = 36.0 * stats["cand_embs"]
-                    roof["traffic"] = int(raw + 0.5 * stream + pmc.get("hbm_write_bytes", 0))
-                    roof["traffic_split"] = {"stream_bytes": int(stream), "gather_miss_bytes": int(raw - 0.5 * stream)}
-                else:
-                    roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
-                roof["traffic_source"] = ("profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                          "this command; " + pmc_all.get("correction", ""))
-            else:
-                roof["traffic_source"] = "null: profiles/pmc_summary.json was measured on different kernel sources"
+        elif world == 1:
+            traffic_from_pmc(pmc_file, dom, stats, roof)
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(prof_steps, 1), 4) for kname, v in prof.items()}
         roof["other_kernels"] = [roofline_of(kn, prof, stats, s.mode, T, K, B) for kn in ("score_approx", "score_exact", "centroid_scores")
                                  if kn in prof and kn != dom and prof[kn]["launches"]]
@@ -943,6 +958,29 @@ def main():
         cpu = {"value": round(nq_cpu / t_cpu, 4), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
                "sample": f"{nq_cpu} queries of the same workload, one at a time, OpenMP over the host cores",
                "gpu_matches_cpu_top_k": ok}
+
+    # ---- N > 1: the MERGED result of one batch (every shard's search, the exchange, the merge) against the CPU oracle's search
+    #      of the UNSHARDED index, generated on rank 0 (the same passages the shards hold: test_block_generated_shards_equal_the_full_index)
+    merged_check = None
+    if world > 1 and not args.no_cpu and not args.built_index:
+        mp_, ms_ = plan.step(0)
+        barrier()
+        if rank == 0:
+            from oracle import oracle as orc
+            orc.build()
+            t1 = time.time()
+            full = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks, blocks=range(n_blocks), topical=not args.uniform_codes)
+            full["emb2pid"] = orc.build_emb2pid(full["doclens"])
+            mp_h, ms_h = mp_.cpu().numpy(), ms_.cpu().numpy()
+            n_chk = min(plan.B, 8 if args.docs <= 400_000 else 4)
+            ok = True
+            for b in range(n_chk):
+                rp, rs, _ = orc.search(full, Q[:, :, b], args.nprobe, k)
+                ok = ok and bool(np.array_equal(rp, mp_h[b])) and bool(np.array_equal(rs.view(np.uint32), ms_h[b].view(np.uint32)))
+            merged_check = {"queries": n_chk, "merged_equals_oracle_on_the_unsharded_index": ok, "seconds": round(time.time() - t1, 1),
+                            "note": "pids identical and fp32 score bits identical, exchange = " + ("two-phase" if two_phase else "single")}
+            del full
+        barrier()
 
     # ---- N = 1 sub-records: the batch sizes the N-GPU runs use, the worst-case code distribution, and BASELINE config 2
     batch_sweep = worst = built = built_1m = None
@@ -972,7 +1010,7 @@ def main():
             if args.mode >= 0:
                 su.set_mode(args.mode)
             worst = measure_sub(torch, clb, su, u_idx, Q, 32, k, args.nprobe, args.steps, 0.4,
-                                0 if args.no_cpu else 4, dev, in_flight=NF, T=T)
+                                0 if args.no_cpu else 4, dev, in_flight=NF, T=T, pmc_key="uniform_codes" if args.docs == 1_000_000 else None)
             worst["workload"] = (f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}, UNIFORM centroid codes: no "
                                  f"id-adjacent codes, the largest candidate sets), top-{k}, nprobe {args.nprobe}, batch 32")
             worst["setup_seconds"] = {"generate": round(tg, 1)}
@@ -987,7 +1025,8 @@ def main():
                 sb.set_mode(args.mode)
             Qb = synthetic.make_queries(bidx, seed=78, n_queries=256, T=T)
             built = measure_sub(torch, clb, sb, bidx, Qb, 32, k, args.nprobe, args.steps, 0.4,
-                                0 if args.no_cpu else 8, dev, in_flight=NF, T=T)
+                                0 if args.no_cpu else 8, dev, in_flight=NF, T=T,
+                                pmc_key="built_index" if (args.built_docs, args.built_kmeans_iters) == (100_000, 20) else None)
             built["workload"] = (f"BASELINE config 2: synthetic {args.built_docs} passages of 4096-component mixture embeddings "
                                  f"(dim 128, doclen~80) indexed by this repo's own build (k-means K={brec['K']}, nbits 2), "
                                  f"top-{k}, nprobe {args.nprobe}, batch 32; queries = noisy decompressed passage tokens")
@@ -1010,7 +1049,8 @@ def main():
                 sd.set_mode(args.mode)
             Qd = synthetic.make_queries(hidx, seed=79, n_queries=256, T=T)
             built_1m = measure_sub(torch, clb, sd, hidx, Qd, 32, k, args.nprobe, args.steps, 0.4,
-                                   0 if args.no_cpu else 8, dev, in_flight=NF, T=T)
+                                   0 if args.no_cpu else 8, dev, in_flight=NF, T=T,
+                                   pmc_key="built_index_1M" if (n_built_1m, args.built_kmeans_iters) == (1_000_000, 20) else None)
             built_1m["workload"] = (f"synthetic {n_built_1m} passages of 4096-component mixture embeddings (dim 128, doclen~80) indexed by "
                                     f"this repo's own device-resident build (k-means K={drec['K']} on {drec['sample_points']} sample points, "
                                     f"nbits 2), top-{k}, nprobe {args.nprobe}, batch 32; queries = noisy decompressed passage tokens")
@@ -1047,7 +1087,7 @@ def main():
                "p50_latency_graph_replay_ms": None if p50_graph_ms is None else round(p50_graph_ms, 4),
                "p50_text_to_topk_ms": (text_lat or {}).get("stream_launches", {}).get("p50_ms"),
                "p50_text_to_topk_graph_ms": (text_lat or {}).get("hip_graph", {}).get("p50_ms"),
-               "text_to_topk": text_lat, "roofline": roof, "cpu_baseline": cpu,
+               "text_to_topk": text_lat, "roofline": roof, "cpu_baseline": cpu, "merged_vs_oracle": merged_check,
                "worst_case_uniform_codes": worst, "built_index": built, "built_index_1M": built_1m, "batch_sweep": batch_sweep,
                "exchange": (None if not gather else "two-phase (global threshold: 2 all-gathers per batch)" if two_phase
                             else "single (north_star: 1 all-gather of the per-shard top-k per batch)"),

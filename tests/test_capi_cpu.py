@@ -265,3 +265,21 @@ def test_key_blocked_v_layout_matches_the_accumulator_order():
                 # ... and that key is the accumulator row of register r = 8u + j in lane half h
                 r = 8 * u + j
                 assert key == (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def test_hand_issued_lds_dma_is_the_only_user_of_m0():
+    """The inline-asm LDS-DMA blocks (global_load_lds_dwordx4 behind `s_mov_b32 m0`) write M0 without declaring it (hipcc
+    rejects M0 as a clobber): tools/check_m0.py disassembles the shipped library and fails if anything else in those
+    kernels reads or writes M0, or if a DMA is not fed by its own block's M0 write -- a later edit that pulls in a builtin
+    using M0 (indirect register indexing, the compiler's own global_load_lds lowering) cannot miscompile silently."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_m0", os.path.join(root, "tools", "check_m0.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    problems, kernels, dmas = mod.check(clb._lib.LIB_PATH, verbose=False)
+    assert not problems, problems[:5]
+    assert kernels >= 3 and dmas >= 8          # pass 1's GL = 1 gather and the plane GEMMs are in the library
