@@ -971,6 +971,11 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
 // stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
 // access in the loop at all; 8 no result stores (what the passage-end stores and the waits they widen cost).
+// Round 5 (profiles/r05_pass1_ablations.jsonl): 9 = the score rows as 32-BYTE rows (8-bit cells: one 16-byte load per lane
+// from a table of half the size, bytes expanded to fp16 1024 + b with 8 v_perm_b32 -- the timing side of the "8-bit rows"
+// trial, the accuracy side is CLB_DEBUG_EPS_T_ADD); 10 = the row-mask sweep folded into pass 1 (every step compares its
+// 16 values against the RUNNING per-token maximum and the passage's 256-bit mask is stored at its last step: what that
+// costs the dominant kernel).
 // GL = 1 ("LDS-DMA gather", round 3): the score rows reach the wave through LDS instead of VGPRs.  Four ADJACENT lanes
 // fetch the 64 bytes of one row with global_load_lds_dwordx4 (16 rows per instruction, 2 instructions per step) -- one
 // L1 tag look-up per row where the VGPR form (lane (r, h) fetching 2 x 16 B of row r, the lanes of a row 32 apart)
@@ -1144,8 +1149,13 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                      :: "v"(c16 + ((ca_ << 6) + gl_poff)), "v"(c16 + ((cb_ << 6) + gl_poff)),               \
                         "s"(ring_lds + (SLOT) * 2048u) : "memory", "scc");                                   \
     } else {                                                                                                \
-        const char* row_ = c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);                   \
+        const char* row_ = ABL == 9 ? c16 + (((CV & cmask) << 5) + h16)                                     \
+                                    : c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);        \
         if (ABL == 1 || ABL == 7) { X0 = u32x4{CV, CV, CV, CV}; X1 = X0; }                                  \
+        else if (ABL == 9) {                                                                                \
+            X0 = *reinterpret_cast<const u32x4*>(row_);      /* 16 one-byte cells: tokens 8h..8h+7, 16+8h.. */ \
+            X1 = X0;                                                                                        \
+        }                                                                                                   \
         else {                                                                                              \
         X0 = *reinterpret_cast<const u32x4*>(row_);                                                         \
         X1 = *reinterpret_cast<const u32x4*>(row_ + 32);                                                    \
@@ -1178,6 +1188,13 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
+        if (ABL == 9) {      /* byte b -> fp16 1024 + b (0x6400 | b): two cells per v_perm_b32 */            \
+            const u32x4 raw_ = X0;                                                                          \
+            X0 = u32x4{__builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04030402u), \
+                       __builtin_amdgcn_perm(0x64646464u, raw_[1], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[1], 0x04030402u)}; \
+            X1 = u32x4{__builtin_amdgcn_perm(0x64646464u, raw_[2], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[2], 0x04030402u), \
+                       __builtin_amdgcn_perm(0x64646464u, raw_[3], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[3], 0x04030402u)}; \
+        }                                                                                                   \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X0), sel1, ACC, 0, 0, 0);    \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X1), sel2, ACC, 0, 0, 0);    \
         if (ABL == 5) { ACC[0] += __uint_as_float(RB[0] ^ RB[1]); ACC[1] += __uint_as_float(RB[2] ^ RB[3]); } \
@@ -1251,7 +1268,32 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             m01 = fmaxf(fmaxf(m01, m23), m45);                                                              \
             m67 = fmaxf(fmaxf(m67, m89), v[15]);                                                            \
             mx = fmaxf(fmaxf(mx, m01), m67);                                                                \
+            if (ABL == 10) {     /* the sweep's window test against the RUNNING maximum, mask kept per passage */ \
+                const float lo = r < T ? mx - 0.09f : __builtin_inff();                                     \
+                uint32_t lm = 0;                                                                            \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) lm |= !(v[i] < lo) ? (1u << i) : 0u;         \
+                lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0xB1, 0xf, 0xf, true);              \
+                lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x4E, 0xf, 0xf, true);              \
+                lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x141, 0xf, 0xf, true);             \
+                lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x140, 0xf, 0xf, true);             \
+                const uint32_t m0_ = __builtin_amdgcn_readlane(lm, 0) | __builtin_amdgcn_readlane(lm, 16);  \
+                const uint32_t m1_ = __builtin_amdgcn_readlane(lm, 32) | __builtin_amdgcn_readlane(lm, 48); \
+                uint32_t bits = ((m0_ & 0xFu) | ((m0_ & 0xF0u) << 4) | ((m0_ & 0xF00u) << 8) | ((m0_ & 0xF000u) << 12)) | \
+                                (((m1_ & 0xFu) | ((m1_ & 0xF0u) << 4) | ((m1_ & 0xF00u) << 8) | ((m1_ & 0xF000u) << 12)) << 4); \
+                if (TAG.rows < kStepRows) bits &= (1u << TAG.rows) - 1u;                                    \
+                const unsigned long long wbits = (unsigned long long)bits << (TAG.base & 32);               \
+                const int wi = TAG.base >> 6;                                                               \
+                wm0 |= wi == 0 ? wbits : 0ull; wm1 |= wi == 1 ? wbits : 0ull;                               \
+                wm2 |= wi == 2 ? wbits : 0ull; wm3 |= wi == 3 ? wbits : 0ull;                               \
+            }                                                                                               \
             if (TAG.last) {                                                                                 \
+                if (ABL == 10) {     /* 32 bytes per candidate passage into the (slot-indexed) row-mask buffer */ \
+                    if (lane == 0 && TAG.j >= 0) {                                                          \
+                        unsigned long long* o = rowmask + ((size_t)b * cand_cap + TAG.j) * 4;               \
+                        o[0] = wm0; o[1] = wm1; o[2] = wm2; o[3] = wm3;                                     \
+                    }                                                                                       \
+                    wm0 = wm1 = wm2 = wm3 = 0;                                                              \
+                }                                                                                           \
                 mx = max_lane_halves(mx);                                                                   \
                 const float sum = sum_lanes_0_31(r < T ? mx : 0.f);     /* valid in lanes 16..31 */         \
                 if (ABL == 8) { if (sum == 12345.678f) out[0] = mx; }    /* ablation: no result stores */     \

@@ -576,8 +576,13 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
                   bool coarse_tau = false) {
     const bool wide = s->wide_select == 1 || (s->wide_select < 0 && w.cand_cap >= kWideSelectCap);
     if (!wide) {
+        ApproxConsts ac = s->approx_consts;
+        // tuning builds: CLB_DEBUG_EPS_T_ADD_1E6 widens the per-(token, embedding) bound by about that many millionths
+        // through the inv_norm quantisation term (1.01 * inv_qerr * qn * (cn + rn)) -- what a coarser score-table format
+        // would cost pass 2 (lists and row masks grow), measured on the real pipeline with correct results
+        if (const int add = CLB_KNOB("CLB_DEBUG_EPS_T_ADD_1E6", 0)) ac.inv_qerr += add * 1e-6f / (1.01f * (ac.cn_max + ac.rn_max));
         hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
-                           w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
+                           w.cand_cap, ac, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
                            w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0);
         return CLB_OK;
     }
@@ -670,6 +675,14 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 case 6: CLB_LAUNCH_APPROX(6); break;
                 case 7: CLB_LAUNCH_APPROX(7); break;
                 case 8: CLB_LAUNCH_APPROX(8); break;
+                case 9: CLB_LAUNCH_APPROX(9); break;
+                case 10:     // the fused row mask writes the slot-indexed row-mask buffer (4 words per candidate slot)
+                    hipLaunchKernelGGL((score_approx32_kernel<false, 10>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+                                       s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
+                                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                                       (const int*)nullptr, (const float*)nullptr, w.rowmask.as<unsigned long long>());
+                    break;
                 default: CLB_LAUNCH_APPROX(0);
             }
 #else

@@ -213,3 +213,129 @@ The library refuses phase 2 with more than one shard until this (or clb_searcher
 """
 sync_bound_consts!(handle::Ptr{Cvoid}, c::Communicator) =
     _check(ccall((:clb_searcher_sync_bound_consts, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle, c.handle))
+
+
+# ---- plain device arrays (clb_device_*): what the device-resident route of index() keeps in HBM ---------------------
+# The shim has no GPU array package of its own; a DeviceBuffer is a raw allocation of the library's device, freed by its
+# finalizer.  Everything that touches its contents is a library call (upload / download / gather / encode / compress ...).
+mutable struct DeviceBuffer
+    ptr::Ptr{Cvoid}
+    bytes::Int
+    device::Int
+    function DeviceBuffer(bytes::Integer; device::Integer = 0)
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        _check(ccall((:clb_device_malloc, libcolbert), Cint, (Cint, Int64, Ref{Ptr{Cvoid}}), device, bytes, p))
+        b = new(p[], bytes, device)
+        finalizer(b -> (b.ptr == C_NULL || ccall((:clb_device_free, libcolbert), Cint, (Cint, Ptr{Cvoid}), b.device, b.ptr); b.ptr = C_NULL), b)
+    end
+end
+"pointer `offset` bytes into the buffer (a slice of a larger allocation: the chunk loop writes codes / residuals in place)"
+_at(b::DeviceBuffer, offset::Integer = 0) = b.ptr + offset
+
+function device_upload!(b::DeviceBuffer, a::Array, offset::Integer = 0)
+    sizeof(a) + offset <= b.bytes || throw(BoundsError(b, offset + sizeof(a)))
+    GC.@preserve a _check(ccall((:clb_device_upload, libcolbert), Cint, (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        b.device, _at(b, offset), a, sizeof(a)))
+    b
+end
+function device_download!(a::Array, b::DeviceBuffer, offset::Integer = 0)
+    sizeof(a) + offset <= b.bytes || throw(BoundsError(b, offset + sizeof(a)))
+    GC.@preserve a _check(ccall((:clb_device_download, libcolbert), Cint, (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        b.device, a, _at(b, offset), sizeof(a)))
+    a
+end
+device_synchronize(device::Integer = 0) = _check(ccall((:clb_device_synchronize, libcolbert), Cint, (Cint,), device))
+"(free, total) bytes of HBM"
+function device_memory(device::Integer = 0)
+    f = Ref{Int64}(0); t = Ref{Int64}(0)
+    _check(ccall((:clb_device_memory, libcolbert), Cint, (Cint, Ref{Int64}, Ref{Int64}), device, f, t))
+    f[], t[]
+end
+
+"dst[:, i] = src[:, rows[i]] for a (row_bytes / 4, n_src) Float32-like device matrix: `rows` 1-BASED Julia indices"
+function gather_columns_device!(dst::DeviceBuffer, dst_offset::Integer, src::DeviceBuffer, src_offset::Integer, n_src::Integer,
+        row_bytes::Integer, rows::Vector{Int})
+    idx = DeviceBuffer(8 * max(length(rows), 1); device = src.device)
+    device_upload!(idx, rows .- 1)                                     # the ABI takes 0-based indices
+    _check(ccall((:clb_gather_rows_device, libcolbert), Cint,
+        (Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+        src.device, _at(src, src_offset), n_src, row_bytes, idx.ptr, length(rows), _at(dst, dst_offset), C_NULL))
+    dst
+end
+
+"""
+_doc_embeddings_and_doclens (checkpoint.jl:27-52) for a PACKED batch left on the device (clb_encode_docs_packed_device):
+`tokens[i]` = the attended token ids of passage i ([CLS] [D] w1 .. wn [SEP], 1-based); the kept embeddings are written at
+`out + out_offset` (capacity: at least the batch's kept tokens); returns the batch's doclens.
+"""
+function _doc_embeddings_packed_device!(ckpt::Checkpoint, d_skiplist::DeviceBuffer, n_skip::Int, tokens::Vector{Vector{Int32}},
+        out::DeviceBuffer, out_offset::Integer; device::Int = 0)
+    N = length(tokens)
+    lens = Int32[length(t) for t in tokens]
+    rows = Int(sum(lens))
+    cu = Int32[0; cumsum(lens)]
+    buf = Vector{Int32}(undef, 3 * rows + N + 1)
+    buf[1:rows] = reduce(vcat, tokens)
+    buf[(rows + 1):(2 * rows)] = reduce(vcat, [Int32.(0:(l - 1)) for l in lens])                 # position of every row
+    buf[(2 * rows + 1):(3 * rows)] = reduce(vcat, [fill(Int32(i - 1), lens[i]) for i in 1:N])    # passage of every row
+    buf[(3 * rows + 1):end] = cu
+    d = DeviceBuffer(sizeof(buf); device = device)
+    device_upload!(d, buf)
+    d_lens = DeviceBuffer(8 * N + 8; device = device)
+    _check(ccall((:clb_encode_docs_packed_device, libcolbert), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32},
+            Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+        ckpt.handle, _at(d, 0), _at(d, 4 * rows), _at(d, 8 * rows), _at(d, 12 * rows), N, Int(maximum(lens)), rows,
+        d_skiplist.ptr, n_skip, _at(out, out_offset), _at(d_lens, 0), _at(d_lens, 8 * N), C_NULL))
+    doclens = Vector{Int}(undef, N + 1)
+    device_download!(doclens, d_lens)                                  # also waits for the batch (null stream)
+    _check(ccall((:clb_encoder_check_last_ids, libcolbert), Cint, (Ptr{Cvoid},), ckpt.handle))
+    doclens[1:N]
+end
+
+"kmeans_gpu_onehot! (src/utils.jl:253-318) on a sample that is already in HBM; returns the centroids' device buffer"
+function _kmeans_device(sample::DeviceBuffer, dim::Int, n::Int, init::DeviceBuffer, k::Int; max_iters::Int = 10,
+        tol::Float32 = 1.0f-4, point_bsize::Int = 1000)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((:clb_kmeans_shard_create_device, libcolbert), Cint,
+        (Cint, Ptr{Float32}, Int64, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), sample.device, sample.ptr, dim, n, k, point_bsize, h))
+    try
+        _check(ccall((:clb_kmeans_shard_set_centroids, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Float32}), h[], init.ptr))
+        block = DeviceBuffer(ccall((:clb_kmeans_shard_block_bytes, libcolbert), Int64, (Ptr{Cvoid},), h[]); device = sample.device)
+        delta = Ref{Float32}(0); converged = Ref{Cint}(0)
+        for _ in 1:max_iters
+            _check(ccall((:clb_kmeans_shard_pass_device, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], block.ptr, C_NULL))
+            _check(ccall((:clb_kmeans_shard_update_device, libcolbert), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float32, Ref{Float32}, Ref{Cint}, Ptr{Cvoid}), h[], block.ptr, 1, tol, delta, converged, C_NULL))
+            @info "max delta: $(delta[])"
+            converged[] != 0 && break
+        end
+        out = DeviceBuffer(4 * dim * k; device = sample.device)
+        _check(ccall((:clb_kmeans_shard_get_centroids, libcolbert), Cint, (Ptr{Cvoid}, Ptr{Float32}), h[], out.ptr))
+        return out
+    finally
+        ccall((:clb_kmeans_shard_destroy, libcolbert), Cint, (Ptr{Cvoid},), h[])
+    end
+end
+
+"the chunk loop's resident codec (clb_codec_*): compress (residual.jl:586-604) on device arrays"
+function _codec_create(dim::Int, nbits::Int, k::Int, d_centroids::DeviceBuffer, bucket_cutoffs::Vector{Float32})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve bucket_cutoffs _check(ccall((:clb_codec_create, libcolbert), Cint,
+        (Cint, Int64, Cint, Int64, Ptr{Float32}, Ptr{Float32}, Int64, Ref{Ptr{Cvoid}}),
+        d_centroids.device, dim, nbits, k, d_centroids.ptr, bucket_cutoffs, length(bucket_cutoffs), h))
+    h[]
+end
+_codec_destroy(h::Ptr{Cvoid}) = ccall((:clb_codec_destroy, libcolbert), Cint, (Ptr{Cvoid},), h)
+_codec_compress_device!(h::Ptr{Cvoid}, embs::DeviceBuffer, n::Int, codes::DeviceBuffer, codes_offset::Integer,
+    residuals::DeviceBuffer) = _check(ccall((:clb_codec_compress_device, libcolbert), Cint,
+    (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{UInt32}, Ptr{UInt8}, Ptr{Cvoid}), h, embs.ptr, n, _at(codes, codes_offset), residuals.ptr, C_NULL))
+
+"_build_ivf (collection_indexer.jl:349-353) over the device array of all codes"
+function _build_ivf_device(codes::DeviceBuffer, n::Int, num_partitions::Int)
+    d_ivf = DeviceBuffer(8 * max(n, 1); device = codes.device)
+    d_len = DeviceBuffer(8 * max(num_partitions, 1); device = codes.device)
+    _check(ccall((:clb_build_ivf_device, libcolbert), Cint, (Cint, Ptr{UInt32}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+        codes.device, codes.ptr, n, num_partitions, d_ivf.ptr, d_len.ptr, C_NULL))
+    device_download!(Vector{Int}(undef, n), d_ivf), device_download!(Vector{Int}(undef, num_partitions), d_len)
+end

@@ -109,8 +109,29 @@ def test_the_shim_binds_the_search_and_build_entry_points():
     for name in ("clb_searcher_create", "clb_searcher_destroy", "clb_search", "clb_compress", "clb_decompress", "clb_kmeans",
                  "clb_compute_avg_residuals", "clb_build_ivf", "clb_encoder_create", "clb_encode", "clb_encode_docs",
                  "clb_encode_queries", "clb_comm_create", "clb_comm_all_gather", "clb_searcher_sync_bound_consts",
-                 "clb_last_error"):
+                 "clb_last_error",
+                 # round 5: the device-resident route of index() (julia/ColBERT/src/indexing.jl: _index_device)
+                 "clb_device_malloc", "clb_device_free", "clb_device_upload", "clb_device_download", "clb_device_memory",
+                 "clb_gather_rows_device", "clb_encode_docs_packed_device", "clb_kmeans_shard_create_device",
+                 "clb_kmeans_shard_pass_device", "clb_kmeans_shard_update_device", "clb_kmeans_shard_get_centroids",
+                 "clb_codec_create", "clb_codec_compress_device", "clb_build_ivf_device", "clb_encoder_check_last_ids"):
         assert name in bound, name
+
+
+def test_the_julia_device_route_uses_only_bound_helpers():
+    """_index_device (indexing.jl) may only call functions the shim defines: a helper renamed in capi.jl would otherwise be
+    found at run time only -- and Julia never runs here."""
+    src = {fn: open(os.path.join(JULIA_DIR, fn)).read() for fn in os.listdir(JULIA_DIR) if fn.endswith(".jl")}
+    text = src["indexing.jl"]
+    body = text[text.index("function _index_device"):]
+    defined = set()
+    for t in src.values():
+        defined |= set(re.findall(r"^(?:function\s+)?([A-Za-z_][\w!]*)\(", t, flags=re.M))
+        defined |= set(re.findall(r"^(?:mutable\s+)?struct\s+([A-Za-z_]\w*)", t, flags=re.M))
+    used = set(re.findall(r"\b(_[a-z][\w!]*|device_[a-z_!]+|gather_columns_device!|save_[a-z_]+|DeviceBuffer)\(", body))
+    assert len(used) >= 12, used
+    for name in used - {"save_object"}:                # JLD2.save_object: the package's, not the shim's
+        assert name in defined, f"_index_device calls {name}, which no file of the shim defines"
 
 
 def test_header_parser_sees_every_declared_symbol():
