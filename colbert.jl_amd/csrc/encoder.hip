@@ -33,6 +33,18 @@ struct clb_encoder {
     int64_t wp_plane = 0;
     int wp_fmt = 0;             // PF_* format the weight planes currently hold (re-split when the GEMM mode changes)
     std::vector<float> wscale;  // PF_F16X2: the power of two every weight matrix was multiplied by (4 per layer + projection)
+    // "LayerNorm without a pass of its own" (gemm_planes2_kernel<LN>): gamma (.) W planes of the Linears that consume a LayerNorm
+    // (Q/K/V of layers >= 1 with the previous layer's second LayerNorm, FFN-in with the layer's first, the projection with the
+    // last), their scales, and the vectors u[n] = sum_k gamma_k W[n][k], c[n] = sum_k beta_k W[n][k] + b[n] (PF_F16X2 only)
+    DevBuf wplanes_f, lnvec, stats1, stats2;
+    int64_t wpf_plane = 0;
+    std::vector<int64_t> f_qkv, f_w1;   // element offsets of the folded matrices inside a plane of wplanes_f (per layer)
+    int64_t f_lin = 0;
+    std::vector<int64_t> v_qkv, v_w1;   // float offsets of (u | c) inside lnvec (per layer): u at off, c at off + N
+    int64_t v_lin = 0;
+    std::vector<float> wscale_f;        // 2 per layer (Q/K/V, FFN-in) + projection
+    bool fold_ready = false;
+    int ln_fold = -1;                   // -1: whenever the batch is long enough to run without split-K; 0: never; 1: always (tests)
     bool planes = false;        // the Linear layers read pre-split bf16 planes (gemm_planes_kernel); COLBERT_ENCODER_PLANES=0: off
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part, pkeep, prank, scan_tmp;
@@ -228,6 +240,30 @@ static bool att_qb2() {
     return v;
 }
 
+// what a Linear needs to fold a LayerNorm around itself (GemmPArgs' ln_* fields)
+struct LnFold {
+    const float* ln_in = nullptr; int parts = 0, width = 0; float eps = 0.f;     // statistics of A's rows (u set) or of R's rows (r_gamma set)
+    const float* u = nullptr;                                                     // fold: `bias` of the call then is c
+    const float* r_gamma = nullptr; const float* r_beta = nullptr;
+    float* stats_out = nullptr;
+};
+
+// the LN = true instantiations: big tiles (producer + consumer) and 64 x 64 (consumer only: the projection's 128 columns)
+bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
+    const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
+    const size_t lds = (size_t)c.stages * 2 * (c.bm + c.bn) * 64;
+#define CLB_GPL_CASE(BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                             \
+    if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
+        auto kern = gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, 2, ST_, 0, true, true>;                                 \
+        if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);                        \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WGM_ * WGN_), lds, st, g);                                           \
+        return true;                                                                                                  \
+    }
+    CLB_GPL_CASE(64, 64, 2, 2, 2, 1, 1) CLB_GPL_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GPL_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GPL_CASE(256, 256, 2, 4, 2, 2, 4)
+#undef CLB_GPL_CASE
+    return false;
+}
+
 template <int NS, bool F16>
 bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
@@ -256,13 +292,22 @@ inline int plane_format(int gemm_mode) { return gemm_mode == 3 ? PF_F16X2 : gemm
 // wscale: the power of two the weight planes were scaled by (PF_F16X2; 1 otherwise)
 void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, float wscale,
                    float* C, uint16_t* Cp, int64_t c_plane, const float* bias, const float* R, int M, int N, int K, int epi,
-                   float* part, const LnArgs* ln, const AttOut* att = nullptr) {
+                   float* part, const LnArgs* ln, const AttOut* att = nullptr, const LnFold* lf = nullptr, int64_t b_plane = 0) {
     const int fmt = plane_format(e->gemm_mode);
     const int NS = fmt == PF_BF16X3 ? 3 : 2;
     const float out_scale = fmt == PF_F16X2 ? 1.0f / (kF16ActScale * wscale) : 1.0f;
     auto wgs = [&](int bm, int bn) { return (int64_t)((N + bn - 1) / bn) * ((M + bm - 1) / bm); };
     PlanCfg c;
-    if (const PlanCfg* o = plan_override(role)) c = *o;
+    if (lf) {
+        // a Linear with a LayerNorm folded around it: never split over K (the statistics are taken from finished rows), the
+        // big-tile rule of long activations below, 128 x 128 at least when it produces statistics (a part = two 32-wide tiles
+        // of one wave); the narrow projection (N = dim) only consumes: 64 x 64
+        const bool wide = N % 4 == 0 && !(epi & EPI_GELU);
+        c = N < 128 ? PlanCfg{64, 64, 2, 1}
+            : wide && !att && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+        part = nullptr;
+    }
+    else if (const PlanCfg* o = plan_override(role)) c = *o;
     else if (M <= 64 && part) {
         // ONE query (search(searcher, query::String, k), 32 rows): every Linear is a weight stream with one tile row.  Split
         // over K until the chip is full (at least three 32-deep steps per slice) with a four-buffer ring: a work-group's
@@ -299,7 +344,11 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         }
     }
     if (!part || K % (c.ks * 32) != 0) c.ks = 1;
-    GemmPArgs g{Ap, Wp, a_plane, e->wp_plane, C, bias, R, Cp, c_plane, M, N, K, N, epi, c.ks, out_scale};
+    GemmPArgs g{Ap, Wp, a_plane, b_plane ? b_plane : e->wp_plane, C, bias, R, Cp, c_plane, M, N, K, N, epi, c.ks, out_scale};
+    if (lf) {
+        g.ln_in = lf->ln_in; g.ln_parts = lf->parts; g.ln_width = lf->width; g.ln_eps = lf->eps;
+        g.ln_u = lf->u; g.r_gamma = lf->r_gamma; g.r_beta = lf->r_beta; g.stats_out = lf->stats_out;
+    }
     if (att) {      // Q | K planes and key-blocked V instead of an fp32 matrix (split over K: written by the reduce pass)
         g.C = nullptr; g.Cp = att->qk; g.c_plane = att->qk_plane; g.epi |= EPI_QKV_ATT;
         g.Vt = att->vt; g.vt_plane = att->vt_plane; g.att_L = att->L; g.att_H = att->H; g.att_heads = att->heads;
@@ -309,6 +358,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
     if (ln) g.Cp = nullptr;
     if (c.ks > 1) { g.C = part; g.Cp = nullptr; }
     auto go = [&](const PlanCfg& cc) {
+        if (lf) return launch_planes_ln(st, cc, g);           // PF_F16X2 only (forward() folds in no other mode)
         return fmt == PF_F16X2 ? launch_planes<2, true>(st, cc, g) : NS == 2 ? launch_planes<2, false>(st, cc, g) : launch_planes<3, false>(st, cc, g);
     };
     if (!go(c)) { c = {64, 64, 2, c.ks}; (void)go(c); }
@@ -392,8 +442,69 @@ int split_weights(clb_encoder* e, int fmt) {
     CLB_HIP(hipGetLastError());
     CLB_HIP(hipStreamSynchronize(st));
     e->wp_fmt = fmt;
+    // ---- the folded operands of "LayerNorm without a pass of its own" (gemm_planes2_kernel<LN>): PF_F16X2 only
+    e->fold_ready = false;
+    if (fmt == PF_F16X2 && e->layers >= 1 && H % 64 == 0 && H % 4 == 0 && e->dim % 4 == 0) {
+        const int64_t L = e->layers;
+        struct Fold { int64_t w_off, rows, g_off, b_off, bias_off, p_off, v_off; };
+        std::vector<Fold> folds;
+        e->f_qkv.assign(L, -1); e->f_w1.assign(L, -1); e->v_qkv.assign(L, -1); e->v_w1.assign(L, -1);
+        int64_t po = 0, vo = 0;
+        for (int64_t l = 0; l < L; ++l) {
+            const int64_t lo = e->o_layer0 + l * e->layer_stride, lp = lo - e->layer_stride;
+            if (l >= 1) {      // Q/K/V of layer l consumes the second LayerNorm of layer l - 1
+                e->f_qkv[l] = po; e->v_qkv[l] = vo;
+                folds.push_back({lo + e->r_wqkv, 3 * H, lp + e->r_g2, lp + e->r_b2n, lo + e->r_bqkv, po, vo});
+                po += 3 * H * H; vo += 2 * 3 * H;
+            }
+            e->f_w1[l] = po; e->v_w1[l] = vo;       // FFN-in consumes the layer's first LayerNorm
+            folds.push_back({lo + e->r_w1, I, lo + e->r_g1, lo + e->r_b1n, lo + e->r_b1, po, vo});
+            po += I * H; vo += 2 * I;
+        }
+        {   // the projection consumes the last layer's second LayerNorm
+            const int64_t ll = e->o_layer0 + (L - 1) * e->layer_stride;
+            e->f_lin = po; e->v_lin = vo;
+            folds.push_back({e->o_lin_w, e->dim, ll + e->r_g2, ll + e->r_b2n, e->o_lin_b, po, vo});
+            po += e->dim * H; vo += 2 * e->dim;
+        }
+        if (po * 4 < ((int64_t)1 << 31)) {
+            e->wpf_plane = po;
+            CLB_TRY(e->wplanes_f.ensure(sizeof(uint16_t) * 2 * po));
+            CLB_TRY(e->lnvec.ensure(sizeof(float) * vo));
+            DevBuf mx;
+            CLB_TRY(mx.alloc(sizeof(unsigned int) * folds.size()));
+            CLB_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned int) * folds.size(), st));
+            const float* W = e->weights.as<float>();
+            for (size_t i = 0; i < folds.size(); ++i)
+                hipLaunchKernelGGL(max_abs_colscaled_kernel, dim3(256), dim3(256), 0, st, W + folds[i].w_off, folds[i].rows, (int)H,
+                                   W + folds[i].g_off, mx.as<unsigned int>() + i);
+            std::vector<unsigned int> bits(folds.size());
+            CLB_HIP(hipMemcpyAsync(bits.data(), mx.p, sizeof(unsigned int) * folds.size(), hipMemcpyDeviceToHost, st));
+            CLB_HIP(hipStreamSynchronize(st));
+            e->wscale_f.assign(folds.size(), 1.0f);
+            for (size_t i = 0; i < folds.size(); ++i) {
+                float m;
+                memcpy(&m, &bits[i], sizeof m);
+                int ex = 0;
+                if (m > 0.f && m <= FLT_MAX) (void)std::frexp(m, &ex);
+                e->wscale_f[i] = std::ldexp(1.0f, std::max(-100, std::min(100, 14 - ex)));
+                hipLaunchKernelGGL(split_planes_kernel, dim3(blocks_for(folds[i].rows * H / 4)), dim3(256), 0, st, W + folds[i].w_off,
+                                   e->wplanes_f.as<uint16_t>() + folds[i].p_off, folds[i].rows, (int)H, po, fmt, e->wscale_f[i],
+                                   W + folds[i].g_off);
+                hipLaunchKernelGGL(ln_fold_vectors_kernel, dim3(blocks_for(folds[i].rows, 4)), dim3(256), 0, st, W + folds[i].w_off,
+                                   (int)folds[i].rows, (int)H, W + folds[i].g_off, W + folds[i].b_off, W + folds[i].bias_off,
+                                   e->lnvec.as<float>() + folds[i].v_off);
+            }
+            CLB_HIP(hipGetLastError());
+            CLB_HIP(hipStreamSynchronize(st));
+            e->fold_ready = true;
+        }
+    }
     return CLB_OK;
 }
+
+// index into wscale_f (the order split_weights folds in): Q/K/V of layer l >= 1, FFN-in of layer l, the projection last
+static inline size_t fold_scale_index(int64_t l, int which /* 0 = Q/K/V (l >= 1), 1 = FFN-in */) { return (size_t)(l == 0 ? 0 : 2 * l - 1 + which); }
 
 // forward for N sequences of length L; ids / mask are device pointers; result in e->out ((N*L) x dim).
 // sync = false: everything is only enqueued on `st` (an out-of-vocabulary id is then clamped silently).
@@ -452,6 +563,17 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     auto wp = [&](int64_t blob_off) { return WP + (blob_off - e->o_layer0); };
     auto ws = [&](int64_t layer, int which) { return e->wscale.empty() ? 1.0f : e->wscale[(size_t)(layer * 4 + which)]; };
     const bool short_batch = T <= 4096;         // split-K scratch only where it can be used (query batches)
+    // "LayerNorm without a pass of its own": long batches (no split-K anywhere), f16x3 planes, second GEMM form
+    const bool fold = P && PF == PF_F16X2 && e->fold_ready && !planes_first_form() && e->layers >= 1 &&
+                      (e->ln_fold == 1 || (e->ln_fold < 0 && !short_batch)) && !plan_override(LR_ATTN_OUT) && !plan_override(LR_FFN_OUT);
+    const int ln_parts = (int)(H / 64);
+    if (fold) {
+        CLB_TRY(e->stats1.ensure(sizeof(float) * 2 * ln_parts * T));
+        CLB_TRY(e->stats2.ensure(sizeof(float) * 2 * ln_parts * T));
+    }
+    const uint16_t* WPF = e->wplanes_f.as<uint16_t>();
+    const float* LV = e->lnvec.as<float>();
+    float* st1 = e->stats1.as<float>(); float* st2 = e->stats2.as<float>();
     const bool tiny = T <= 64;                  // one query: every Linear is split over K (up to 32 slices)
     if (short_batch) CLB_TRY(e->part.ensure(sizeof(float) * (tiny ? 32 * T * std::max(3 * H, I) : 8 * T * H)));
     float* part = short_batch ? e->part.as<float>() : nullptr;
@@ -477,8 +599,14 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         const float* P_ = W + e->o_layer0 + l * e->layer_stride;
         // q, k, v projections in one GEMM: (T x H) . (3H x H)^T
         const int64_t lo = e->o_layer0 + l * e->layer_stride;       // blob offset of this layer's parameters
+        const float* Pp_ = l >= 1 ? W + e->o_layer0 + (l - 1) * e->layer_stride : nullptr;     // the previous layer's parameters
         { EncTimed tm(e, ES_QKV, st);
-        if (P) linear_planes(e, st, LR_QKV, xp, hp, wp(lo + e->r_wqkv), ws(l, 0), qkv, nullptr, 0, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H),
+        if (fold && l >= 1) {   // x holds the RAW output of the previous FFN-out: its LayerNorm is folded into this product
+            const LnFold lf{st2, ln_parts, 64, e->eps, LV + e->v_qkv[l], nullptr, nullptr, nullptr};
+            linear_planes(e, st, LR_QKV, xp, hp, WPF + e->f_qkv[l], e->wscale_f[fold_scale_index(l, 0)], qkv, nullptr, 0, LV + e->v_qkv[l] + 3 * H, nullptr,
+                          (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr, nullptr, att16 ? &att_out : nullptr, &lf, e->wpf_plane);
+        }
+        else if (P) linear_planes(e, st, LR_QKV, xp, hp, wp(lo + e->r_wqkv), ws(l, 0), qkv, nullptr, 0, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H),
                              (int)H, EPI_BIAS, part_wide, nullptr, att16 ? &att_out : nullptr);
         else linear(e, st, x, P_ + e->r_wqkv, qkv, P_ + e->r_bqkv, nullptr, (int)T, (int)(3 * H), (int)H, EPI_BIAS, nullptr); }
         EncTimed* t_att = new EncTimed(e, ES_ATTENTION, st);
@@ -514,23 +642,43 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
         // attention output + residual, LayerNorm
         const LnArgs ln1{P_ + e->r_g1, P_ + e->r_b1n, e->eps}, ln2{P_ + e->r_g2, P_ + e->r_b2n, e->eps};
         { EncTimed tm(e, ES_ATTN_OUT, st);
-        if (P) linear_planes(e, st, LR_ATTN_OUT, ctxp, hp, wp(lo + e->r_wo), ws(l, 1), tmp, tmpp, hp, P_ + e->r_bo, x, (int)T, (int)H, (int)H,
+        if (fold) {     // raw rows + their partial statistics; the residual is x, raw too from layer 1 on (normalised on the fly)
+            const LnFold lf{l >= 1 ? st2 : nullptr, ln_parts, 64, e->eps, nullptr, l >= 1 ? Pp_ + e->r_g2 : nullptr, l >= 1 ? Pp_ + e->r_b2n : nullptr, st1};
+            linear_planes(e, st, LR_ATTN_OUT, ctxp, hp, wp(lo + e->r_wo), ws(l, 1), tmp, tmpp, hp, P_ + e->r_bo, x, (int)T, (int)H, (int)H,
+                          EPI_BIAS | EPI_RESID, nullptr, nullptr, nullptr, &lf);
+        }
+        else if (P) linear_planes(e, st, LR_ATTN_OUT, ctxp, hp, wp(lo + e->r_wo), ws(l, 1), tmp, tmpp, hp, P_ + e->r_bo, x, (int)T, (int)H, (int)H,
                              EPI_BIAS | EPI_RESID, part, &ln1);
         else linear(e, st, ctx, P_ + e->r_wo, tmp, P_ + e->r_bo, x, (int)T, (int)H, (int)H, EPI_BIAS | EPI_RESID, part, &ln1); }
         // feed-forward: GELU(x W1^T + b1) W2^T + b2 + residual, LayerNorm.  On the plane path the (T x I) intermediate
         // exists only as the bf16 planes the second Linear reads
         { EncTimed tm(e, ES_FFN_IN, st);
-        if (P) linear_planes(e, st, LR_FFN_IN, tmpp, hp, wp(lo + e->r_w1), ws(l, 2), nullptr, hbp, ip, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H,
+        if (fold) {
+            const LnFold lf{st1, ln_parts, 64, e->eps, LV + e->v_w1[l], nullptr, nullptr, nullptr};
+            linear_planes(e, st, LR_FFN_IN, tmpp, hp, WPF + e->f_w1[l], e->wscale_f[fold_scale_index(l, 1)], nullptr, hbp, ip, LV + e->v_w1[l] + I, nullptr,
+                          (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr, nullptr, nullptr, &lf, e->wpf_plane);
+        }
+        else if (P) linear_planes(e, st, LR_FFN_IN, tmpp, hp, wp(lo + e->r_w1), ws(l, 2), nullptr, hbp, ip, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H,
                              EPI_BIAS | EPI_GELU, part_wide, nullptr);
         else linear(e, st, tmp, P_ + e->r_w1, hb, P_ + e->r_b1, nullptr, (int)T, (int)I, (int)H, EPI_BIAS | EPI_GELU, nullptr); }
         { EncTimed tm(e, ES_FFN_OUT, st);
-        if (P) linear_planes(e, st, LR_FFN_OUT, hbp, ip, wp(lo + e->r_w2), ws(l, 3), x, xp, hp, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I,
+        if (fold) {     // the residual is the raw attention-output row: its (first) LayerNorm is applied on the fly
+            const LnFold lf{st1, ln_parts, 64, e->eps, nullptr, P_ + e->r_g1, P_ + e->r_b1n, st2};
+            linear_planes(e, st, LR_FFN_OUT, hbp, ip, wp(lo + e->r_w2), ws(l, 3), x, xp, hp, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I,
+                          EPI_BIAS | EPI_RESID, nullptr, nullptr, nullptr, &lf);
+        }
+        else if (P) linear_planes(e, st, LR_FFN_OUT, hbp, ip, wp(lo + e->r_w2), ws(l, 3), x, xp, hp, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I,
                              EPI_BIAS | EPI_RESID, part, &ln2);
         else linear(e, st, hb, P_ + e->r_w2, x, P_ + e->r_b2, tmp, (int)T, (int)H, (int)I, EPI_BIAS | EPI_RESID, part, &ln2); }
     }
     // ColBERT projection: Layers.Dense(hidden -> dim)
     { EncTimed tm(e, ES_PROJECTION, st);
-    if (P) linear_planes(e, st, LR_PROJ, xp, hp, wp(e->o_lin_w), ws(e->layers, 0), e->out.as<float>(), nullptr, 0, W + e->o_lin_b, nullptr, (int)T,
+    if (fold) {         // x holds the raw output of the last FFN-out
+        const LnFold lf{st2, ln_parts, 64, e->eps, LV + e->v_lin, nullptr, nullptr, nullptr};
+        linear_planes(e, st, LR_PROJ, xp, hp, WPF + e->f_lin, e->wscale_f.back(), e->out.as<float>(), nullptr, 0, LV + e->v_lin + e->dim, nullptr, (int)T,
+                      (int)e->dim, (int)H, EPI_BIAS, nullptr, nullptr, nullptr, &lf, e->wpf_plane);
+    }
+    else if (P) linear_planes(e, st, LR_PROJ, xp, hp, wp(e->o_lin_w), ws(e->layers, 0), e->out.as<float>(), nullptr, 0, W + e->o_lin_b, nullptr, (int)T,
                          (int)e->dim, (int)H, EPI_BIAS, part, nullptr);
     else linear(e, st, x, W + e->o_lin_w, e->out.as<float>(), W + e->o_lin_b, nullptr, (int)T, (int)e->dim, (int)H, EPI_BIAS, part); }
     CLB_HIP(hipGetLastError());
@@ -685,6 +833,13 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     if (mode < 0 || mode > 3) return fail(CLB_EARGUMENT, "gemm mode %d: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = f16x3", mode);
     e->gemm_mode = mode;
+    return CLB_OK;
+}
+
+int clb_encoder_set_ln_fold(clb_encoder* e, int mode) {
+    if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (mode < -1 || mode > 1) return fail(CLB_EARGUMENT, "LayerNorm folding: -1 = long batches only (default), 0 = never, 1 = always");
+    e->ln_fold = mode;
     return CLB_OK;
 }
 

@@ -490,7 +490,31 @@ struct GemmPArgs {
     // packed batches (sequences of different lengths back to back, no padding rows): the sequence and the position of
     // every row; null: row m = sequence m / att_L, position m % att_L
     const int32_t* att_seq = nullptr; const int32_t* att_pos = nullptr;
+    // LayerNorm folded AROUND the product (gemm_planes2_kernel<..., LN = true>; see "LayerNorm without a pass of its own"):
+    //   ln_in     [M][ln_parts][2] partial (mean, M2 = sum of squared deviations from that mean) of the rows the LayerNorm is
+    //             taken over, ln_width columns per part: A's rows when ln_u is set (fold), R's rows when r_gamma is set
+    //   ln_u      fold: u[n] = sum_k gamma_k W[n][k]; `bias` then holds c[n] = sum_k beta_k W[n][k] + b[n] and the B planes hold
+    //             gamma (.) W:  LN(a) . W^T + b  =  rstd (a . (gamma (.) W)^T - mean u) + c
+    //   r_gamma / r_beta   the residual R holds RAW rows (a product's output before its LayerNorm): what is added is
+    //             (R - mean) rstd gamma + beta
+    //   stats_out [M][N / 64][2]: the partial (mean, M2) of THIS product's output rows, 64 columns per part
+    const float* ln_in = nullptr; int ln_parts = 0, ln_width = 0; float ln_eps = 0.f;
+    const float* ln_u = nullptr;
+    const float* r_gamma = nullptr; const float* r_beta = nullptr;
+    float* stats_out = nullptr;
 };
+
+// mean and 1 / sqrt(var + eps) of a row from its partial statistics (equal-width parts): Chan's combination -- the deviations
+// are taken from each part's own mean and the parts' means from the row's, never E[x^2] - mean^2
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int parts, int width, float eps, float& mean, float& rstd) {
+    float msum = 0.f, m2 = 0.f;
+    for (int p = 0; p < parts; ++p) msum += st[2 * p];
+    mean = msum / (float)parts;
+    float dev = 0.f;
+    for (int p = 0; p < parts; ++p) { const float d = st[2 * p] - mean; m2 += st[2 * p + 1]; dev = fmaf(d, d, dev); }
+    const float var = (m2 + (float)width * dev) / (float)(parts * width);
+    rstd = 1.0f / sqrtf(var + eps);
+}
 
 // V for attention_f16_kernel: [sequence][head][tile of 32 keys][d = 0..63][32 keys], the keys of a tile in the order in which
 // the lanes of the score accumulator hold them -- lane half h, MFMA step u, slot j <-> key 16 u + 8 (j >> 2) + 4 h + (j & 3) sits
@@ -573,13 +597,15 @@ __device__ __forceinline__ void store_planes4(uint16_t* p, int64_t plane, int fm
 // fp32 (rows x K, row-major) -> K-blocked planes, four elements per thread (weights at create time; activations whose
 // producer is not fused)
 static __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes_,
-                                                                 int64_t rows, int K, int64_t plane, int fmt, float scale) {
+                                                                 int64_t rows, int K, int64_t plane, int fmt, float scale,
+                                                                 const float* __restrict__ colscale = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index of the row-major (rows x K) input
     if (i >= rows * (K / 4)) return;
     const int64_t row = i / (K / 4);
     const int k = (int)(i % (K / 4)) * 4;
     uint16_t* planes = planes_ + plane_index(row, k, rows);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    if (colscale) v = v * *reinterpret_cast<const f32x4*>(colscale + k);   // gamma (.) W: one fp32 rounding, then the exact split
     if (fmt == PF_F16X2) {       // `scale`: kF16ActScale for activations, the matrix's own power of two for weights
         uint16_t h[4], l[4];
 #pragma unroll
@@ -599,6 +625,31 @@ static __global__ __launch_bounds__(256) void split_planes_kernel(const float* _
         const uint32_t t1 = cvt_pk_bf16(r2 - __uint_as_float(l1 << 16), r3 - __uint_as_float(l1 & 0xffff0000u));
         *reinterpret_cast<uint2*>(planes + 2 * plane) = make_uint2(t0, t1);
     }
+}
+
+// max |colscale[k] W[n][k]| of a (rows x K) matrix -> the power-of-two scale of its folded fp16 planes
+static __global__ __launch_bounds__(256) void max_abs_colscaled_kernel(const float* __restrict__ w, int64_t rows, int K,
+                                                                       const float* __restrict__ colscale, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    const int64_t n = rows * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i] * colscale[i % K]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
+// u[n] = sum_k gamma_k W[n][k], c[n] = sum_k beta_k W[n][k] + b[n] (one wave per n: lane partial sums over k = lane, lane + 64,
+// ..., then a fixed butterfly -- deterministic); out = [u (N) | c (N)]
+static __global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ w, int N, int K, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ bias,
+                                                                     float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float u = 0.f, c = 0.f;
+    for (int k = lane; k < K; k += 64) { const float x = w[(int64_t)n * K + k]; u = fmaf(gamma[k], x, u); c = fmaf(beta[k], x, c); }
+    for (int o = 32; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); c += __shfl_xor(c, o, 64); }
+    if (lane == 0) { out[n] = u; out[N + n] = c + bias[n]; }
 }
 
 // number of work-groups to launch for gemm_planes_kernel's XCD-aware mapping (1-D grid)
@@ -771,7 +822,16 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes_kernel(Gemm
 // this one, and the single barrier of a step sits between the halves -- "tile k + 1 has landed and tile k has been read by
 // everyone" -- after which the DMA of tile k + STAGES goes into the buffer just freed: the LDS latency is never exposed and a
 // DMA has a whole step to land even with two buffers.  Requires N % 4 == 0 (host).
-template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false>
+// LN = true (round 5): "LayerNorm without a pass of its own".  On a passage batch the stand-alone LayerNorm read and wrote
+// 177 MB per call, 48.7 us x 24 = 8.6 % of the forward.  Here the Linear that PRODUCES a LayerNorm's input (attention output,
+// FFN-out) stores the raw rows -- fp32 and planes -- and, per row and 64-column part, their (mean, M2) (stats_out: a lane owns
+// one output row, so a part is 32 registers of this lane + 32 of its partner in the other lane half: two in-lane sums and two
+// exchanges); the Linear that CONSUMES it (Q/K/V, FFN-in, the projection) multiplies the RAW planes with gamma (.) W and applies
+//   LN(a) . W^T + b = rstd (a . (gamma (.) W)^T - mean u) + c,   u[n] = sum_k gamma_k W[n][k],  c[n] = sum_k beta_k W[n][k] + b[n]
+// in its epilogue (two floats per row from ln_in, two vectors per column); the residual connection, which needs the normalised
+// row itself, normalises the raw fp32 row it reads anyway (r_gamma / r_beta).  The flags are run-time (GemmPArgs) so that one
+// instantiation per tile serves producer, consumer and both.
+template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false, bool LN = false>
 static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(GemmPArgs g) {
     static_assert(!F16 || NS == 2, "the fp16 split has two planes");
     constexpr int PFMT = F16 ? PF_F16X2 : (NS == 3 ? PF_BF16X3 : PF_BF16X2);
@@ -892,17 +952,24 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
     // D' layout: column (lane & 31) = m, row (r & 3) + 8 * (r >> 2) + 4 * h = n: four consecutive n per register group
     const bool qkv_att = F16 && !split && (g.epi & EPI_QKV_ATT);
     const int att_nt = qkv_att ? (g.att_L + 31) >> 5 : 0;
+    const bool ln_fold = LN && !split && g.ln_u != nullptr;           // the A rows are raw: fold their LayerNorm into this product
+    const bool ln_res = LN && !split && g.r_gamma != nullptr;         // the residual rows are raw: normalise them on the fly
+    const bool ln_out = LN && !split && g.stats_out != nullptr;       // leave the partial statistics of the output rows
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
         const int m = m0 + (wr * WM + a) * 32 + i;
+        // (no early exit for rows past M when statistics are exchanged between the lane halves below: both halves hold the same m)
         if (m >= g.M) continue;
         int64_t vrow = 0;                 // EPI_QKV_ATT: vt_index of (this token, head 0, d 0)
         if (qkv_att) {
             const uint32_t seq = g.att_seq ? (uint32_t)g.att_seq[m] : (uint32_t)m / (uint32_t)g.att_L;
             vrow = vt_index(seq, 0, g.att_heads, att_nt, g.att_pos ? g.att_pos[m] : m - (int)seq * g.att_L, 0);
         }
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if (LN && (ln_fold || ln_res)) ln_row_stats(g.ln_in + (int64_t)m * g.ln_parts * 2, g.ln_parts, g.ln_width, g.ln_eps, ln_mean, ln_rstd);
+        float psum = 0.f;                 // ln_out: this lane's sum over the current 64-column part
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+        for (int b = 0; b < WN; ++b) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
@@ -910,9 +977,23 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                 f32x4 v = {acc[a][b][4 * gq], acc[a][b][4 * gq + 1], acc[a][b][4 * gq + 2], acc[a][b][4 * gq + 3]};
                 if (!split) {
                     if (F16) v = v * g.out_scale;
-                    if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
+                    if (LN && ln_fold) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(g.ln_u + n);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] - ln_mean * u[j], ln_rstd, c[j]);
+                    } else if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
                     if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-                    if (g.epi & EPI_RESID) v = v + *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
+                    if (g.epi & EPI_RESID) {
+                        f32x4 r = *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
+                        if (LN && ln_res) {
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(g.r_gamma + n);
+                            const f32x4 bt = *reinterpret_cast<const f32x4*>(g.r_beta + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r[j] = fmaf((r[j] - ln_mean) * ln_rstd, gm[j], bt[j]);
+                        }
+                        v = v + r;
+                    }
                     if (qkv_att) {
                         if (n < 2 * g.att_H) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
                         else {            // V: (head, d) of column n - 2H; the four d of this group are 64 bytes apart in a key row
@@ -927,9 +1008,29 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                             }
                         }
                     } else if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
+                    if (LN && ln_out) {   // keep the finished values for the second (deviation) sweep
+                        acc[a][b][4 * gq] = v[0]; acc[a][b][4 * gq + 1] = v[1]; acc[a][b][4 * gq + 2] = v[2]; acc[a][b][4 * gq + 3] = v[3];
+                        psum += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
                 }
                 if (C) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + n) = v;
             }
+            if (LN && ln_out && (b & 1)) {
+                // part = the 64 columns of tiles b - 1, b: 32 values here, 32 in lane i of the other half (same row m)
+                static_assert(!LN || WN % 2 == 0 || WN == 1, "a 64-column part is two adjacent 32-column tiles of one wave");
+                const float mean = (psum + __shfl_xor(psum, 32, 64)) * (1.0f / 64.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int bb = b - 1; bb <= b; ++bb)
+#pragma unroll
+                    for (int r_ = 0; r_ < 16; ++r_) { const float d = acc[a][bb < 0 ? 0 : bb][r_] - mean; q = fmaf(d, d, q); }
+                q += __shfl_xor(q, 32, 64);
+                const int part = (n0 + (wc * WN + b - 1) * 32) >> 6;
+                if (h == 0 && n0 + (wc * WN + b) * 32 < g.N)
+                    *reinterpret_cast<f32x2_t*>(g.stats_out + ((int64_t)m * (g.N >> 6) + part) * 2) = f32x2_t{mean, q};
+                psum = 0.f;
+            }
+        }
     }
 }
 

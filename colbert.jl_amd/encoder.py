@@ -68,7 +68,7 @@ def random_weights(bert_cfg: dict, dim: int = 128, seed: int = 0) -> np.ndarray:
 class BertEncoder:
     def __init__(self, weights: np.ndarray, bert_cfg: dict, dim: int = 128, device: int = 0,
                  tokenizer=None, config: Optional[ColBERTConfig] = None, gemm: Optional[str] = None,
-                 attention: str = "fused"):
+                 attention: str = "fused", ln_fold: Optional[int] = None):
         """`gemm`: arithmetic of the Linear layers -- "f16x3" (default: every fp32 operand, scaled by a power of two, split
         into TWO fp16 planes -- round-to-nearest makes them hold all 24 significant bits -- and three exact fp16 MFMA products
         per fp32 product, fp32 accumulation: fp32-faithful like bf16x6 at half its products), "bf16x6" (three bf16 planes, six
@@ -94,6 +94,11 @@ class BertEncoder:
         if attention not in amodes:
             raise ValueError(f"attention must be one of {sorted(amodes)}, not {attention!r}")
         check(lib().clb_encoder_set_attention_mode(self._h, amodes[attention]))
+        # LayerNorm folded around the Linear layers (clb_encoder_set_ln_fold): -1 long batches only (default), 0 never, 1 always
+        if ln_fold is None and "COLBERT_ENC_LNFOLD" in os.environ:
+            ln_fold = int(os.environ["COLBERT_ENC_LNFOLD"])
+        if ln_fold is not None:
+            check(lib().clb_encoder_set_ln_fold(self._h, C.c_int(int(ln_fold))))
 
     @classmethod
     def from_export(cls, path: str, **kw) -> "BertEncoder":

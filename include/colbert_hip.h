@@ -349,6 +349,12 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
  * 1 = fp32 MFMA, register-resident for every length; 2 = the three-kernel path (scores in memory; always taken for other head
  * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode -- 1 to 3 exist for comparison. */
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
+/* LayerNorm folded around the Linear layers (f16x3 only): the Linear that produces a LayerNorm's input stores the raw rows and
+ * their partial (mean, M2); the Linear that consumes it multiplies the raw rows with gamma (.) W and applies
+ * rstd (a . (gamma (.) W)^T - mean u) + c in its epilogue -- no stand-alone LayerNorm pass (48.7 us x 24 per 64 x 300 passage
+ * batch).  Same function of the inputs as `doc` (src/modelling/checkpoint.jl:21-25), different rounding.
+ * mode: -1 = batches too long to split over K (default: passage batches), 0 = never, 1 = always (tests). */
+int clb_encoder_set_ln_fold(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
 int clb_encode(clb_encoder* e, const int32_t* integer_ids, const uint8_t* bitmask, int64_t L, int64_t N, float* out);

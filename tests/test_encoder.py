@@ -262,6 +262,60 @@ def test_fused_attention_long_sequences(L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["two_layers", "wide_three_layers", "long_batch_auto"])
+def test_layernorm_folded_around_the_linear_layers(shape):
+    """Round 5: the LayerNorms as statistics carried between the Linear layers (clb_encoder_set_ln_fold; the producing Linear
+    leaves raw rows + per-row partial (mean, M2), the consuming Linear multiplies gamma (.) W and applies
+    rstd (a . W'^T - mean u) + c) against the independent fp32 reference at the tolerance of the unfolded path, against the
+    unfolded path itself, and deterministic.  `long_batch_auto`: more than 4 096 rows take the folded path on their own
+    (what a 64 x 300 passage batch and the packed batches of index() do); padded AND packed."""
+    hidden, layers, heads, inter, L, N = {"two_layers": (64, 2, 1, 128, 37, 5), "wide_three_layers": (192, 3, 3, 320, 50, 7),
+                                          "long_batch_auto": (128, 2, 2, 256, 130, 36)}[shape]
+    torch, cfg, bert, linear = _random_bert(hidden=hidden, layers=layers, heads=heads, inter=inter, vocab=150, max_pos=160, dim=32, seed=11)
+    with torch.no_grad():                       # LayerNorm parameters away from (1, 0): the folded vectors u, c must carry them
+        for name, p_ in bert.named_parameters():
+            if "LayerNorm.weight" in name:
+                p_.copy_(1.0 + 0.3 * torch.randn_like(p_))
+            if "LayerNorm.bias" in name:
+                p_.copy_(0.2 * torch.randn_like(p_))
+    from colbert_jl_amd.encoder import pack_weights
+    bcfg = cfg.to_dict()
+    w = pack_weights(_state(bert, linear), bcfg, 32)
+    rng = np.random.default_rng(4)
+    ids0 = rng.integers(0, cfg.vocab_size, size=(N, L))
+    lens = rng.integers(L // 2, L + 1, size=N); lens[0] = L
+    mask = np.zeros((N, L), bool)
+    for n, l in enumerate(lens):
+        mask[n, :l] = True
+    with torch.no_grad():
+        ref = linear(bert(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state).numpy()
+    jl_ids, jl_mask = (ids0.T + 1).astype(np.int32), mask.T
+    plain = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", ln_fold=0)
+    base = plain.doc(jl_ids, jl_mask)
+    plain.close()
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", ln_fold=-1 if shape == "long_batch_auto" else 1)
+    got = enc.doc(jl_ids, jl_mask)
+    again = enc.doc(jl_ids, jl_mask)
+    assert np.array_equal(got.view(np.uint32), again.view(np.uint32))
+    if shape == "long_batch_auto":
+        assert N * L > 4096 and not np.array_equal(got.view(np.uint32), base.view(np.uint32))       # it did take the other path
+    err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()
+    err0 = np.abs(base.transpose(2, 1, 0) - ref)[mask].max()
+    print(f"[LayerNorm fold, {shape}] max |got - torch fp32| = {err:.3g} (unfolded: {err0:.3g})")
+    assert err < GEMM_TOL["f16x3"] and err < 3 * err0 + 2e-5, (err, err0)
+    assert np.abs(got - base).transpose(2, 1, 0)[mask].max() < 1e-4
+    # the document epilogue on top, and packed batches (every row attended, no padding rows) through the same folded Linears
+    skip = [5, 17, 33]
+    D, dl = enc.doc_embeddings_and_doclens(skip, jl_ids, jl_mask)
+    keep = mask & ~np.isin(ids0 + 1, skip)
+    assert np.array_equal(dl, keep.sum(axis=1))
+    flat = ref[keep]
+    flat = flat / (np.linalg.norm(flat, axis=1, keepdims=True) + np.finfo(np.float32).eps)
+    assert np.abs(D.T - flat).max() < 2e-4
+    enc.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gemm", ["f32", "bf16x6", "f16x3", "bf16x3"])
 def test_bert_base_shape_and_export_roundtrip(tmp_path, tok, gemm):
     """bert-base-uncased geometry (12 x 768, 12 heads, FFN 3072), one short batch; weights through the export tool."""
