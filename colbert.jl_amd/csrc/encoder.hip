@@ -22,7 +22,8 @@ struct clb_encoder {
     int attention_mode = 0;     // 0 = fused: the fp16-plane kernel behind the f16x3 Linear layers (attention_f16_kernel), else
                                 // fp32 MFMA (register-resident up to 64 keys, online softmax beyond); 1 = fp32 register-resident
                                 // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64),
-                                // 3 = fused on the fp32 MFMA whatever the GEMM mode (comparison)
+                                // 3 = fused on the fp32 MFMA whatever the GEMM mode (comparison); 4 = as 0, every wave loading its
+                                // own K / V tiles (the round-4 kernel: comparison, bit-identical to 0)
     int gemm_mode = 3;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6, 3 = f16x3 (MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
@@ -262,6 +263,12 @@ bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     CLB_GPL_CASE(64, 64, 2, 2, 2, 1, 1) CLB_GPL_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GPL_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GPL_CASE(256, 256, 2, 4, 2, 2, 4)
 #undef CLB_GPL_CASE
     return false;
+}
+
+// COLBERT_ENC_ATT_LDS=0: every wave of attention_f16_kernel loads its own K / V tiles (the round-4 kernel) -- comparison runs
+static bool att_lds() {
+    static const bool v = [] { const char* e = getenv("COLBERT_ENC_ATT_LDS"); return !(e && atoi(e) == 0); }();
+    return v;
 }
 
 template <int NS, bool F16>
@@ -512,7 +519,7 @@ static inline size_t fold_scale_index(int64_t l, int which /* 0 = Q/K/V (l >= 1)
 static bool can_pack(const clb_encoder* e, int64_t L, int64_t rows_max = 0) {
     const int64_t H = e->H, I = e->I;
     return e->planes && e->gemm_mode == 3 && H % 32 == 0 && I % 32 == 0 && e->heads > 0 && H / e->heads == 64 && L <= 512 &&
-           e->attention_mode == 0 && !planes_first_form() && rows_max * std::max(H, I) * 6 < ((int64_t)1 << 31);
+           (e->attention_mode == 0 || e->attention_mode == 4) && !planes_first_form() && rows_max * std::max(H, I) * 6 < ((int64_t)1 << 31);
 }
 
 // pk (packed batch): d_ids holds pk->rows token ids, L is the longest sequence, d_mask is unused; needs the fp16-plane attention.
@@ -541,7 +548,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     const int PF = plane_format(e->gemm_mode);
     if (P && e->wp_fmt != PF) CLB_TRY(split_weights(e, PF));
     // attention on fp16 planes: the Q/K/V projection writes them (second GEMM form, never split over K)
-    const bool att16 = P && PF == PF_F16X2 && fused && e->attention_mode == 0 && H % 4 == 0 && !planes_first_form();
+    const bool att16 = P && PF == PF_F16X2 && fused && (e->attention_mode == 0 || e->attention_mode == 4) && H % 4 == 0 && !planes_first_form();
     const int64_t ntile = (L + 31) / 32, qk_plane = T * 2 * H, vt_plane = N * heads * ntile * 64 * 32;
     if (pk && !att16)
         return fail(CLB_EARGUMENT, "a packed batch needs the fp16-plane attention (head size 64, f16x3 Linear layers, attention mode 0)");
@@ -615,7 +622,23 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
             uint16_t* cp_ = P ? ctxp : nullptr;
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
-            if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
+            if (att16 && L > 32 && att_lds() && e->attention_mode != 4) {
+                // the query blocks of a (sequence, head) share its K / V tiles through LDS (attention_f16_lds_kernel): NW waves
+                // of QB blocks per work-group -- a whole sequence up to 512 tokens at QB = 2; bit-identical to the kernels below
+                const int QB = L >= 128 && att_qb2() ? 2 : 1;
+                int NW = (int)((L + 32 * QB - 1) / (32 * QB));
+                // QB = 2 needs ~290 registers: up to four waves run one per SIMD with the AGPRs as overflow; five and more share
+                // SIMDs (256 registers) and spill unless the staging is spread over eight waves (idle ones only stage)
+                NW = NW > 8 ? 8 : NW == 7 ? 8 : NW < 2 ? 2 : (QB == 2 && NW >= 5) ? 8 : NW;
+                const dim3 gridl((unsigned)((L + 32 * QB * NW - 1) / (32 * QB * NW)), (unsigned)heads, (unsigned)N);
+#define CLB_ATTL(QB_, NW_)                                                                                              \
+    if (QB == QB_ && NW == NW_)                                                                                         \
+        hipLaunchKernelGGL((attention_f16_lds_kernel<QB_, NW_>), gridl, dim3(64 * NW_), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, \
+                           d_mask, (int)L, (int)H, inv_sqrt, ctxp, hp, PF, pk ? pk->cu : nullptr);
+                CLB_ATTL(1, 2) CLB_ATTL(1, 3) CLB_ATTL(1, 4) CLB_ATTL(2, 2) CLB_ATTL(2, 3) CLB_ATTL(2, 4) CLB_ATTL(2, 5) CLB_ATTL(2, 6) CLB_ATTL(2, 8)
+                CLB_ATTL(1, 5) CLB_ATTL(1, 6) CLB_ATTL(1, 8)
+#undef CLB_ATTL
+            } else if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
                 const dim3 grid2((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)N);
                 hipLaunchKernelGGL(attention_f16_kernel<2>, grid2, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
                                    (int)H, inv_sqrt, ctxp, hp, PF, pk ? pk->cu : nullptr);
@@ -845,8 +868,9 @@ int clb_encoder_set_ln_fold(clb_encoder* e, int mode) {
 
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
-    if (mode < 0 || mode > 3)
-        return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels, 3 = fused on the fp32 MFMA", mode);
+    if (mode < 0 || mode > 4)
+        return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels, 3 = fused on the fp32 MFMA, "
+                                   "4 = fused without the LDS-shared K / V tiles", mode);
     e->attention_mode = mode;
     return CLB_OK;
 }

@@ -1723,6 +1723,227 @@ static __global__ __launch_bounds__(64, QB == 1 ? 3 : 2) void attention_f16_kern
     }
 }
 
+// Round 5: the same attention with the K / V tiles of a (sequence, head) SHARED by its query blocks through LDS.  In the kernel
+// above every wave pulls all key tiles of its sequence through L2 on its own -- 16 KB per tile and wave, 1.2 GB per layer on a
+// 64 x 300 passage batch, and the kernel is bound by those loads (halving them bought 20 %, cutting a third of its vector
+// instructions 3 %).  Here a work-group of NW waves owns 32 QB NW queries of one (sequence, head) -- a whole 300-token passage
+// at QB = 2, NW = 5 -- and stages every key tile ONCE: 2 planes x (K: 2 feature blocks x 32 keys x 64 B, V: 64 d x 64 B) = 16 KB,
+// double-buffered (global -> registers while the previous tile is multiplied, registers -> LDS behind it, one barrier per tile);
+// rows are padded to 80 bytes, so the ds_read_b128 of 16 consecutive lanes touch 64 different banks.  Every wave then reads
+// exactly the fragments it used to load: the same MFMAs on the same operands in the same order -- bit-identical output.
+// A wave whose queries lie past the end of a (packed) sequence still stages and meets the barriers.  grid = (ceil(L / (32 QB
+// NW)), heads, N), block = 64 NW.
+template <int QB, int NW>
+static __global__ __launch_bounds__(64 * NW) void attention_f16_lds_kernel(const uint16_t* __restrict__ qk, int64_t qk_plane, int64_t rows,
+                                                                          const uint16_t* __restrict__ vt, int64_t vt_plane,
+                                                                          const uint8_t* __restrict__ mask, int L, int H, float scale,
+                                                                          uint16_t* __restrict__ ctxp, int64_t c_plane, int ns,
+                                                                          const int32_t* __restrict__ cu = nullptr) {
+    constexpr int NT = 64 * NW;
+    constexpr int kRow = 80;                              // padded LDS row (64 B of data)
+    constexpr int kKBytes = 2 * 2 * 32 * kRow, kVBytes = 2 * 64 * kRow, kStage = kKBytes + kVBytes;     // 20 480 B per tile
+    constexpr int kChunks = 1024;                         // 16-byte pieces of a tile: 512 of K, 512 of V
+    constexpr int CPT = (kChunks + NT - 1) / NT;          // pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, heads = gridDim.y;
+    const int64_t n = blockIdx.z;
+    const int nt_layout = (L + 31) >> 5;
+    const int64_t row0 = cu ? (int64_t)cu[n] : n * L;
+    if (cu) L = cu[n + 1] - cu[n];
+    if ((int)blockIdx.x * NW * 32 * QB >= L) return;                     // the whole work-group lies past the sequence
+    const int q0 = ((int)blockIdx.x * NW + wave) * 32 * QB;
+    const bool active = q0 < L;
+    const uint8_t* mk = cu ? nullptr : mask + n * L;
+    // key tiles up to the last attended key (padding behind it is all masked: nothing to add, nothing to stage)
+    int nt = (L + 31) >> 5;
+    if (mk) {
+        int last = -1;
+        for (int k0 = lane; k0 < L; k0 += 64) last = mk[k0] ? k0 : last;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(last, o, 64); last = y > last ? y : last; }
+        nt = (last + 32) >> 5;                                           // last = -1: no tile
+    }
+    // ---- staging: piece c of a tile -> (source address, LDS offset); tile jt adds its own strides
+    u32x4 stg[CPT];
+    auto load_tile = [&](int jt) {
+#pragma unroll
+        for (int p = 0; p < CPT; ++p) {
+            const int c = tid + NT * p;
+            if (c >= kChunks) break;
+            const int plane = (c >> 8) & 1, ch = c & 3;
+            if (c < 512) {
+                const int blk = (c >> 7) & 1, r = (c >> 2) & 31;
+                const int key = 32 * jt + r;
+                const int krow = key < L ? key : L - 1;
+                const uint16_t* src = qk + (int64_t)plane * qk_plane + plane_index(row0 + krow, H + head * 64 + 32 * blk, rows) + 8 * ch;
+                stg[p] = *reinterpret_cast<const u32x4*>(src);
+            } else {
+                const int d = (c >> 2) & 63;
+                const uint16_t* src = vt + (int64_t)plane * vt_plane + (((((n * heads + head) * nt_layout + jt) * 64) + d) << 5) + 8 * ch;
+                stg[p] = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = tiles + buf * kStage;
+#pragma unroll
+        for (int p = 0; p < CPT; ++p) {
+            const int c = tid + NT * p;
+            if (c >= kChunks) break;
+            const int plane = (c >> 8) & 1, ch = c & 3;
+            if (c < 512) {
+                const int blk = (c >> 7) & 1, r = (c >> 2) & 31;
+                *reinterpret_cast<u32x4*>(base + ((plane * 2 + blk) * 32 + r) * kRow + 16 * ch) = stg[p];
+            } else {
+                const int d = (c >> 2) & 63;
+                *reinterpret_cast<u32x4*>(base + kKBytes + (plane * 64 + d) * kRow + 16 * ch) = stg[p];
+            }
+        }
+    };
+    u32x4 qh[QB][4], ql[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + 32 * qb + i;
+        const int64_t qrow = row0 + (qi < L ? qi : L - 1);
+        const uint16_t* qp = qk + plane_index(qrow, head * 64 + 32 * h, rows);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qh[qb][s] = reinterpret_cast<const u32x4*>(qp)[s];
+            ql[qb][s] = reinterpret_cast<const u32x4*>(qp + qk_plane)[s];
+        }
+    }
+    f32x16 o0[QB], o1[QB];
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = kNegInf; l[qb] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[qb][r] = 0.f; o1[qb][r] = 0.f; }
+    }
+    const float sscale = scale * (1.0f / (kF16ActScale * kF16ActScale)) * 1.44269504088896340736f;     // -> log2 domain
+    constexpr float kPScale = 1024.0f;
+    if (nt > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+    for (int jt = 0; jt < nt; ++jt) {
+        const bool more = jt + 1 < nt;
+        if (more) load_tile(jt + 1);                                    // in flight under this tile's products
+        const int key = 32 * jt + i;
+        const int krow = key < L ? key : L - 1;
+        const uint32_t valid = (uint32_t)__builtin_amdgcn_ballot_w64(h == 0 && key < L && (!mk || mk[krow] != 0));
+        if (active && valid != 0u) {
+            const unsigned char* kb = tiles + (jt & 1) * kStage + (h * 32 + i) * kRow;
+            const unsigned char* vb = tiles + (jt & 1) * kStage + kKBytes + i * kRow + 32 * h;
+            // phase 1, every query block: scores, running maximum / sum, probabilities (split in registers).  The K fragments
+            // are dead before the V fragments are read (from LDS there is no latency to hide by requesting them early): the
+            // kernel stays under the 256 registers of two waves per SIMD
+            u32x4 ph[QB][2], pl[QB][2];
+            {
+                u32x4 kh[4], kl[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    kh[s] = *reinterpret_cast<const u32x4*>(kb + 16 * s);
+                    kl[s] = *reinterpret_cast<const u32x4*>(kb + 2 * 32 * kRow + 16 * s);
+                }
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    f32x16 st;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kl[s]), __builtin_bit_cast(f16x8, qh[qb][s]), st, 0, 0, 0);
+                        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, ql[qb][s]), st, 0, 0, 0);
+                        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kh[s]), __builtin_bit_cast(f16x8, qh[qb][s]), st, 0, 0, 0);
+                    }
+                    float tmax = kNegInf;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kbit = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float v = ((valid >> kbit) & 1u) ? st[r] * sscale : kNegInf;
+                        st[r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    const float m_new = fmaxf(m[qb], tmax);
+                    const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                    float psum = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            const float e0 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2] - m_new);
+                            const float e1 = __builtin_amdgcn_exp2f(st[8 * u + 2 * j2 + 1] - m_new);
+                            psum += e0;
+                            psum += e1;
+                            const f16x2 hh = {(_Float16)(e0 * kPScale), (_Float16)(e1 * kPScale)};
+                            const f16x2 ll = {(_Float16)(e0 * kPScale - (float)hh[0]), (_Float16)(e1 * kPScale - (float)hh[1])};
+                            ph[qb][u][j2] = __builtin_bit_cast(uint32_t, hh);
+                            pl[qb][u][j2] = __builtin_bit_cast(uint32_t, ll);
+                        }
+                    l[qb] = l[qb] * alpha + psum;
+                    if (__builtin_amdgcn_ballot_w64(m_new > m[qb]) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int qa = (r & 3) + 8 * (r >> 2);
+                            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa));
+                            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), qa + 4));
+                            const float a = h ? a1 : a0;
+                            o0[qb][r] *= a;
+                            o1[qb][r] *= a;
+                        }
+                    }
+                    m[qb] = m_new;
+                }
+            }
+            // phase 2, every query block: P . V (the products of a block in the order of the kernel above)
+            {
+                u32x4 vh[2][2], vl[2][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        vh[c][u] = *reinterpret_cast<const u32x4*>(vb + c * 32 * kRow + 16 * u);
+                        vl[c][u] = *reinterpret_cast<const u32x4*>(vb + (64 + c * 32) * kRow + 16 * u);
+                    }
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[qb][u]), __builtin_bit_cast(f16x8, vh[0][u]), o0[qb], 0, 0, 0);
+                        o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[qb][u]), __builtin_bit_cast(f16x8, vl[0][u]), o0[qb], 0, 0, 0);
+                        o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[qb][u]), __builtin_bit_cast(f16x8, vh[0][u]), o0[qb], 0, 0, 0);
+                        o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pl[qb][u]), __builtin_bit_cast(f16x8, vh[1][u]), o1[qb], 0, 0, 0);
+                        o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[qb][u]), __builtin_bit_cast(f16x8, vl[1][u]), o1[qb], 0, 0, 0);
+                        o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ph[qb][u]), __builtin_bit_cast(f16x8, vh[1][u]), o1[qb], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) store_tile((jt + 1) & 1);       // the other buffer: every wave left it at the barrier that ended tile jt - 1
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const float inv = lsum > 0.f ? 1.0f / (lsum * kPScale * kF16ActScale) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qa = (r & 3) + 8 * (r >> 2);
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), qa + 4));
+            const float sc = h ? s1 : s0;
+            const int q = q0 + 32 * qb + qa + 4 * h;
+            if (q < L) {
+                const int64_t trow = row0 + q;
+                store_planes(ctxp + plane_index(trow, head * 64 + i, rows), c_plane, ns, o0[qb][r] * sc);
+                store_planes(ctxp + plane_index(trow, head * 64 + 32 + i, rows), c_plane, ns, o1[qb][r] * sc);
+            }
+        }
+    }
+}
+
 // exclusive prefix sum of the N document lengths (one wave; N is a batch of passages) + their total
 static __global__ __launch_bounds__(64) void doclens_scan_kernel(const int64_t* __restrict__ doclens, int N,
                                                                  int64_t* __restrict__ start, int64_t* __restrict__ total) {

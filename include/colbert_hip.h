@@ -347,7 +347,9 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
  * layers on the 16-bit matrix pipe, on fp16 planes the Q/K/V projection writes for it (three exact products per fp32
  * product; batches of more than 64 tokens), else fp32 MFMA (all score tiles resident up to 64 keys, online softmax beyond);
  * 1 = fp32 MFMA, register-resident for every length; 2 = the three-kernel path (scores in memory; always taken for other head
- * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode -- 1 to 3 exist for comparison. */
+ * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode; 4 = mode 0 with every wave loading its own K / V tiles instead
+ * of the tiles of a (sequence, head) staged once in LDS for all its query blocks (round 5; bit-identical to 0) -- 1 to 4
+ * exist for comparison. */
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
 /* LayerNorm folded around the Linear layers (f16x3 only): the Linear that produces a LayerNorm's input stores the raw rows and
  * their partial (mean, M2); the Linear that consumes it multiplies the raw rows with gamma (.) W and applies

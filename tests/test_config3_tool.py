@@ -25,7 +25,7 @@ def _tool():
     return mod
 
 
-def _fabricate(tmp_path, n_passages=50, seed=3):
+def _fabricate(tmp_path, n_passages=50, seed=3, word_scale=8.0, pos_scale=0.1):
     """An HF-layout checkpoint directory with colbertv2.0's key names (bert.* + linear.weight), a "pid<TAB>text" collection,
     LoTTE-style questions / qas files (every query is the text of one passage, whose pid is its answer)."""
     torch = pytest.importorskip("torch")
@@ -40,6 +40,10 @@ def _fabricate(tmp_path, n_passages=50, seed=3):
     with torch.no_grad():
         for p in bert.parameters():
             p.mul_(4.0)
+        # a randomly initialised encoder has to be LEXICAL for the retrieval check to mean anything: token identity must
+        # dominate position and marker (a trained ColBERT gets that from its training)
+        bert.embeddings.word_embeddings.weight.mul_(word_scale)
+        bert.embeddings.position_embeddings.weight.mul_(pos_scale)
     state = {"bert." + k: v.detach().float().numpy().copy() for k, v in bert.state_dict().items()}
     state["linear.weight"] = torch.nn.Linear(64, 128, bias=False).weight.detach().numpy().copy()      # colbertv2.0 has no linear.bias
     save_file(state, str(hf / "model.safetensors"))

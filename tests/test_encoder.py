@@ -259,6 +259,12 @@ def test_fused_attention_long_sequences(L):
     alt = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
     enc.close()
     assert np.abs(g16 - alt).transpose(2, 1, 0)[mask].max() < 1e-4
+    # round 5: the K / V tiles of a (sequence, head) staged once in LDS for all its query blocks (the default from 33 tokens
+    # on) against every wave loading its own -- the same products in the same order: identical bits, masked rows included
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_per_wave")
+    per_wave = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+    enc.close()
+    assert np.array_equal(g16.view(np.uint32), per_wave.view(np.uint32))
 
 
 @pytest.mark.gpu
@@ -543,6 +549,11 @@ def test_packed_passage_batches_match_padded_ones(tok):
     assert torch.allclose(a.norm(dim=1), torch.ones(a.shape[0], device=a.device), atol=1e-5)
     some = np.array([3, 4, 20, 36])
     assert float((packed.sample(some) - padded.sample(some)).abs().max()) < 5e-5
+    # packed sequences of different lengths through the LDS-shared K / V tiles == every wave loading its own, bit for bit
+    enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_per_wave")
+    a_pw = EncoderSource(enc_pw, collection, 0, packed=True).encode_pids(order)
+    assert torch.equal(a.view(torch.int32), a_pw.view(torch.int32))
+    enc_pw.close()
     # the host entry point (clb_encode_docs: what the Julia shim calls) packs by itself -- also a mask with holes, whose
     # attended tokens keep their positions; reference: the same call on an encoder that cannot pack (fp32-MFMA attention)
     ref_enc = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_f32")
