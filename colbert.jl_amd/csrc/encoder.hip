@@ -22,8 +22,9 @@ struct clb_encoder {
     int attention_mode = 0;     // 0 = fused: the fp16-plane kernel behind the f16x3 Linear layers (attention_f16_kernel), else
                                 // fp32 MFMA (register-resident up to 64 keys, online softmax beyond); 1 = fp32 register-resident
                                 // for every length, 2 = the three-kernel path (comparison; always taken for head sizes != 64),
-                                // 3 = fused on the fp32 MFMA whatever the GEMM mode (comparison); 4 = as 0, every wave loading its
-                                // own K / V tiles (the round-4 kernel: comparison, bit-identical to 0)
+                                // 3 = fused on the fp32 MFMA whatever the GEMM mode (comparison); 5 = as 0 with the K / V tiles of a
+                                // (sequence, head) staged once in LDS for all its query blocks (round 5: bit-identical to 0 and
+                                // measured SLOWER -- 1.42 -> 1.92 ms per 64 x 300 batch --, kept for comparison)
     int gemm_mode = 3;          // 0 = fp32 MFMA GEMMs, 1 = bf16x3, 2 = bf16x6, 3 = f16x3 (MFMA products of split operands)
     // offsets (in floats) into the blob
     int64_t o_word = 0, o_pos = 0, o_type = 0, o_eg = 0, o_eb = 0, o_layer0 = 0, layer_stride = 0, o_lin_w = 0, o_lin_b = 0;
@@ -45,7 +46,8 @@ struct clb_encoder {
     int64_t v_lin = 0;
     std::vector<float> wscale_f;        // 2 per layer (Q/K/V, FFN-in) + projection
     bool fold_ready = false;
-    int ln_fold = -1;                   // -1: whenever the batch is long enough to run without split-K; 0: never; 1: always (tests)
+    int ln_fold = 0;                    // 0: never (default: measured SLOWER so far, profiles/r05_experiments.md); -1: whenever the batch is
+                                        // long enough to run without split-K; 1: always (tests)
     bool planes = false;        // the Linear layers read pre-split bf16 planes (gemm_planes_kernel); COLBERT_ENCODER_PLANES=0: off
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part, pkeep, prank, scan_tmp;
@@ -265,12 +267,6 @@ bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     return false;
 }
 
-// COLBERT_ENC_ATT_LDS=0: every wave of attention_f16_kernel loads its own K / V tiles (the round-4 kernel) -- comparison runs
-static bool att_lds() {
-    static const bool v = [] { const char* e = getenv("COLBERT_ENC_ATT_LDS"); return !(e && atoi(e) == 0); }();
-    return v;
-}
-
 template <int NS, bool F16>
 bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
@@ -310,7 +306,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // big-tile rule of long activations below, 128 x 128 at least when it produces statistics (a part = two 32-wide tiles
         // of one wave); the narrow projection (N = dim) only consumes: 64 x 64
         const bool wide = N % 4 == 0 && !(epi & EPI_GELU);
-        c = N < 128 ? PlanCfg{64, 64, 2, 1}
+        c = N < 128 && !lf->stats_out ? PlanCfg{64, 64, 2, 1}
             : wide && !att && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
         part = nullptr;
     }
@@ -519,7 +515,7 @@ static inline size_t fold_scale_index(int64_t l, int which /* 0 = Q/K/V (l >= 1)
 static bool can_pack(const clb_encoder* e, int64_t L, int64_t rows_max = 0) {
     const int64_t H = e->H, I = e->I;
     return e->planes && e->gemm_mode == 3 && H % 32 == 0 && I % 32 == 0 && e->heads > 0 && H / e->heads == 64 && L <= 512 &&
-           (e->attention_mode == 0 || e->attention_mode == 4) && !planes_first_form() && rows_max * std::max(H, I) * 6 < ((int64_t)1 << 31);
+           (e->attention_mode == 0 || e->attention_mode == 5) && !planes_first_form() && rows_max * std::max(H, I) * 6 < ((int64_t)1 << 31);
 }
 
 // pk (packed batch): d_ids holds pk->rows token ids, L is the longest sequence, d_mask is unused; needs the fp16-plane attention.
@@ -548,7 +544,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
     const int PF = plane_format(e->gemm_mode);
     if (P && e->wp_fmt != PF) CLB_TRY(split_weights(e, PF));
     // attention on fp16 planes: the Q/K/V projection writes them (second GEMM form, never split over K)
-    const bool att16 = P && PF == PF_F16X2 && fused && (e->attention_mode == 0 || e->attention_mode == 4) && H % 4 == 0 && !planes_first_form();
+    const bool att16 = P && PF == PF_F16X2 && fused && (e->attention_mode == 0 || e->attention_mode == 5) && H % 4 == 0 && !planes_first_form();
     const int64_t ntile = (L + 31) / 32, qk_plane = T * 2 * H, vt_plane = N * heads * ntile * 64 * 32;
     if (pk && !att16)
         return fail(CLB_EARGUMENT, "a packed batch needs the fp16-plane attention (head size 64, f16x3 Linear layers, attention mode 0)");
@@ -622,7 +618,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
             uint16_t* cp_ = P ? ctxp : nullptr;
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
-            if (att16 && L > 32 && att_lds() && e->attention_mode != 4) {
+            if (att16 && L > 32 && e->attention_mode == 5) {
                 // the query blocks of a (sequence, head) share its K / V tiles through LDS (attention_f16_lds_kernel): NW waves
                 // of QB blocks per work-group -- a whole sequence up to 512 tokens at QB = 2; bit-identical to the kernels below
                 const int QB = L >= 128 && att_qb2() ? 2 : 1;
@@ -868,9 +864,9 @@ int clb_encoder_set_ln_fold(clb_encoder* e, int mode) {
 
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
-    if (mode < 0 || mode > 4)
+    if (mode < 0 || mode > 5 || mode == 4)
         return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels, 3 = fused on the fp32 MFMA, "
-                                   "4 = fused without the LDS-shared K / V tiles", mode);
+                                   "5 = fused with the K / V tiles of a (sequence, head) shared through LDS", mode);
     e->attention_mode = mode;
     return CLB_OK;
 }

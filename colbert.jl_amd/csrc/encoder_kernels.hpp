@@ -506,12 +506,20 @@ struct GemmPArgs {
 
 // mean and 1 / sqrt(var + eps) of a row from its partial statistics (equal-width parts): Chan's combination -- the deviations
 // are taken from each part's own mean and the parts' means from the row's, never E[x^2] - mean^2
+constexpr int kLnMaxParts = 16;     // hidden <= 1 024 (64 columns per part)
 __device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int parts, int width, float eps, float& mean, float& rstd) {
+    // all parts requested before the first is used (a rolled load -> add loop is a chain of `parts` memory latencies in front of
+    // every row tile's epilogue: it cost the consuming GEMMs 14 % when it was written that way)
+    f32x2_t sv[kLnMaxParts];
+#pragma unroll
+    for (int p = 0; p < kLnMaxParts; ++p) sv[p] = reinterpret_cast<const f32x2_t*>(st)[p < parts ? p : parts - 1];
     float msum = 0.f, m2 = 0.f;
-    for (int p = 0; p < parts; ++p) msum += st[2 * p];
+#pragma unroll
+    for (int p = 0; p < kLnMaxParts; ++p) if (p < parts) { msum += sv[p][0]; m2 += sv[p][1]; }
     mean = msum / (float)parts;
     float dev = 0.f;
-    for (int p = 0; p < parts; ++p) { const float d = st[2 * p] - mean; m2 += st[2 * p + 1]; dev = fmaf(d, d, dev); }
+#pragma unroll
+    for (int p = 0; p < kLnMaxParts; ++p) if (p < parts) { const float d = sv[p][0] - mean; dev = fmaf(d, d, dev); }
     const float var = (m2 + (float)width * dev) / (float)(parts * width);
     rstd = 1.0f / sqrtf(var + eps);
 }
@@ -970,6 +978,22 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
         float psum = 0.f;                 // ln_out: this lane's sum over the current 64-column part
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
+            // LN kernels: everything the four groups of this 32-column tile read -- the per-column vectors and the residual row --
+            // is requested BEFORE the first group is finished and stored: behind a store the compiler cannot hoist the next
+            // group's loads (the pointers of GemmPArgs may alias), and 32 load -> use -> store rounds per row tile were a chain
+            // of 32 memory latencies (the first fold kernels: +37 ... +55 us per launch)
+            f32x4 pre_b[4], pre_u[4], pre_r[4], pre_g[4], pre_t[4];
+            if (LN && !split) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
+                    const int nn = n < g.N ? n : 0;
+                    if (ln_fold || (g.epi & EPI_BIAS)) pre_b[gq] = *reinterpret_cast<const f32x4*>(g.bias + nn);
+                    if (ln_fold) pre_u[gq] = *reinterpret_cast<const f32x4*>(g.ln_u + nn);
+                    if (g.epi & EPI_RESID) pre_r[gq] = *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + nn);
+                    if (ln_res) { pre_g[gq] = *reinterpret_cast<const f32x4*>(g.r_gamma + nn); pre_t[gq] = *reinterpret_cast<const f32x4*>(g.r_beta + nn); }
+                }
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
@@ -978,19 +1002,15 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                 if (!split) {
                     if (F16) v = v * g.out_scale;
                     if (LN && ln_fold) {
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(g.ln_u + n);
-                        const f32x4 c = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] - ln_mean * u[j], ln_rstd, c[j]);
-                    } else if (g.epi & EPI_BIAS) v = v + *reinterpret_cast<const f32x4*>(g.bias + n);
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] - ln_mean * pre_u[gq][j], ln_rstd, pre_b[gq][j]);
+                    } else if (g.epi & EPI_BIAS) v = v + (LN ? pre_b[gq] : *reinterpret_cast<const f32x4*>(g.bias + n));
                     if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                     if (g.epi & EPI_RESID) {
-                        f32x4 r = *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
+                        f32x4 r = LN ? pre_r[gq] : *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
                         if (LN && ln_res) {
-                            const f32x4 gm = *reinterpret_cast<const f32x4*>(g.r_gamma + n);
-                            const f32x4 bt = *reinterpret_cast<const f32x4*>(g.r_beta + n);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) r[j] = fmaf((r[j] - ln_mean) * ln_rstd, gm[j], bt[j]);
+                            for (int j = 0; j < 4; ++j) r[j] = fmaf((r[j] - ln_mean) * ln_rstd, pre_g[gq][j], pre_t[gq][j]);
                         }
                         v = v + r;
                     }

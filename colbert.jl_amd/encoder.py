@@ -90,7 +90,7 @@ class BertEncoder:
         if self.gemm not in modes:
             raise ValueError(f"gemm must be one of {sorted(modes)}, not {self.gemm!r}")
         check(lib().clb_encoder_set_gemm_mode(self._h, modes[self.gemm]))
-        amodes = {"fused": 0, "resident": 1, "unfused": 2, "fused_f32": 3, "fused_per_wave": 4}     # 1-4: comparison paths (clb_encoder_set_attention_mode)
+        amodes = {"fused": 0, "resident": 1, "unfused": 2, "fused_f32": 3, "fused_lds": 5}     # 1-5: comparison paths (clb_encoder_set_attention_mode)
         if attention not in amodes:
             raise ValueError(f"attention must be one of {sorted(amodes)}, not {attention!r}")
         check(lib().clb_encoder_set_attention_mode(self._h, amodes[attention]))

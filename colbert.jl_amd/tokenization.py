@@ -9,9 +9,30 @@ token is then inserted as the second row (_add_marker_row, tokenizer_utils.jl:14
 REPL outputs recorded in the reference's docstrings (tests/golden/tokenizer_kats.json)."""
 from __future__ import annotations
 
+import os
 from typing import List
 
 import numpy as np
+
+
+def cpu_budget() -> int:
+    """CPUs this process may really use: the cgroup quota (cpu.max) where there is one, else the affinity mask -- a GPU box shows
+    all of the host's cores (128) to a container that is entitled to a fraction of them."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# The HuggingFace tokenizer's thread pool (rayon) sizes itself by the VISIBLE cores when it is first used.  index() runs the
+# tokenizer on a host thread while the main thread prepares and launches the encoder's batches (indexer.EncoderSource): with
+# 128 pool threads on a 16-CPU share the batch preparation starved and the sample phase of a 1 M-passage build took twice as
+# long (24 against 12 s).  The pool gets the CPU budget minus two cores for the threads that feed the device, at most 16.
+os.environ.setdefault("RAYON_NUM_THREADS", str(max(1, min(16, cpu_budget() - 2))))
 
 PUNCTUATION = list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")      # src/indexing.jl:30-31
 

@@ -347,15 +347,16 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode);
  * layers on the 16-bit matrix pipe, on fp16 planes the Q/K/V projection writes for it (three exact products per fp32
  * product; batches of more than 64 tokens), else fp32 MFMA (all score tiles resident up to 64 keys, online softmax beyond);
  * 1 = fp32 MFMA, register-resident for every length; 2 = the three-kernel path (scores in memory; always taken for other head
- * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode; 4 = mode 0 with every wave loading its own K / V tiles instead
- * of the tiles of a (sequence, head) staged once in LDS for all its query blocks (round 5; bit-identical to 0) -- 1 to 4
- * exist for comparison. */
+ * sizes); 3 = mode 0 on the fp32 MFMA whatever the GEMM mode; 5 = mode 0 with the K / V tiles of a (sequence, head) staged once
+ * in LDS for all its query blocks instead of every wave loading its own (round 5: bit-identical to 0, measured slower) --
+ * 1 to 5 exist for comparison. */
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
 /* LayerNorm folded around the Linear layers (f16x3 only): the Linear that produces a LayerNorm's input stores the raw rows and
  * their partial (mean, M2); the Linear that consumes it multiplies the raw rows with gamma (.) W and applies
  * rstd (a . (gamma (.) W)^T - mean u) + c in its epilogue -- no stand-alone LayerNorm pass (48.7 us x 24 per 64 x 300 passage
  * batch).  Same function of the inputs as `doc` (src/modelling/checkpoint.jl:21-25), different rounding.
- * mode: -1 = batches too long to split over K (default: passage batches), 0 = never, 1 = always (tests). */
+ * mode: 0 = never (the default: on a 64 x 300 passage batch the folded epilogues cost more than the LayerNorm pass they
+ * remove, 14.6 against 14.2 ms -- profiles/r05_experiments.md), -1 = batches too long to split over K, 1 = always (tests). */
 int clb_encoder_set_ln_fold(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */

@@ -259,9 +259,9 @@ def test_fused_attention_long_sequences(L):
     alt = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
     enc.close()
     assert np.abs(g16 - alt).transpose(2, 1, 0)[mask].max() < 1e-4
-    # round 5: the K / V tiles of a (sequence, head) staged once in LDS for all its query blocks (the default from 33 tokens
-    # on) against every wave loading its own -- the same products in the same order: identical bits, masked rows included
-    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_per_wave")
+    # round 5: the K / V tiles of a (sequence, head) staged once in LDS for all its query blocks (attention="fused_lds",
+    # from 33 tokens on) against every wave loading its own -- the same products in the same order: identical bits
+    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_lds")
     per_wave = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
     enc.close()
     assert np.array_equal(g16.view(np.uint32), per_wave.view(np.uint32))
@@ -293,6 +293,7 @@ def test_layernorm_folded_around_the_linear_layers(shape):
     mask = np.zeros((N, L), bool)
     for n, l in enumerate(lens):
         mask[n, :l] = True
+    ids0[~mask] = 4                              # padding carries an id of the skiplist below (as [PAD] does): dropped by the epilogue
     with torch.no_grad():
         ref = linear(bert(input_ids=torch.from_numpy(ids0), attention_mask=torch.from_numpy(mask.astype(np.int64))).last_hidden_state).numpy()
     jl_ids, jl_mask = (ids0.T + 1).astype(np.int32), mask.T
@@ -550,7 +551,7 @@ def test_packed_passage_batches_match_padded_ones(tok):
     some = np.array([3, 4, 20, 36])
     assert float((packed.sample(some) - padded.sample(some)).abs().max()) < 5e-5
     # packed sequences of different lengths through the LDS-shared K / V tiles == every wave loading its own, bit for bit
-    enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_per_wave")
+    enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_lds")
     a_pw = EncoderSource(enc_pw, collection, 0, packed=True).encode_pids(order)
     assert torch.equal(a.view(torch.int32), a_pw.view(torch.int32))
     enc_pw.close()
