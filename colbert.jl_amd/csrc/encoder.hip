@@ -46,8 +46,8 @@ struct clb_encoder {
     int64_t v_lin = 0;
     std::vector<float> wscale_f;        // 2 per layer (Q/K/V, FFN-in) + projection
     bool fold_ready = false;
-    int ln_fold = 0;                    // 0: never (default: measured SLOWER so far, profiles/r05_experiments.md); -1: whenever the batch is
-                                        // long enough to run without split-K; 1: always (tests)
+    int ln_fold = -1;                   // -1 (default): whenever the batch is long enough to run without split-K (14.34 -> 13.93 ms per
+                                        // 64 x 300 passage batch, profiles/r05_experiments.md); 0: never; 1: always (tests)
     bool planes = false;        // the Linear layers read pre-split bf16 planes (gemm_planes_kernel); COLBERT_ENCODER_PLANES=0: off
     // workspace
     DevBuf ids, mask, x, qkv, scores, ctx, hbuf, tmp, out, err, qmask, qlens, part, pkeep, prank, scan_tmp;
@@ -251,18 +251,21 @@ struct LnFold {
     float* stats_out = nullptr;
 };
 
-// the LN = true instantiations: big tiles (producer + consumer) and 64 x 64 (consumer only: the projection's 128 columns)
+// the LN instantiations: 1 = consumer (64 x 64 for the projection's 128 columns, 128 x 128 behind GELU, 128 x 256 in front of the
+// attention), 2 = producer (the big plain tiles)
 bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
     const size_t lds = (size_t)c.stages * 2 * (c.bm + c.bn) * 64;
-#define CLB_GPL_CASE(BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                             \
-    if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
-        auto kern = gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, 2, ST_, 0, true, true>;                                 \
+    const int mode = g.ln_u ? 1 : 2;
+#define CLB_GPL_CASE(MODE_, BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                      \
+    if (mode == MODE_ && c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                             \
+        auto kern = gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, 2, ST_, 0, true, MODE_>;                                \
         if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);                        \
         hipLaunchKernelGGL(kern, grid, dim3(64 * WGM_ * WGN_), lds, st, g);                                           \
         return true;                                                                                                  \
     }
-    CLB_GPL_CASE(64, 64, 2, 2, 2, 1, 1) CLB_GPL_CASE(128, 128, 2, 2, 2, 2, 2) CLB_GPL_CASE(128, 256, 2, 2, 4, 2, 2) CLB_GPL_CASE(256, 256, 2, 4, 2, 2, 4)
+    CLB_GPL_CASE(1, 64, 64, 2, 2, 2, 1, 1) CLB_GPL_CASE(1, 128, 128, 2, 2, 2, 2, 2) CLB_GPL_CASE(1, 128, 256, 2, 2, 4, 2, 2)
+    CLB_GPL_CASE(2, 128, 128, 2, 2, 2, 2, 2) CLB_GPL_CASE(2, 128, 256, 2, 2, 4, 2, 2) CLB_GPL_CASE(2, 256, 256, 2, 4, 2, 2, 4)
 #undef CLB_GPL_CASE
     return false;
 }
@@ -307,7 +310,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // of one wave); the narrow projection (N = dim) only consumes: 64 x 64
         const bool wide = N % 4 == 0 && !(epi & EPI_GELU);
         c = N < 128 && !lf->stats_out ? PlanCfg{64, 64, 2, 1}
-            : wide && !att && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+            : wide && !att && !lf->u && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
         part = nullptr;
     }
     else if (const PlanCfg* o = plan_override(role)) c = *o;
@@ -364,7 +367,10 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         if (lf) return launch_planes_ln(st, cc, g);           // PF_F16X2 only (forward() folds in no other mode)
         return fmt == PF_F16X2 ? launch_planes<2, true>(st, cc, g) : NS == 2 ? launch_planes<2, false>(st, cc, g) : launch_planes<3, false>(st, cc, g);
     };
-    if (!go(c)) { c = {64, 64, 2, c.ks}; (void)go(c); }
+    if (!go(c)) {
+        if (lf) { (void)fail(CLB_EUNSUPPORTED, "no LayerNorm-folding GEMM for a %d x %d tile", c.bm, c.bn); return; }
+        c = {64, 64, 2, c.ks}; (void)go(c);
+    }
     if (c.ks > 1) {
         if (ln && N <= 1024) {
             if (N % 4 == 0)

@@ -507,12 +507,9 @@ struct GemmPArgs {
 // mean and 1 / sqrt(var + eps) of a row from its partial statistics (equal-width parts): Chan's combination -- the deviations
 // are taken from each part's own mean and the parts' means from the row's, never E[x^2] - mean^2
 constexpr int kLnMaxParts = 16;     // hidden <= 1 024 (64 columns per part)
-__device__ __forceinline__ void ln_row_stats(const float* __restrict__ st, int parts, int width, float eps, float& mean, float& rstd) {
-    // all parts requested before the first is used (a rolled load -> add loop is a chain of `parts` memory latencies in front of
-    // every row tile's epilogue: it cost the consuming GEMMs 14 % when it was written that way)
-    f32x2_t sv[kLnMaxParts];
-#pragma unroll
-    for (int p = 0; p < kLnMaxParts; ++p) sv[p] = reinterpret_cast<const f32x2_t*>(st)[p < parts ? p : parts - 1];
+// (all parts are requested before the first is used: a rolled load -> add loop is a chain of `parts` memory latencies -- it cost the
+// consuming GEMMs 14 % when it was written that way)
+__device__ __forceinline__ void ln_merge_stats(const f32x2_t* sv /* kLnMaxParts, in registers */, int parts, int width, float eps, float& mean, float& rstd) {
     float msum = 0.f, m2 = 0.f;
 #pragma unroll
     for (int p = 0; p < kLnMaxParts; ++p) if (p < parts) { msum += sv[p][0]; m2 += sv[p][1]; }
@@ -839,7 +836,10 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes_kernel(Gemm
 // in its epilogue (two floats per row from ln_in, two vectors per column); the residual connection, which needs the normalised
 // row itself, normalises the raw fp32 row it reads anyway (r_gamma / r_beta).  The flags are run-time (GemmPArgs) so that one
 // instantiation per tile serves producer, consumer and both.
-template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false, bool LN = false>
+// LN = 1: the consuming side (ln_u / ln_in); LN = 2: the producing side (stats_out, and r_gamma / r_beta / ln_in for its residual).
+// In both the statistics of the lane's rows are requested BEFORE the operand DMAs of the prologue and merged behind them (their
+// latency hides under the first tile's), and the consumer loads the two column vectors of all its columns in one batch.
+template <int WGM, int WGN, int WM, int WN, int NS, int STAGES, int ABL = 0, bool F16 = false, int LN = 0>
 static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(GemmPArgs g) {
     static_assert(!F16 || NS == 2, "the fp16 split has two planes");
     constexpr int PFMT = F16 ? PF_F16X2 : (NS == 3 ? PF_BF16X3 : PF_BF16X2);
@@ -897,9 +897,31 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int nsteps = K_ / 32;
+    // LN: (mean, 1 / sqrt(var + eps)) of the rows this lane finishes -- A's rows (consumer) or the residual's (producer): the
+    // partial statistics are requested here, in front of the prologue's DMAs (vector memory operations complete in order, so
+    // the first tile's wait covers them), and merged right behind the DMAs' issue
+    float ln_mean_[WM], ln_rstd_[WM];
+    f32x2_t ln_sv[LN ? WM : 1][LN ? kLnMaxParts : 1];
+    const bool ln_rows = LN != 0 && !split && g.ln_in != nullptr && (g.ln_u != nullptr || g.r_gamma != nullptr);
+    if (LN != 0 && ln_rows) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            int m = m0 + (wr * WM + a) * 32 + i;
+            m = m < g.M ? m : g.M - 1;
+            const f32x2_t* st = reinterpret_cast<const f32x2_t*>(g.ln_in + (int64_t)m * g.ln_parts * 2);
+#pragma unroll
+            for (int p = 0; p < kLnMaxParts; ++p) ln_sv[a][p] = st[p < g.ln_parts ? p : g.ln_parts - 1];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < STAGES; ++s)
         if (s < nsteps) CLB_GP2_ISSUE(s, s)
+#pragma unroll
+    for (int a = 0; a < WM; ++a) { ln_mean_[a] = 0.f; ln_rstd_[a] = 1.f; }
+    if (LN != 0 && ln_rows) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a) ln_merge_stats(ln_sv[LN ? a : 0], g.ln_parts, g.ln_width, g.ln_eps, ln_mean_[a], ln_rstd_[a]);
+    }
     const int sw = (i >> 2) & 3;
     const unsigned char* As0 = gplds + (wr * 32 * WM + i) * 64;
     const unsigned char* Bs0 = gplds + NS * PA + (wc * 32 * WN + i) * 64;
@@ -960,9 +982,23 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
     // D' layout: column (lane & 31) = m, row (r & 3) + 8 * (r >> 2) + 4 * h = n: four consecutive n per register group
     const bool qkv_att = F16 && !split && (g.epi & EPI_QKV_ATT);
     const int att_nt = qkv_att ? (g.att_L + 31) >> 5 : 0;
-    const bool ln_fold = LN && !split && g.ln_u != nullptr;           // the A rows are raw: fold their LayerNorm into this product
-    const bool ln_res = LN && !split && g.r_gamma != nullptr;         // the residual rows are raw: normalise them on the fly
-    const bool ln_out = LN && !split && g.stats_out != nullptr;       // leave the partial statistics of the output rows
+    const bool ln_fold = LN == 1 && !split && g.ln_u != nullptr;      // the A rows are raw: fold their LayerNorm into this product
+    const bool ln_res = LN == 2 && !split && g.r_gamma != nullptr;    // the residual rows are raw: normalise them on the fly
+    const bool ln_out = LN == 2 && !split && g.stats_out != nullptr;  // leave the partial statistics of the output rows
+    // consumer: u and c of ALL the lane's columns in one batch (they do not depend on the row: one exposed round trip per tile,
+    // what the plain kernel pays for its bias)
+    f32x4 col_u[LN == 1 ? WN : 1][4], col_c[LN == 1 ? WN : 1][4];
+    if (LN == 1 && ln_fold) {
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
+                const int nn = n < g.N ? n : 0;
+                col_u[b][gq] = *reinterpret_cast<const f32x4*>(g.ln_u + nn);
+                col_c[b][gq] = *reinterpret_cast<const f32x4*>(g.bias + nn);
+            }
+    }
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
         const int m = m0 + (wr * WM + a) * 32 + i;
@@ -973,8 +1009,7 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
             const uint32_t seq = g.att_seq ? (uint32_t)g.att_seq[m] : (uint32_t)m / (uint32_t)g.att_L;
             vrow = vt_index(seq, 0, g.att_heads, att_nt, g.att_pos ? g.att_pos[m] : m - (int)seq * g.att_L, 0);
         }
-        float ln_mean = 0.f, ln_rstd = 1.f;
-        if (LN && (ln_fold || ln_res)) ln_row_stats(g.ln_in + (int64_t)m * g.ln_parts * 2, g.ln_parts, g.ln_width, g.ln_eps, ln_mean, ln_rstd);
+        const float ln_mean = ln_mean_[a], ln_rstd = ln_rstd_[a];
         float psum = 0.f;                 // ln_out: this lane's sum over the current 64-column part
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
@@ -982,14 +1017,13 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
             // is requested BEFORE the first group is finished and stored: behind a store the compiler cannot hoist the next
             // group's loads (the pointers of GemmPArgs may alias), and 32 load -> use -> store rounds per row tile were a chain
             // of 32 memory latencies (the first fold kernels: +37 ... +55 us per launch)
-            f32x4 pre_b[4], pre_u[4], pre_r[4], pre_g[4], pre_t[4];
-            if (LN && !split) {
+            f32x4 pre_b[LN == 2 ? 4 : 1], pre_r[LN == 2 ? 4 : 1], pre_g[LN == 2 ? 4 : 1], pre_t[LN == 2 ? 4 : 1];
+            if (LN == 2 && !split) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int n = n0 + (wc * WN + b) * 32 + 8 * gq + 4 * h;
                     const int nn = n < g.N ? n : 0;
-                    if (ln_fold || (g.epi & EPI_BIAS)) pre_b[gq] = *reinterpret_cast<const f32x4*>(g.bias + nn);
-                    if (ln_fold) pre_u[gq] = *reinterpret_cast<const f32x4*>(g.ln_u + nn);
+                    if (g.epi & EPI_BIAS) pre_b[gq] = *reinterpret_cast<const f32x4*>(g.bias + nn);
                     if (g.epi & EPI_RESID) pre_r[gq] = *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + nn);
                     if (ln_res) { pre_g[gq] = *reinterpret_cast<const f32x4*>(g.r_gamma + nn); pre_t[gq] = *reinterpret_cast<const f32x4*>(g.r_beta + nn); }
                 }
@@ -1001,14 +1035,14 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                 f32x4 v = {acc[a][b][4 * gq], acc[a][b][4 * gq + 1], acc[a][b][4 * gq + 2], acc[a][b][4 * gq + 3]};
                 if (!split) {
                     if (F16) v = v * g.out_scale;
-                    if (LN && ln_fold) {
+                    if (LN == 1 && ln_fold) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] - ln_mean * pre_u[gq][j], ln_rstd, pre_b[gq][j]);
-                    } else if (g.epi & EPI_BIAS) v = v + (LN ? pre_b[gq] : *reinterpret_cast<const f32x4*>(g.bias + n));
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] - ln_mean * col_u[b][gq][j], ln_rstd, col_c[b][gq][j]);
+                    } else if (g.epi & EPI_BIAS) v = v + (LN == 2 ? pre_b[gq] : *reinterpret_cast<const f32x4*>(g.bias + n));
                     if (g.epi & EPI_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                     if (g.epi & EPI_RESID) {
-                        f32x4 r = LN ? pre_r[gq] : *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
-                        if (LN && ln_res) {
+                        f32x4 r = LN == 2 ? pre_r[gq] : *reinterpret_cast<const f32x4*>(g.R + (int64_t)m * g.ldc + n);
+                        if (LN == 2 && ln_res) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) r[j] = fmaf((r[j] - ln_mean) * ln_rstd, pre_g[gq][j], pre_t[gq][j]);
                         }
@@ -1028,16 +1062,16 @@ static __global__ __launch_bounds__(64 * WGM * WGN) void gemm_planes2_kernel(Gem
                             }
                         }
                     } else if (g.Cp) store_planes4(g.Cp + plane_index(m, n, g.M), g.c_plane, PFMT, v);
-                    if (LN && ln_out) {   // keep the finished values for the second (deviation) sweep
+                    if (LN == 2 && ln_out) {   // keep the finished values for the second (deviation) sweep
                         acc[a][b][4 * gq] = v[0]; acc[a][b][4 * gq + 1] = v[1]; acc[a][b][4 * gq + 2] = v[2]; acc[a][b][4 * gq + 3] = v[3];
                         psum += (v[0] + v[1]) + (v[2] + v[3]);
                     }
                 }
                 if (C) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + n) = v;
             }
-            if (LN && ln_out && (b & 1)) {
+            if (LN == 2 && ln_out && (b & 1)) {
                 // part = the 64 columns of tiles b - 1, b: 32 values here, 32 in lane i of the other half (same row m)
-                static_assert(!LN || WN % 2 == 0 || WN == 1, "a 64-column part is two adjacent 32-column tiles of one wave");
+                static_assert(LN != 2 || WN % 2 == 0, "a 64-column part is two adjacent 32-column tiles of one wave");
                 const float mean = (psum + __shfl_xor(psum, 32, 64)) * (1.0f / 64.0f);
                 float q = 0.f;
 #pragma unroll

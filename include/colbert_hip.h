@@ -355,8 +355,8 @@ int clb_encoder_set_attention_mode(clb_encoder* e, int mode);
  * their partial (mean, M2); the Linear that consumes it multiplies the raw rows with gamma (.) W and applies
  * rstd (a . (gamma (.) W)^T - mean u) + c in its epilogue -- no stand-alone LayerNorm pass (48.7 us x 24 per 64 x 300 passage
  * batch).  Same function of the inputs as `doc` (src/modelling/checkpoint.jl:21-25), different rounding.
- * mode: 0 = never (the default: on a 64 x 300 passage batch the folded epilogues cost more than the LayerNorm pass they
- * remove, 14.6 against 14.2 ms -- profiles/r05_experiments.md), -1 = batches too long to split over K, 1 = always (tests). */
+ * mode: -1 = batches too long to split over K (the default: a 64 x 300 passage batch 14.34 -> 13.93 ms,
+ * profiles/r05_experiments.md), 0 = never, 1 = always (tests). */
 int clb_encoder_set_ln_fold(clb_encoder* e, int mode);
 /* doc(bert, linear, integer_ids, bitmask)  (checkpoint.jl:21-25): integer_ids Int32 (L, N), 1-based token ids;
  * bitmask (L, N) 0/1 bytes = attention (key) mask; out Float32 (dim, L, N). */
