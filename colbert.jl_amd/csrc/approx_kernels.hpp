@@ -179,7 +179,10 @@ static __global__ void pack_code_inv_kernel(const uint32_t* __restrict__ codes0,
 // -------------------------------------------------------------------------------------------------------------
 constexpr int kRowBytes16 = 272;   // staged bf16 row: 256 B + 16 B pad -> conflict-free ds_read_b128 per 16-lane group
 constexpr int kTopPartial = 4;     // per-lane list length in the bf16x3 kernel
-constexpr int kTopRefine = 4;      // groups of 16 centroids re-scored exactly per token (one per 16 lanes)
+constexpr int kTopRefine = 4;      // groups of 16 centroids re-scored exactly per ROUND of the refine wave (one per 16 lanes)
+constexpr int kTopRefineCap = 256; // qualifying groups a token may have before the wave scans all K centroids (round 5: was
+                                   // kTopRefine -- on an index with near-degenerate centroids, what a random-weight encoder
+                                   // gives, five qualifying groups already cost a ~2-ms scan per token)
 
 static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
                                          uint16_t* __restrict__ lo, int64_t n) {
@@ -740,7 +743,7 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
         return;
     }
     __shared__ float qs[kDim];
-    __shared__ ValIdx cand[kTopRefine];
+    __shared__ ValIdx cand[kTopRefineCap];
     const float* q = Q + ((size_t)b * T + t) * kDim;
     qs[lane] = q[lane];
     qs[lane + 64] = q[lane + 64];
@@ -809,19 +812,20 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
             const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
             if (m == 0) break;                                   // sorted lists: later entries are smaller
             const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-            if (take && pos < kTopRefine) cand[pos] = ValIdx{v[e], id[e]};
+            if (take && pos < kTopRefineCap) cand[pos] = ValIdx{v[e], id[e]};
             total += __popcll(m);
         }
     }
     __syncthreads();
     // a list holds more than kTopPartial groups' worth of history only if the lane saw that many tiles
-    const bool overflow = total > kTopRefine || last_max >= thr;
+    const bool overflow = total > kTopRefineCap || last_max >= thr;
     float tv[2] = {kNegInf, kNegInf};
     int ti[2] = {0x7fffffff, 0x7fffffff};
     if (!overflow) {
         // 16 lanes per qualifying group: lane (grp, rr) re-scores centroid rr of group grp with the chain the fp32
-        // MFMA kernel performs
-        const int grp = lane >> 4, rr = lane & 15;
+        // MFMA kernel performs; kTopRefine groups per round (normally one round: two groups qualify)
+        for (int g0 = 0; g0 < total; g0 += kTopRefine) {
+        const int grp = g0 + (lane >> 4), rr = lane & 15;
         const int gid = grp < total ? cand[grp].i : 0;
         const int id = (gid >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (gid & 1);
         if (grp < total && id < K) {
@@ -838,6 +842,7 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
                 a = fmaf(cr[m].w, qs[4 * m + 3], a);
             }
             topn_insert<2>(tv, ti, a, id);
+        }
         }
     } else {
         for (int c = lane; c < K; c += 64) {
