@@ -610,6 +610,16 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int p = 0; p < kTopPartial; ++p) { bv0[p] = bv1[p] = kNegInf; bi0[p] = bi1[p] = 0x7fffffff; }
     // 48 MFMAs: the staged tile against this wave's two queries
+    // (-DCLB_ABL_CENTROID_X1, tuning builds only: ONE product per fp32 product -- what a single-fp16-product table would cost)
+#ifdef CLB_ABL_CENTROID_X1
+#define CLB_TM_LO_PRODUCTS(S)      /* (the lo plane is still loaded and staged: an upper bound of the single-product kernel's time) */
+#else
+#define CLB_TM_LO_PRODUCTS(S)                                                                             \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[0][S]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[1][S]), acc1, 0, 0, 0); \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][S]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][S]), acc1, 0, 0, 0);
+#endif
 #define CLB_TM_STORE(DATA, ADDR) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ADDR), "v"(DATA));
 #define CLB_TM_MFMA(MY)                                                                                   \
     {                                                                                                     \
@@ -617,10 +627,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                   \
             const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + i * kRowBytes16 + 16 * (8 * h + s)));        \
             const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + (32 + i) * kRowBytes16 + 16 * (8 * h + s))); \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][s]), acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][s]), acc1, 0, 0, 0); \
+            CLB_TM_LO_PRODUCTS(s)                                                                         \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
             /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue) */            \
@@ -707,6 +714,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #undef CLB_TM_LOAD
 #undef CLB_TM_WAIT
 #undef CLB_TM_MFMA
+#undef CLB_TM_LO_PRODUCTS
 #undef CLB_TM_STORE
 #undef CLB_TM_EPI
     const int slot = blockIdx.x * 2 + h;
