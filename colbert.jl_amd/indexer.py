@@ -280,14 +280,60 @@ class EncoderSource(DeviceEmbeddingSource):
                 ids = np.asarray(e.ids[:self._maxlen - 1], dtype=np.int32) + 1
                 self._tokens[p] = np.concatenate([ids[:1], [self._marker], ids[1:]]).astype(np.int32)
 
+    def _tokenize_in_worker_process(self, pids):
+        """The passages `pids` through colbert.jl_amd/_tok_worker.py (a child process: the conversion loop of _tokenize holds the
+        interpreter lock, and on a thread it starved the thread that feeds the device).  This thread only moves bytes -- pipe
+        reads and writes release the lock.  Falls back to _tokenize in this thread if the worker cannot be started or dies."""
+        import struct
+        import subprocess
+        import sys
+        tok = self.encoder.tokenizer
+        vocab_file = getattr(tok, "vocab_file", None)
+        done = 0
+        proc = None
+        try:
+            if vocab_file is None or os.environ.get("COLBERT_TOKENIZER_PROCESS", "1") == "0":
+                raise OSError("no vocabulary file to hand to a worker process")
+            worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tok_worker.py")
+            proc = subprocess.Popen([sys.executable, worker, vocab_file, "1" if getattr(tok, "lowercase", True) else "0",
+                                     str(self._maxlen), str(int(self._marker))], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+
+            def read_exact(n):
+                buf = proc.stdout.read(n)
+                if len(buf) != n:
+                    raise OSError("tokenizer worker closed its pipe")
+                return buf
+            for start in range(0, len(pids), 8192):
+                part = pids[start:start + 8192]
+                enc = [self.collection[p].encode("utf-8") for p in part]
+                proc.stdin.write(struct.pack("<II", len(part), sum(len(b) for b in enc)))
+                proc.stdin.write(np.array([len(b) for b in enc], dtype=np.uint32).tobytes())
+                proc.stdin.write(b"".join(enc))
+                proc.stdin.flush()
+                n, ntok = struct.unpack("<II", read_exact(8))
+                toklen = np.frombuffer(read_exact(4 * n), dtype=np.int32)
+                flat = np.frombuffer(read_exact(4 * ntok), dtype=np.int32)
+                assert n == len(part) and int(toklen.sum()) == ntok
+                off = np.concatenate([[0], np.cumsum(toklen)])
+                for j, p in enumerate(part):
+                    self._tokens[p] = flat[off[j]:off[j + 1]]
+                done = start + len(part)
+            proc.stdin.close()
+            proc.wait(timeout=30)
+        except (OSError, AssertionError, ValueError, subprocess.SubprocessError):
+            if proc is not None:
+                proc.kill()
+            self._tokenize(pids[done:])
+
     def prepare_sample(self, pids):
-        """Tokenise the passages `pids` now and everything else on a background thread."""
+        """Tokenise the passages `pids` now and everything else in the background (a worker process fed by a thread)."""
         import threading
         if not self.lazy or self._doclens is not None or self._worker is not None:
             return                       # everything is (being) tokenised already
         self._tokenize(int(p) for p in pids)
         done = set(int(p) for p in pids)
-        self._worker = threading.Thread(target=self._tokenize, args=([p for p in range(self.n_docs) if p not in done],), daemon=True)
+        self._worker = threading.Thread(target=self._tokenize_in_worker_process, args=([p for p in range(self.n_docs) if p not in done],),
+                                        daemon=True)
         self._worker.start()
 
     def _doclens_of(self, pids):

@@ -40,6 +40,7 @@ PUNCTUATION = list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")      # src/indexing.jl:
 class WordPieceTokenizer:
     def __init__(self, vocab_file: str, lowercase: bool = True):
         from tokenizers import BertWordPieceTokenizer
+        self.vocab_file, self.lowercase = vocab_file, lowercase       # (a worker process rebuilds the tokenizer from these)
         self.tok = BertWordPieceTokenizer(vocab_file, lowercase=lowercase)
         self.vocab = self.tok.get_vocab()
 

@@ -95,6 +95,39 @@ def test_tensorize_queries(tok):
     assert mask2.all()
 
 
+def test_tokenizer_worker_process_matches_in_process(tok):
+    """index()'s device route tokenises the passages outside the clustering sample in a worker PROCESS
+    (colbert.jl_amd/_tok_worker.py: the conversion loop holds the interpreter lock and starved the thread feeding the device
+    when it ran on a thread): the same token arrays as the in-process tokenizer, and the in-process path when the worker is
+    switched off.  CPU only -- the worker never touches the GPU."""
+    from colbert_jl_amd import indexer
+    rng = np.random.default_rng(0)
+    words = ["hello", "world", "this", "is", "a", "test", "of", "the", "tokenizer", "longer", "passage", "with"]
+    coll = [" ".join(rng.choice(words, size=rng.integers(1, 30))) + rng.choice([".", "!", ""]) for _ in range(9000)]
+    coll[17] = "h\u00e9llo w\u00f6rld \u2014 caf\u00e9"                     # multi-byte text: lengths are byte lengths on the pipe
+
+    class Enc:
+        pass
+    src = indexer.EncoderSource.__new__(indexer.EncoderSource)
+    src.encoder = Enc(); src.encoder.tokenizer = tok
+    src.collection, src.n_docs, src._maxlen = coll, len(coll), 16
+    src._marker = np.int32(tok.lookup("[unused1]"))
+    src._tokens = [None] * len(coll)
+    src._tokenize(range(len(coll)))
+    want = [t.copy() for t in src._tokens]
+    assert max(t.size for t in want) == 16 and want[0][1] == src._marker
+    src._tokens = [None] * len(coll)
+    src._tokenize_in_worker_process(list(range(len(coll))))
+    assert all(np.array_equal(a, b) for a, b in zip(want, src._tokens))
+    os.environ["COLBERT_TOKENIZER_PROCESS"] = "0"
+    try:
+        src._tokens = [None] * len(coll)
+        src._tokenize_in_worker_process(list(range(len(coll))))
+        assert all(np.array_equal(a, b) for a, b in zip(want, src._tokens))
+    finally:
+        del os.environ["COLBERT_TOKENIZER_PROCESS"]
+
+
 # ---------------------------------------------------------------------------------------------------------
 def _random_bert(hidden=64, layers=2, heads=4, inter=128, vocab=120, max_pos=48, dim=32, seed=0):
     torch = pytest.importorskip("torch")
