@@ -291,6 +291,26 @@ bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     return false;
 }
 
+// The tile of a long-activation Linear (passage batches), among 256 x 256 (eight waves, one work-group per CU), 128 x 256 (four
+// waves, one per CU) and 128 x 128 (two work-groups per CU): the one with the smallest  rounds x work-groups-per-CU x tile area x
+// cost-per-flop  -- ROUNDS matter as much as the tile: a 22 386-row packed batch gives a 768-wide output 264 tiles of 256 x 256,
+// one more than eight per XCD... 1.03 rounds that take two (measured: FFN-out 5.95 ms per batch against 3.45 at 19 200 rows, where
+// 225 tiles fit one round).  Cost per flop relative to 256 x 256 from the round-4 sweeps (half / a quarter of the operand reuse).
+static PlanCfg pick_long_tile(int M, int N, bool allow_256, bool allow_128x256) {
+    struct Cand { int bm, bn, per_cu; double cost; bool ok; };
+    const Cand cands[3] = {{256, 256, 1, 1.00, allow_256}, {128, 256, 1, 1.04, allow_128x256}, {128, 128, 2, 1.09, true}};
+    PlanCfg best{128, 128, 2, 1};
+    double best_t = 1e300;
+    for (const Cand& c : cands) {
+        if (!c.ok) continue;
+        const int64_t tiles = (int64_t)((N + c.bn - 1) / c.bn) * ((M + c.bm - 1) / c.bm);
+        const int64_t rounds = (tiles + 256 * c.per_cu - 1) / (256 * c.per_cu);
+        const double t = (double)rounds * c.per_cu * c.bm * c.bn * c.cost;
+        if (t < best_t) { best_t = t; best = PlanCfg{c.bm, c.bn, 2, 1}; }
+    }
+    return best;
+}
+
 // A planes (M x K) . W planes (N x K)^T -> C fp32 and / or Cp planes, epilogue bias / GELU / residual, optional LayerNorm
 // of the output (then both C and, if given, Cp hold the normalised rows).  part: split-K scratch (8 * M * N floats) or null.
 inline int plane_format(int gemm_mode) { return gemm_mode == 3 ? PF_F16X2 : gemm_mode == 1 ? PF_BF16X2 : PF_BF16X3; }
@@ -310,7 +330,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // of one wave); the narrow projection (N = dim) only consumes: 64 x 64
         const bool wide = N % 4 == 0 && !(epi & EPI_GELU);
         c = N < 128 && !lf->stats_out ? PlanCfg{64, 64, 2, 1}
-            : wide && !att && !lf->u && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+            : wgs(128, 128) >= 256 ? pick_long_tile(M, N, wide && !att && !lf->u, wide) : PlanCfg{128, 128, 2, 1};
         part = nullptr;
     }
     else if (const PlanCfg* o = plan_override(role)) c = *o;
@@ -331,7 +351,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // epilogue with the other's loop, a single large one cannot (FFN-in of 64 x 300 passages: 322 against 358 us)
         {
             const bool wide = NS == 2 && N % 4 == 0 && !(epi & EPI_GELU) && !planes_first_form();
-            c = wide && !att && wgs(256, 256) >= 200 ? PlanCfg{256, 256, 2, 1} : wide && wgs(128, 256) >= 384 ? PlanCfg{128, 256, 2, 1} : PlanCfg{128, 128, 2, 1};
+            c = pick_long_tile(M, N, wide && !att, wide);
         }
     else {
         // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured

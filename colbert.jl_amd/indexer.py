@@ -249,6 +249,10 @@ class EncoderSource(DeviceEmbeddingSource):
         import torch
         self.packed = packed          # batches without padding rows (clb_encode_docs_packed_device) where the encoder can
         self.pack_batches = int(os.environ.get("COLBERT_PACK_BATCHES", pack_batches))
+        # packed calls are filled by ROWS, not by passages: 170 row tiles of 256 = 43 520 rows give the 768-wide outputs 510 tiles
+        # of 256 x 256 -- two full rounds of the 256 CUs -- and the wide ones 5.98 / 7.97 x 2 rounds (a 256-passage call of
+        # ~22 390 rows left 8 of 264 tiles for a second round: 0.79 us per row against 0.65)
+        self.pack_rows = int(os.environ.get("COLBERT_PACK_ROWS", 170 * 256))
         self.encoder = encoder
         self.collection = collection
         self.n_docs = len(collection)
@@ -408,20 +412,51 @@ class EncoderSource(DeviceEmbeddingSource):
         # batch keeps follows from its tokens alone), no concatenation afterwards
         expected = self._expected(pids)
         out = torch.empty((int(expected.sum()), self.dim), dtype=torch.float32, device=self.device)
-        lens, fill = [], 0
-        for start in range(0, pids.size, bs):
-            batch = pids[start:start + bs]
-            n_b = int(expected[start:start + bs].sum())
+        lens, fill, first = [], 0, 0
+        # whether the encoder packs at all is learnt from the first call's first batch (a fixed number of passages): if it does not,
+        # every batch is a padded batch of index_bsize passages counted from the first one -- the batches of the host route
+        if self.packed and not getattr(self, "_pack_checked", False):
+            n0 = min(bs, pids.size)
+            n_b0 = int(expected[:n0].sum())
+            dl = self._encode_packed(pids[:n0], out[:n_b0], n_b0)
+            self._pack_checked = True
+            if dl is not None:
+                lens.append(dl); fill, first = n_b0, n0
+        # batch boundaries: fixed passage counts when padding; a ROW budget when packing (see pack_rows)
+        if self.packed and self.pack_rows > 0:
+            ntok = np.fromiter((self._tokens[int(p)].size for p in pids), dtype=np.int64, count=pids.size)
+            cum = np.cumsum(ntok)
+            starts, s0 = [first], first
+            while s0 < pids.size:
+                nxt = int(np.searchsorted(cum, (cum[s0 - 1] if s0 else 0) + self.pack_rows, side="right"))
+                nxt = max(nxt, s0 + 1)
+                if nxt >= pids.size:
+                    break
+                starts.append(nxt); s0 = nxt
+            bounds = [(a, b) for a, b in zip(starts, starts[1:] + [pids.size]) if a < b]
+        else:
+            step0 = bs if self.packed else self.encoder.config.index_bsize
+            bounds = [(a, min(pids.size, a + step0)) for a in range(first, pids.size, step0)]
+        for start, stop in bounds:
+            batch = pids[start:stop]
+            n_b = int(expected[start:stop].sum())
             dst = out[fill:fill + n_b]
             dl = None
             if self.packed:
                 dl = self._encode_packed(batch, dst, n_b)
-            if dl is None:
-                ids, mask = self._tensorize(batch)
+            if dl is not None:
+                lens.append(dl); fill += n_b
+                continue
+            # padded batches of index_bsize passages (the encoder cannot pack; a row-budget batch is cut down to that size)
+            step = self.encoder.config.index_bsize
+            for a in range(start, stop, step):
+                sub = pids[a:min(stop, a + step)]
+                n_s = int(expected[a:min(stop, a + step)].sum())
+                ids, mask = self._tensorize(sub)
                 d_ids = torch.from_numpy(ids).to(self.device)
                 d_mask = torch.from_numpy(mask).to(self.device)
-                _, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=n_b, out=dst)
-            lens.append(dl); fill += n_b
+                _, dl = self.encoder.doc_embeddings_device(d_ids, d_mask, self._d_skip, n_out=n_s, out=out[fill:fill + n_s])
+                lens.append(dl); fill += n_s
         self.encoder.check_last_ids()
         assert np.array_equal(torch.cat(lens).cpu().numpy(), expected)
         return out
