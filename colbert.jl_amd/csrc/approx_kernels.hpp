@@ -195,6 +195,34 @@ static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* 
     lo[i] = (uint16_t)f32_to_bf16_rne(rem);
 }
 
+// Round 5, "f16x1": the score table of the batched centroid stage from ONE fp16 product per fp32 product.  The table is stored
+// as fp16 anyway (relative rounding 2^-11: 4.9e-4 |score|, the largest term of e_cells), so the three-product bf16 split
+// (7.4e-5 qn cn) buys the TABLE nothing; what the product must not lose is bounded by the measured conversion errors:
+//   |Q.c - Q'.c'| <= ||Q - Q'|| ||c'|| + ||Q|| ||c - c'||  =  dq * cn16 + qn * dc      (Q', c' the fp16-rounded operands;
+// their products are exact in fp32, the accumulation adds 2*128*u*qn*cn) -- dq per query (select_margin_kernel measures it
+// for pass 1's operand already), dc = max_c ||c - fp16(c)|| per index (max_row_f16_err_kernel).  A third of the MFMAs:
+// centroid_top_bf16x3_teams_kernel<true>, 0.110 -> 0.090 ms per 32 queries x 131 072 centroids even with the lo plane still staged.
+static __global__ void to_f16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const __half h = __float2half_rn(x[i]);
+    out[i] = *reinterpret_cast<const uint16_t*>(&h);
+}
+// max over the rows of ||c - fp16(c)|| (a component beyond the fp16 range makes it infinite: such an index is searched exactly)
+static __global__ __launch_bounds__(256) void max_row_f16_err_kernel(const float* __restrict__ C, int K, unsigned int* __restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < K; c += gridDim.x * 4) {
+        const float a = C[(size_t)c * kDim + lane], b = C[(size_t)c * kDim + 64 + lane];
+        const float da = fabsf(a) < 6.0e4f ? a - round_f16(a) : __builtin_inff(), db = fabsf(b) < 6.0e4f ? b - round_f16(b) : __builtin_inff();
+        float q = da * da + db * db;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        m = fmaxf(m, sqrtf(q) * 1.0001f);
+    }
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
 // Insert into a lane's descending list of approximate scores.  Ordering is by value only: which of several EQUAL
 // approximate scores survives at the end of a list is irrelevant, because top_refine_kernel re-scores everything above
 // its cut and treats a list whose last entry reaches the cut as overflowed.  Branch-free shift (3 compares, 14
@@ -557,7 +585,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // hardware bf16 split of the query operands.
 // grid = (gx, ceil(B / 16)), block = 512, LDS = 2 buffers * 2 arrays * 32 rows * 272 B + 8 waves * 4 KB (66 KB).
 constexpr int kTeamQueries = 16;
+typedef _Float16 f16x8_c __attribute__((ext_vector_type(8)));
 
+// X1 = true (round 5, "f16x1"): Chi is the fp16 table, Clo is not read -- one v_mfma_f32_32x32x16_f16 per 16 dims and query
+// instead of three bf16 ones (see to_f16_kernel); one tile load per stage (the hand-counted waits stay: behind it are still
+// exactly the four stores of an MFMA phase).  Same tiles, lists, table layout and stores.
+template <bool X1>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_teams_kernel(
     const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
     ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles) {
@@ -570,21 +603,22 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // the kernel above: every epilogue issues exactly four stores, so the two loads of a tile have landed once at most
     // four younger vector-memory operations are outstanding
     const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
-    u32x4 ph, pl;
+    u32x4 ph, pl = {0u, 0u, 0u, 0u};
 #define CLB_TM_LOAD(TL)                                                                                   \
     {                                                                                                     \
         int c_ = (TL) * 32 + prow;                                                                        \
         c_ = c_ < K ? c_ : K - 1;                                                                         \
         const uint16_t* a0_ = Chi + (size_t)c_ * kDim + 8 * pchunk;                                       \
         const uint16_t* a1_ = Clo + (size_t)c_ * kDim + 8 * pchunk;                                       \
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"                 \
+        if (X1) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ph) : "v"(a0_) : "memory");        \
+        else asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"            \
                      : "=&v"(ph), "=&v"(pl) : "v"(a0_), "v"(a1_) : "memory");                             \
     }
 #define CLB_TM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ph), "+v"(pl) :: "memory");
     // the first tile is requested before the query operands are split
     int tile = blockIdx.x, buf = 0;
     CLB_TM_LOAD(tile < n_tiles ? tile : n_tiles - 1)
-    u32x4 qh[2][8], ql[2][8];
+    u32x4 qh[2][8], ql[2][X1 ? 1 : 8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int b = bq0 + q < B ? bq0 + q : B - 1;      // past the batch: a duplicate whose results are dropped
@@ -598,11 +632,12 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
             uint32_t hh[4], ll[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                split_bf16_pair(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+                if (X1) { hh[j] = pack_f16(v[2 * j], v[2 * j + 1]); ll[j] = 0u; }
+                else split_bf16_pair(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
                 if (i >= T) { hh[j] = 0u; ll[j] = 0u; }      // tokens past T: zero operand rows
             }
             qh[q][s] = u32x4{hh[0], hh[1], hh[2], hh[3]};
-            ql[q][s] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+            ql[q][X1 ? 0 : s] = u32x4{ll[0], ll[1], ll[2], ll[3]};
         }
     }
     float bv0[kTopPartial], bv1[kTopPartial];
@@ -617,19 +652,25 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #define CLB_TM_LO_PRODUCTS(S)                                                                             \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[0][S]), acc0, 0, 0, 0); \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, qh[1][S]), acc1, 0, 0, 0); \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][S]), acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][S]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[0][X1 ? 0 : S]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, ql[1][X1 ? 0 : S]), acc1, 0, 0, 0);
 #endif
 #define CLB_TM_STORE(DATA, ADDR) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ADDR), "v"(DATA));
 #define CLB_TM_MFMA(MY)                                                                                   \
     {                                                                                                     \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }                  \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                   \
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + i * kRowBytes16 + 16 * (8 * h + s)));        \
+            const u32x4 aw_ = *reinterpret_cast<const u32x4*>((MY) + i * kRowBytes16 + 16 * (8 * h + s));     \
+            if (X1) {                                                                                     \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_c, aw_), __builtin_bit_cast(f16x8_c, qh[0][s]), acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_c, aw_), __builtin_bit_cast(f16x8_c, qh[1][s]), acc1, 0, 0, 0); \
+            } else {                                                                                      \
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, aw_);                                            \
             const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((MY) + (32 + i) * kRowBytes16 + 16 * (8 * h + s))); \
             CLB_TM_LO_PRODUCTS(s)                                                                         \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
+            }                                                                                             \
             /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue) */            \
             if (s == 0) CLB_TM_STORE(o0, a0)                                                              \
             if (s == 2) CLB_TM_STORE(o1, a1)                                                              \
@@ -683,16 +724,16 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         CLB_TM_WAIT(4)                                                                                    \
         unsigned char* nb_ = lds16 + (buf ^ 1) * (2 * 32 * kRowBytes16);                                  \
         *reinterpret_cast<u32x4*>(nb_ + prow * kRowBytes16 + 16 * pchunk) = ph;                           \
-        *reinterpret_cast<u32x4*>(nb_ + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;                    \
+        if (!X1) *reinterpret_cast<u32x4*>(nb_ + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;           \
         const int after_ = tile + 2 * (int)gridDim.x;                                                     \
         CLB_TM_LOAD(after_ < n_tiles ? after_ : n_tiles - 1)                                              \
         __syncthreads();                                                                                  \
     }
     if (tile < n_tiles) {
         // (tied to the last operand words, or hipcc moves the wait in front of the operand split)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ph), "+v"(pl), "+v"(ql[0][7]), "+v"(ql[1][7]) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ph), "+v"(pl), "+v"(qh[0][7]), "+v"(qh[1][7]) :: "memory");
         *reinterpret_cast<u32x4*>(lds16 + prow * kRowBytes16 + 16 * pchunk) = ph;
-        *reinterpret_cast<u32x4*>(lds16 + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;
+        if (!X1) *reinterpret_cast<u32x4*>(lds16 + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;
         const int second = tile + (int)gridDim.x;
         CLB_TM_LOAD(second < n_tiles ? second : n_tiles - 1)
         __syncthreads();
@@ -743,7 +784,7 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
                                                               const float* __restrict__ C,
                                                               const float* __restrict__ Q, int T, int K,
                                                               int nslots, float cn_max, int* __restrict__ sel,
-                                                              int* __restrict__ redo_flag) {
+                                                              int* __restrict__ redo_flag, float dc_max = 0.f) {
     static_assert(kTopPartial == 4, "a partial list is read as two 16-byte halves");
     const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (t >= T) {
@@ -799,9 +840,11 @@ static __global__ __launch_bounds__(64) void top_refine_kernel(const ValIdx* __r
     }
     __syncthreads();
     float qq = qs[lane] * qs[lane] + qs[lane + 64] * qs[lane + 64];
+    const float d0 = qs[lane] - round_f16(qs[lane]), d1 = qs[lane + 64] - round_f16(qs[lane + 64]);
+    float dd = d0 * d0 + d1 * d1;                    // ||q - fp16(q)||^2: the query side of the single-product kernel's error
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
-    const float eps_c = kEpsSafety * 7.4e-5f * (sqrtf(qq) * 1.001f) * cn_max;
+    for (int o = 32; o > 0; o >>= 1) { qq += __shfl_xor(qq, o, 64); dd += __shfl_xor(dd, o, 64); }
+    const float eps_c = kEpsSafety * centroid_product_bound(sqrtf(qq) * 1.001f, sqrtf(dd) * 1.001f, cn_max, dc_max);
     const float thr = b2v - 2.f * eps_c;
     // sweep 2: every entry >= thr goes to the LDS candidate list (order is irrelevant: they are re-scored exactly)
     int total = 0;
@@ -1417,7 +1460,15 @@ struct ApproxConsts {
     float rb_max;   // max over the shard's embeddings of ||r'||, r' = the fp16-rounded residual vector
     float dw_rn;    // sqrt(dim) * max_b |fp16(w_b) - w_b|  (>= ||r - r'|| of every embedding)
     float inv_qerr; // max |dequantised inv_norm - inv_norm| = half a quantisation step of the packed code|inv word
+    float dc_max;   // max ||c - fp16(c)||: the centroid side of the single-fp16-product score table (0: that kernel is not in use)
 };
+// |approximate - canonical| of one centroid score, whichever centroid kernel produced it: the three-product bf16 split
+// (7.4e-5 qn cn, see above) or one fp16 product (measured conversion errors + fp32 accumulation; dc = 0 disables the term)
+__device__ __forceinline__ float centroid_product_bound(float qn, float dq, float cn, float dc) {
+    const float b3 = 7.4e-5f * qn * cn;
+    const float b1 = dc > 0.f ? 1.001f * (dq * cn * 1.0005f + qn * dc) + 384.f * 5.9604645e-08f * qn * cn : 0.f;
+    return fmaxf(b3, b1);
+}
 
 // The error bound of one query (see the header of this file): eps_t bounds |approx - canonical| of ONE (token, embedding)
 // score, eps_sum the same for a passage score (T tokens); `unsafe` = the fp16 score table cannot be trusted for this
@@ -1451,7 +1502,7 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     const float u = 5.9604645e-08f;  // 2^-24
     const float qn = *s_qn;
     // fp16 storage: relative 2^-11 in the normal range, absolute 2^-25 below it (subnormal spacing 2^-24)
-    const float e_cells = kEpsSafety * 7.4e-5f * qn * ac.cn_max + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
+    const float e_cells = kEpsSafety * centroid_product_bound(qn, *s_dq, ac.cn_max, ac.dc_max) + 4.8828125e-04f * qn * ac.cn_max + 2.9802322e-08f;
     // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the fp16 operands (their products are exact
     // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
     // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
@@ -1984,6 +2035,12 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
     hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 1);
     hipLaunchKernelGGL(max_f16_err_kernel, dim3(1), dim3(64), 0, st, dW, n_weights, bits + 5);
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K, bits + 2);
+    DevBuf dcb;
+    CLB_TRY(dcb.alloc(sizeof(unsigned int)));
+    CLB_HIP(hipMemsetAsync(dcb.p, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(max_row_f16_err_kernel, dim3(std::max(1, std::min(1024, K / 4))), dim3(256), 0, st, dC, K, dcb.as<unsigned int>());
+    unsigned int hdc = 0;
+    CLB_HIP(hipMemcpyAsync(&hdc, dcb.p, sizeof hdc, hipMemcpyDeviceToHost, st));
     CLB_HIP(hipGetLastError());
     unsigned int h[6];
     CLB_HIP(hipMemcpyAsync(h, bits, sizeof h, hipMemcpyDeviceToHost, st));
@@ -1998,6 +2055,7 @@ inline int build_approx_tables(hipStream_t st, const float* dC, const float* dW,
     // no inv_norm pass (constants only): fall back to the generic bound ||r'|| <= sqrt(dim) * max |w| * (1 + 2^-11)
     out->rb_max = pack ? sqrtf(f[3]) * 1.0001f : out->rn_max * 1.0005f;
     out->inv_qerr = 0.f;
+    memcpy(&out->dc_max, &hdc, sizeof(float));       // the caller zeroes it when the single-product centroid kernel is off
     if (pack) {
         // at most 20 bits for inv_norm: every level is then an exact float (a 26-bit qmax rounds UP as a float and the
         // top level would overflow the word) and the step is already far below the other error terms
