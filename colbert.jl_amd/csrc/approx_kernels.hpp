@@ -202,6 +202,13 @@ static __global__ void split_bf16_kernel(const float* __restrict__ x, uint16_t* 
 // their products are exact in fp32, the accumulation adds 2*128*u*qn*cn) -- dq per query (select_margin_kernel measures it
 // for pass 1's operand already), dc = max_c ||c - fp16(c)|| per index (max_row_f16_err_kernel).  A third of the MFMAs:
 // centroid_top_bf16x3_teams_kernel<true>, 0.110 -> 0.090 ms per 32 queries x 131 072 centroids even with the lo plane still staged.
+// |approximate - canonical| of one centroid score, whichever centroid kernel produced it: the three-product bf16 split
+// (7.4e-5 qn cn) or one fp16 product (measured conversion errors + fp32 accumulation; dc = 0 disables the term)
+__device__ __forceinline__ float centroid_product_bound(float qn, float dq, float cn, float dc) {
+    const float b3 = 7.4e-5f * qn * cn;
+    const float b1 = dc > 0.f ? 1.001f * (dq * cn * 1.0005f + qn * dc) + 384.f * 5.9604645e-08f * qn * cn : 0.f;
+    return fmaxf(b3, b1);
+}
 static __global__ void to_f16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -211,7 +218,7 @@ static __global__ void to_f16_kernel(const float* __restrict__ x, uint16_t* __re
 // max over the rows of ||c - fp16(c)|| (a component beyond the fp16 range makes it infinite: such an index is searched exactly)
 static __global__ __launch_bounds__(256) void max_row_f16_err_kernel(const float* __restrict__ C, int K, unsigned int* __restrict__ out_bits) {
     const int lane = threadIdx.x & 63;
-    float m = 0.f;
+    float m = 1e-30f;                                 // never exactly 0: 0 is the callers' "single-product kernel not in use"
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < K; c += gridDim.x * 4) {
         const float a = C[(size_t)c * kDim + lane], b = C[(size_t)c * kDim + 64 + lane];
         const float da = fabsf(a) < 6.0e4f ? a - round_f16(a) : __builtin_inff(), db = fabsf(b) < 6.0e4f ? b - round_f16(b) : __builtin_inff();
@@ -1462,13 +1469,6 @@ struct ApproxConsts {
     float inv_qerr; // max |dequantised inv_norm - inv_norm| = half a quantisation step of the packed code|inv word
     float dc_max;   // max ||c - fp16(c)||: the centroid side of the single-fp16-product score table (0: that kernel is not in use)
 };
-// |approximate - canonical| of one centroid score, whichever centroid kernel produced it: the three-product bf16 split
-// (7.4e-5 qn cn, see above) or one fp16 product (measured conversion errors + fp32 accumulation; dc = 0 disables the term)
-__device__ __forceinline__ float centroid_product_bound(float qn, float dq, float cn, float dc) {
-    const float b3 = 7.4e-5f * qn * cn;
-    const float b1 = dc > 0.f ? 1.001f * (dq * cn * 1.0005f + qn * dc) + 384.f * 5.9604645e-08f * qn * cn : 0.f;
-    return fmaxf(b3, b1);
-}
 
 // The error bound of one query (see the header of this file): eps_t bounds |approx - canonical| of ONE (token, embedding)
 // score, eps_sum the same for a passage score (T tokens); `unsafe` = the fp16 score table cannot be trusted for this

@@ -25,7 +25,7 @@ struct Stream {
 
 // Scratch of the bf16x3 nearest-centroid path, kept across calls (k-means calls it once per iteration).
 struct NearestScratch {
-    DevBuf hi, lo, bias, partial, cn;
+    DevBuf hi, lo, bias, partial, cn;    // hi: the bf16 hi plane, or the one fp16 plane of the single-product lists (lo unused then)
     DevBuf ovf_list, ovf_count;      // points whose candidate lists overflowed (mass ties): re-scored against all centroids
 };
 
@@ -43,14 +43,33 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
         const size_t cel = (size_t)K * kDim;
         const int kpad = (K + 31) / 32 * 32 + 32;
         CLB_TRY(w.hi.ensure(sizeof(uint16_t) * cel));
-        CLB_TRY(w.lo.ensure(sizeof(uint16_t) * cel));
         CLB_TRY(w.bias.ensure(sizeof(float) * kpad));
-        CLB_TRY(w.cn.ensure(sizeof(unsigned int)));
-        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC,
-                           w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), (int64_t)cel);
-        CLB_HIP(hipMemsetAsync(w.cn.p, 0, sizeof(unsigned int), st));
+        CLB_TRY(w.cn.ensure(2 * sizeof(unsigned int)));
+        CLB_HIP(hipMemsetAsync(w.cn.p, 0, 2 * sizeof(unsigned int), st));
         hipLaunchKernelGGL(max_row_norm_kernel, dim3(std::max(1, std::min(1024, K / 256))), dim3(256), 0, st, dC, K,
                            w.cn.as<unsigned int>());
+        // One fp16 product per fp32 product (nearest_top_f16_kernel) unless a centroid component is outside the fp16 range
+        // (the measured max ||c - fp16(c)|| comes back infinite: 4 bytes and one wait per call) or a comparison run asks
+        // for the three-product bf16 split, COLBERT_NEAREST_PRODUCTS=3
+        const char* products = getenv("COLBERT_NEAREST_PRODUCTS");        // read per call: tests and comparison runs switch it
+        const bool want_x1 = !(products && strcmp(products, "3") == 0);
+        bool x1 = false;
+        if (want_x1) {
+            float dc = 0.f;
+            hipLaunchKernelGGL(max_row_f16_err_kernel, dim3(std::max(1, std::min(1024, K / 4))), dim3(256), 0, st, dC, K,
+                               w.cn.as<unsigned int>() + 1);
+            CLB_HIP(hipMemcpyAsync(&dc, w.cn.as<unsigned int>() + 1, sizeof dc, hipMemcpyDeviceToHost, st));
+            CLB_HIP(hipStreamSynchronize(st));
+            x1 = dc > 0.f && std::isfinite(dc);
+            if (!x1) CLB_HIP(hipMemsetAsync(w.cn.as<unsigned int>() + 1, 0, sizeof(unsigned int), st));
+        }
+        if (x1) {
+            hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC, w.hi.as<uint16_t>(), (int64_t)cel);
+        } else {
+            CLB_TRY(w.lo.ensure(sizeof(uint16_t) * cel));
+            hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC,
+                               w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), (int64_t)cel);
+        }
         if (MODE == 1)
             hipLaunchKernelGGL(half_neg_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, dc2, K, w.bias.as<float>(), kpad);
         const int n_tiles = (K + 31) / 32;
@@ -63,7 +82,15 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
             const int64_t m = std::min(chunk_max, n - p0);
             const int groups32 = (int)((m + 31) / 32);                  // "queries" of 32 points
             const dim3 grid(1, (unsigned)((groups32 + kMqQueries - 1) / kMqQueries));
-            if (MODE == 1)
+            constexpr int kNq = 4;                                      // groups of 32 points per wave of the single-product kernel
+            const dim3 grid1((unsigned)((groups32 + 4 * kNq - 1) / (4 * kNq)));
+            if (x1 && MODE == 1)
+                hipLaunchKernelGGL((nearest_top_f16_kernel<true, kNq>), grid1, dim3(256), lds / 2, st, w.hi.as<uint16_t>(),
+                                   dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, w.bias.as<float>(), m);
+            else if (x1)
+                hipLaunchKernelGGL((nearest_top_f16_kernel<false, kNq>), grid1, dim3(256), lds / 2, st, w.hi.as<uint16_t>(),
+                                   dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, (const float*)nullptr, m);
+            else if (MODE == 1)
                 hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, true>), grid, dim3(256), lds, st,
                                    w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), dX + (size_t)p0 * kDim,
                                    w.partial.as<ValIdx>(), (uint32_t*)nullptr, K, 32, groups32, n_tiles,

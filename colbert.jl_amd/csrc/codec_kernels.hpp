@@ -479,6 +479,98 @@ static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const 
 }
 
 // -------------------------------------------------------------------------------------------------------------
+// Index build (round 5): the group lists of nearest_refine_kernel from ONE fp16 product per fp32 product instead of the three
+// bf16 products of centroid_top_bf16x3_mq_kernel<false, BIAS> -- the lists only have to bring the exact winner's group
+// within a PROVEN margin of the best listed one (the winner itself is re-scored in canonical fp32), and the margin can
+// carry the measured conversion errors of both operands (centroid_product_bound in approx_kernels.hpp):
+// |x.c - x'.c'| <= ||x - x'|| ||c'|| + ||x|| ||c - c'||.  A third of the MFMAs, half the centroid bytes, and -- the point
+// operands needing half the registers -- NQ = 4 groups of 32 points per wave: 512 points share each staged 32-centroid tile
+// (256 before), and one A fragment read from LDS feeds four MFMAs.
+// Layout and roles as in the mq kernel: A = 32 centroids x 16 dims from LDS (rows of 272 B, dims 64h + 8s + j in k-step s),
+// B = the wave's points in registers, lane (i, h) = (point i of the group, dim half h); accumulator lane (i, h) register r =
+// centroid c0 + (r & 3) + 8 (r >> 2) + 4 h.  bias[c] (= -||c||^2 / 2 for the k-means distance) is where the fp32 sums start.
+// partial: [group of 32 points][32 points][2 halves][kTopPartial].  grid = ceil(groups32 / (4 NQ)), block = 256,
+// LDS = 2 buffers x 32 rows x 272 B.
+// -------------------------------------------------------------------------------------------------------------
+template <bool BIAS, int NQ>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void nearest_top_f16_kernel(
+    const uint16_t* __restrict__ C16, const float* __restrict__ X, ValIdx* __restrict__ partial, int K, int groups32,
+    int n_tiles, const float* __restrict__ bias, int64_t n_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int bq0 = (int)blockIdx.x * (4 * NQ) + wave * NQ;      // this wave's groups: bq0 .. bq0 + NQ - 1
+    u32x4 xq[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int b = bq0 + q < groups32 ? bq0 + q : groups32 - 1;   // past the input: a duplicate whose lists are dropped
+        int64_t row = (int64_t)b * 32 + i;
+        row = row < n_rows ? row : n_rows - 1;
+        const float* xrow = X + (size_t)row * kDim + 64 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * s);
+            const float4 c = *reinterpret_cast<const float4*>(xrow + 8 * s + 4);
+            xq[q][s] = u32x4{pack_f16(a.x, a.y), pack_f16(a.z, a.w), pack_f16(c.x, c.y), pack_f16(c.z, c.w)};
+        }
+    }
+    float bv[NQ][kTopPartial];
+    int bi[NQ][kTopPartial];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) { bv[q][p] = kNegInf; bi[q][p] = 0x7fffffff; }
+    // loader: thread tid moves the 16-byte chunk (tid & 15) of rows (tid >> 4) and 16 + (tid >> 4)
+    const int prow = threadIdx.x >> 4, pchunk = threadIdx.x & 15;
+    auto tile_rows = [&](int tl, u32x4& r0, u32x4& r1) {
+        int c0 = tl * 32 + prow, c1 = c0 + 16;
+        c0 = c0 < K ? c0 : K - 1;                      // rows past K are copies of row K - 1 (group_max16 masks them)
+        c1 = c1 < K ? c1 : K - 1;
+        r0 = *reinterpret_cast<const u32x4*>(C16 + (size_t)c0 * kDim + 8 * pchunk);
+        r1 = *reinterpret_cast<const u32x4*>(C16 + (size_t)c1 * kDim + 8 * pchunk);
+    };
+    u32x4 p0, p1;
+    tile_rows(0, p0, p1);
+    int buf = 0;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        unsigned char* my = lds16 + buf * (32 * kRowBytes16);
+        *reinterpret_cast<u32x4*>(my + prow * kRowBytes16 + 16 * pchunk) = p0;
+        *reinterpret_cast<u32x4*>(my + (16 + prow) * kRowBytes16 + 16 * pchunk) = p1;
+        tile_rows(tile + 1 < n_tiles ? tile + 1 : n_tiles - 1, p0, p1);
+        // one barrier per tile: the buffer written now was last read two iterations ago, before the previous barrier
+        __syncthreads();
+        const int c0 = tile * 32;
+        // the accumulators START at the bias (this lane's rows c0 + (r & 3) + 8 (r >> 2) + 4 h: four aligned float4 of the
+        // padded bias row) -- the first MFMA of every group reads it as its C operand: no add per score afterwards
+        f32x16 init;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BIAS) b4 = *reinterpret_cast<const float4*>(bias + c0 + 8 * qd + 4 * h);
+            init[4 * qd] = b4.x; init[4 * qd + 1] = b4.y; init[4 * qd + 2] = b4.z; init[4 * qd + 3] = b4.w;
+        }
+        f32x16 acc[NQ];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f16x8 a = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(my + i * kRowBytes16 + 16 * (8 * h + s)));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xq[q][s]), s == 0 ? init : acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) topn_insert_lazy<kTopPartial>(bv[q], bi[q], group_max16(acc[q], c0, h, K), 2 * tile + h);
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (bq0 + q >= groups32) continue;
+        ValIdx* out = partial + (((size_t)(bq0 + q) * 32 + i) * 2 + h) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv[q][p], bi[q][p]};
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
 // Index build: exact nearest centroid of every point from the group lists centroid_top_bf16x3_mq_kernel<false, BIAS>
 // wrote with gx = 1 (partial: [ceil(n/32)][32 points][2 halves][kTopPartial]).  MODE 0: argmax of the canonical dot
 // product, first index on ties (compress_into_codes!, residual.jl:67-81).  MODE 1: argmin of
@@ -578,14 +670,21 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
     const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const int64_t pp = p < n ? p : n - 1;                       // idle quarters shadow the last point
     const float* x = X + (size_t)pp * kDim;
-    // ||x||: 8 dims per lane; the canonical ||x||^2 of MODE 1 is computed separately below
-    float part = 0.f;
+    // ||x|| and ||x - fp16(x)||: 8 dims per lane; the canonical ||x||^2 of MODE 1 is computed separately below
+    float part = 0.f, dpart = 0.f;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) part = fmaf(x[8 * sub + d], x[8 * sub + d], part);
+    for (int d = 0; d < 8; ++d) {
+        const float v = x[8 * sub + d], dv = fabsf(v) < 6.0e4f ? v - round_f16(v) : __builtin_inff();
+        part = fmaf(v, v, part);
+        dpart = fmaf(dv, dv, dpart);
+    }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o, 64);
-    const float xn = sqrtf(part) * 1.001f, cn = __uint_as_float(*cn_max_bits);
-    const float margin = 2.f * kEpsSafety * 7.4e-5f * xn * cn + 4e-6f * (1.f + xn * xn + cn * cn);
+    for (int o = 1; o < 16; o <<= 1) { part += __shfl_xor(part, o, 64); dpart += __shfl_xor(dpart, o, 64); }
+    // cn_max_bits[1] = max ||c - fp16(c)|| when the lists come from the single-fp16-product kernel, 0 for the bf16 split
+    const float xn = sqrtf(part) * 1.001f, cn = __uint_as_float(cn_max_bits[0]), dc = __uint_as_float(cn_max_bits[1]);
+    // (single-product lists: their accumulators start at the bias -||c||^2/2, so its magnitude rides through the 128 adds)
+    const float margin = 2.f * kEpsSafety * centroid_product_bound(xn, sqrtf(dpart) * 1.001f, cn, dc) + 4e-6f * (1.f + xn * xn + cn * cn) +
+                         (dc > 0.f ? 1.6e-5f * cn * cn : 0.f);
     const float x2 = MODE == 1 ? sumsq_canonical(x, kDim) : 0.f;
     const int64_t b = pp >> 5;
     const int i = (int)(pp & 31);
@@ -596,8 +695,10 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
     for (int e = 0; e < kTopPartial; ++e) { ent[e] = l0[e]; ent[kTopPartial + e] = l1[e]; }
     const float g1 = fmaxf(ent[0].v, ent[kTopPartial].v);
     const float thr = g1 - margin;
+    // (a point the fp16 operand cannot hold -- a component beyond its range, NaN -- has no finite margin: scored exactly)
     const bool overflow = (ent[kTopPartial - 1].i != 0x7fffffff && ent[kTopPartial - 1].v >= thr) ||
-                          (ent[2 * kTopPartial - 1].i != 0x7fffffff && ent[2 * kTopPartial - 1].v >= thr);
+                          (ent[2 * kTopPartial - 1].i != 0x7fffffff && ent[2 * kTopPartial - 1].v >= thr) ||
+                          (dc > 0.f && !(margin < 3.0e38f));
     float bestv = 0.f;
     int best = 0x7fffffff;
     auto consider = [&](int c) {

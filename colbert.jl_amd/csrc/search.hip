@@ -63,6 +63,7 @@ struct Workspace {
     int64_t Ttuned = 0;         // largest query length <= 128 this slot has seen (what the tuned-path buffers are sized for)
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
+    bool x1_table = false;      // the score table in cells_q came from the single-fp16-product kernel: the bound carries its terms
     bool stats_keep = false;    // set for the 2nd, 3rd ... sub-batch of one call: the work counters accumulate over the call
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
@@ -97,6 +98,10 @@ struct clb_searcher {
     int cbits = 0;      // bits of the code field
     float inv_lo = 0.f, inv_step = 0.f;
     DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
+    DevBuf cent_f16;          // fp16 [K][128]: the one operand of the single-product score table (batches of 16+ queries)
+    float dc_f16 = 0.f;       // max ||c - fp16(c)|| over the centroids; approx_consts.dc_max carries it only for tables made from cent_f16
+    int s1_x1 = 0;            // 1: 16+ queries build the score table from ONE fp16 product (to_f16_kernel's comment); 0: three bf16 products.
+                              // Off: -0.020 ms on the centroid kernel, +0.01-0.02 ms on pass 2 through the wider bound (profiles/r05_experiments.md)
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     int gather_lds = 0; // pass 1: score rows through LDS-DMA, four adjacent lanes per row (0: the per-lane VGPR gather); set at load
     double code_adjacency = 0.0;   // fraction of consecutive embeddings that share a 128-B line of the score table
@@ -251,6 +256,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
     const int NPs = nprobe <= 2 ? 2 : nprobe <= 8 ? 8 : nprobe <= 32 ? 32 : nprobe;
     const int n_tiles = (int)((s->K + 31) / 32);
     const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
+    w.x1_table = false;
     if (nprobe <= 2 && T <= 32) {
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
         // batches of 8+ queries share each staged centroid tile between 8 queries (centroid_top_bf16x3_mq_kernel)
@@ -267,6 +273,8 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         const bool teams = mq && want_half && B >= kTeamQueries && CLB_KNOB("CLB_DEBUG_S1_TEAMS", 1);
         const int team_groups = (B + kTeamQueries - 1) / kTeamQueries;
         if (teams) gx = std::max(1, std::min(n_tiles, std::min(256, std::max(256 / team_groups, 16))));
+        const bool x1 = teams && s->s1_x1 == 1 && s->cent_f16.p && s->dc_f16 > 0.f;
+        w.x1_table = x1;
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
@@ -278,11 +286,17 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
-                if (teams) {
-                    // 66 KB of dynamic LDS: above the 64-KB default limit of a launch
-                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel),
+                if (teams && x1) {
+                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel<true>),
                                       2 * 2 * 32 * kRowBytes16 + 8 * 4096);
-                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
+                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel<true>, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
+                                       s->cent_f16.as<uint16_t>(), (const uint16_t*)nullptr, dQ,
+                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
+                } else if (teams) {
+                    // 66 KB of dynamic LDS: above the 64-KB default limit of a launch
+                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel<false>),
+                                      2 * 2 * 32 * kRowBytes16 + 8 * 4096);
+                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel<false>, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
                 } else if (mq && want_half)
@@ -306,7 +320,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
                 Timed t(s, KID_TOPN, st);
                 hipLaunchKernelGGL(top_refine_kernel, dim3(32, B), dim3(64), 0, st, w.partial.as<ValIdx>(),
                                    s->centroids.as<float>(), dQ, T, (int)s->K, nslots, s->approx_consts.cn_max,
-                                   w.sel.as<int>(), w.redo.as<int>());
+                                   w.sel.as<int>(), w.redo.as<int>(), x1 ? s->dc_f16 : 0.f);
             }
         } else {
             {
@@ -577,6 +591,7 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
     const bool wide = s->wide_select == 1 || (s->wide_select < 0 && w.cand_cap >= kWideSelectCap);
     if (!wide) {
         ApproxConsts ac = s->approx_consts;
+        ac.dc_max = w.x1_table ? s->dc_f16 : 0.f;
         // tuning builds: CLB_DEBUG_EPS_T_ADD_1E6 widens the per-(token, embedding) bound by about that many millionths
         // through the inv_norm quantisation term (1.01 * inv_qerr * qn * (cn + rn)) -- what a coarser score-table format
         // would cost pass 2 (lists and row masks grow), measured on the real pipeline with correct results
@@ -589,8 +604,10 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
     CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
     CLB_HIP(hipMemsetAsync(w.wsel.p, 0, sizeof(WideSel) * B, st));
     const dim3 grid(kWideBlocks, B);
+    ApproxConsts acw = s->approx_consts;
+    acw.dc_max = w.x1_table ? s->dc_f16 : 0.f;
     hipLaunchKernelGGL(wide_minmax_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, w.cand_cap,
-                       s->approx_consts, w.wsel.as<WideSel>(), w.eps_pair.as<float>());
+                       acw, w.wsel.as<WideSel>(), w.eps_pair.as<float>());
     if (!tau_in)
         for (int pass = 0; pass < 4; ++pass)
             hipLaunchKernelGGL(wide_hist_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
@@ -938,6 +955,10 @@ static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, c
         const int64_t nel = dim * K;
         hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s->stream,
                            s->centroids.as<float>(), s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), nel);
+        if ((rc = s->cent_f16.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
+        hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s->stream,
+                           s->centroids.as<float>(), s->cent_f16.as<uint16_t>(), nel);
+        if (const char* g = getenv("COLBERT_S1_PRODUCTS")) s->s1_x1 = strcmp(g, "1") == 0;      // "1" / "3": comparison runs
     }
     s->cbits = 1;
     while (((int64_t)1 << s->cbits) < K) ++s->cbits;
@@ -973,6 +994,10 @@ static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, c
                                   s->approx_ok ? s->codeinv.as<uint32_t>() : nullptr, s->cbits, 1 << nbits,
                                   &s->approx_consts, &s->inv_lo, &s->inv_step)))
         return bail(rc);
+    // the fp16 side's error lives beside the consts: a table made by the three-product kernels (fewer than 16 queries) keeps
+    // the tighter bound.  Infinite (a centroid component beyond the fp16 range): the single-product kernel is never chosen.
+    s->dc_f16 = std::isfinite(s->approx_consts.dc_max) ? s->approx_consts.dc_max : 0.f;
+    s->approx_consts.dc_max = 0.f;
     s->mode = s->approx_ok ? 1 : 0;
     s->index_bytes = (int64_t)(s->centroids.bytes + s->weights.bytes + s->codes0.bytes + s->residuals.bytes +
                                s->doc_off.bytes + s->ivf_off.bytes + s->ivf_pid.bytes + s->codeinv.bytes);
@@ -1044,6 +1069,18 @@ int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
     if (!s) return -1;
     if (adjacency) *adjacency = s->code_adjacency;
     return s->gather_lds;
+}
+
+int clb_searcher_set_centroid_products(clb_searcher* s, int n) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (n != -1 && n != 1 && n != 3) return fail(CLB_EARGUMENT, "centroid products must be -1 (default), 1 (one fp16 product) or 3 (bf16 split)");
+    s->s1_x1 = n == 1 ? 1 : 0;
+    return CLB_OK;
+}
+int clb_searcher_get_centroid_products(const clb_searcher* s, float* max_f16_error) {
+    if (!s) return -1;
+    if (max_f16_error) *max_f16_error = s->dc_f16;
+    return s->s1_x1 == 1 && s->cent_f16.p && s->dc_f16 > 0.f ? 1 : 3;
 }
 
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {

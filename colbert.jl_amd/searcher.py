@@ -114,6 +114,16 @@ class Searcher:
         adj = C.c_double(0)
         return int(lib().clb_searcher_get_pass1_gather(self._h, C.byref(adj))), adj.value
 
+    def set_centroid_products(self, n: int):
+        """Batches of 16+ queries, two-pass mode: 1 = score table from one fp16 product, 3 = the bf16 split (the default, -1)."""
+        check(lib().clb_searcher_set_centroid_products(self._h, C.c_int(n)))
+
+    @property
+    def centroid_products(self):
+        """(products in use for batches of 16+ queries: 1 or 3, max ||c - fp16(c)|| over the centroids)"""
+        dc = C.c_float(0)
+        return int(lib().clb_searcher_get_centroid_products(self._h, C.byref(dc))), dc.value
+
     @property
     def mode(self) -> int:
         return int(lib().clb_searcher_get_mode(self._h))

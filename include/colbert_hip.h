@@ -130,6 +130,17 @@ int clb_searcher_set_wide_select(clb_searcher* s, int on);
  * share a 128-byte line. */
 int clb_searcher_set_pass1_gather(clb_searcher* s, int form);
 int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency);
+/* Products of the batched centroid stage (the Q x centroids GEMM of ranking.jl:9-13 for batches of 16 or more queries in
+ * the two-pass mode; no call site of its own in the reference): n = 1, the fp16 score table of pass 1 is made from ONE fp16
+ * product per fp32 product, with the measured conversion errors of both operands in the error bound; n = 3, from the
+ * three-product bf16 split (every smaller batch always is); n = -1, the default: 3 -- measured on the 1 M-passage workload the
+ * single product takes 0.020 ms off the centroid kernel (0.104 -> 0.084) and its wider bound (+12 % re-scored rows) puts
+ * 0.01-0.02 ms back on pass 2.  n = 1 on an index with a centroid component outside the fp16 range stays at 3.  Results are
+ * identical either way (the nprobe best centroids are re-scored in canonical fp32, the table only feeds the approximate pass,
+ * whose bound carries the difference).  The getter returns the count in use for such batches and, through *max_f16_error
+ * (may be null), max over the centroids of ||c - fp16(c)|| (0: out of range). */
+int clb_searcher_set_centroid_products(clb_searcher* s, int n);
+int clb_searcher_get_centroid_products(const clb_searcher* s, float* max_f16_error);
 /* Constants of the two-pass error bound of this handle: consts[0] = max ||centroid||, [1] = sqrt(dim) * max |bucket
  * weight|, [2] = max over the shard's embeddings of 1/(||c + r|| + eps), [3] = max ||bf16-rounded residual vector||,
  * [4] = sqrt(dim) * max |w - bf16(w)|, [5] = the quantisation error of the packed inv_norm.  Sharded search with a global threshold (clb_search_shard_phase1/2) needs ONE

@@ -146,6 +146,34 @@ def test_nearest_centroid_mass_ties_take_the_list_path(oracle):
     assert np.array_equal(codec.compress_into_codes(dup, data), oracle.compress_into_codes(dup, data))
 
 
+@pytest.mark.parametrize("products", ["1", "3"])
+@pytest.mark.parametrize("scale", [1.0, 50.0, 2.0e-3, 1.0e3])
+def test_nearest_centroid_near_ties_below_the_fp16_product_error(oracle, monkeypatch, products, scale):
+    """The build's group lists come from ONE fp16 product per fp32 product (nearest_top_f16_kernel; COLBERT_NEAREST_PRODUCTS=3:
+    the bf16 split).  Points that sit between two centroids with a score gap (1e-7 .. 1e-4) far below that product's error
+    (~4e-4) must still get the oracle's code -- the refine margin carries the measured conversion errors -- in both modes
+    (argmax dot, k-means distance), with long, short and (x 1e3 + one component beyond the fp16 range: three products) centroids."""
+    monkeypatch.setenv("COLBERT_NEAREST_PRODUCTS", products)
+    rng = np.random.default_rng(211)
+    K, n = 512, 6000
+    cent = oracle.normalize_array(rng.normal(size=(128, K)).astype(np.float32))
+    cent[:, 100:140] = cent[:, 60:100] + np.float32(3e-4) * rng.normal(size=(128, 40)).astype(np.float32)   # close pairs
+    a, b = rng.integers(0, K, n), rng.integers(0, K, n)
+    gap = (10.0 ** rng.uniform(-7, -4, n)).astype(np.float32)
+    pts = cent[:, a] * (1 + gap) + cent[:, b] + np.float32(1e-3) * rng.normal(size=(128, n)).astype(np.float32)
+    pts = np.asfortranarray(oracle.normalize_array(pts.astype(np.float32)))
+    cent = np.asfortranarray(cent * np.float32(scale))
+    if scale == 1.0e3:
+        cent[3, 11] = np.float32(7.0e4)
+        pts[:, :50] *= np.float32(7.0e4)                          # points beyond the fp16 range as well
+    assert np.array_equal(codec.compress_into_codes(cent, pts), oracle.compress_into_codes(cent, pts))
+    init = np.asfortranarray(cent[:, :300] if scale != 1.0e3 else cent[:, 12:312])
+    c, asg, it = codec.kmeans(pts, init, max_iters=3)
+    rc, ra, rit = oracle.kmeans(pts, init, max_iters=3)
+    assert it == rit and np.array_equal(asg, ra)
+    assert_same_f32(c, rc, "kmeans centroids")
+
+
 @pytest.mark.parametrize("dim,n,K,bsize", [(128, 3000, 40, 1000), (128, 700, 64, 100), (16, 500, 9, 1000),
                                              (128, 6000, 200, 1000)])
 def test_kmeans_bit_exact(oracle, dim, n, K, bsize):
@@ -320,6 +348,41 @@ def test_search_batch_sizes(oracle, T):
                     rp, rs, rn = ref[j]
                     assert np.array_equal(bp[:, j], rp) and bn[j] == rn, (mode, B, j)
                     assert_same_f32(bs[:, j], rs, f"mode={mode} B={B} q={j}")
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 60.0, 3.0e-3, 1.0e3])
+def test_centroid_products_of_large_batches(oracle, scale):
+    """Batches of 16+ queries (two-pass mode) can build pass 1's fp16 score table from ONE fp16 product per fp32 product
+    (clb_searcher_set_centroid_products(1)), the error bound carrying the measured fp16 conversion errors of queries and
+    centroids; 3 (default) = the bf16 split every smaller batch uses.  Both give the oracle's result bit for bit -- also with centroids
+    whose fp16 images are coarse (x 60: ulp 0.03), denormal-ish (x 3e-3) or out of range (x 1e3 -> three products)."""
+    idx = synthetic.make_index(seed=41, n_docs=6000, K=2048)
+    idx = dict(idx)
+    idx["centroids"] = np.asfortranarray(idx["centroids"] * np.float32(scale))
+    if scale == 1.0e3:
+        idx["centroids"][5, 7] = np.float32(7.0e4)                    # beyond fp16's largest finite value
+    Qs = synthetic.make_queries(idx, 42, 32)
+    ref = [oracle.search(idx, Qs[:, :, j], nprobe=2, k=100) for j in range(Qs.shape[2])]
+    s = clb.Searcher(index=idx)
+    try:
+        n_default, dc = s.centroid_products
+        assert n_default == 3 and (dc > 0) == (scale < 1.0e3), (n_default, dc)
+        n_one = 1 if dc > 0 else 3
+        if scale < 1.0e3:       # the measured error is at most half an fp16 ulp per component of the longest centroid
+            assert dc <= 2.0 ** -11 * float(np.linalg.norm(idx["centroids"], axis=0).max()) * 1.001 + 128 ** 0.5 * 2.0 ** -25
+        for n in (1, 3, -1):
+            s.set_centroid_products(n)
+            assert s.centroid_products[0] == (n_one if n == 1 else 3)
+            for B in (16, 32):
+                bp, bs, bn = s.search_batch(np.asfortranarray(Qs[:, :, :B]), 100, nprobe=2)
+                for j in range(B):
+                    rp, rs, rn = ref[j]
+                    assert np.array_equal(bp[:, j], rp) and bn[j] == rn, (n, B, j)
+                    assert_same_f32(bs[:, j], rs, f"products={n} B={B} q={j}")
+        with pytest.raises(clb.ArgumentError):
+            s.set_centroid_products(2)
     finally:
         s.close()
 
