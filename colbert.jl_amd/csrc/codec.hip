@@ -26,13 +26,16 @@ struct Stream {
 // Scratch of the bf16x3 nearest-centroid path, kept across calls (k-means calls it once per iteration).
 struct NearestScratch {
     DevBuf hi, lo, bias, partial, cn;    // hi: the bf16 hi plane, or the one fp16 plane of the single-product lists (lo unused then)
-    DevBuf ovf_list, ovf_count;      // points whose candidate lists overflowed (mass ties): re-scored against all centroids
+    DevBuf ovf_list, ovf_count, ovf_keys;   // points whose candidate lists overflowed (near / mass ties): re-scored against all centroids
 };
 
 // device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means.
-// dim 128, K >= 32: approximate scores at the bf16 MFMA rate (three split products, proven bound) shared between
-// 256 points per staged centroid tile, then an exact re-evaluation of the few candidates per point with the
-// canonical arithmetic -- the same codes as the all-fp32 kernel (kept as the small-K / other-dim path), bit for bit.
+// dim 128, K >= 32: approximate scores at the 16-bit MFMA rate with a proven bound -- ONE fp16 product per fp32 product since
+// round 5 (nearest_top_f16_dma_kernel: 512 points per staged centroid tile, the measured conversion errors of points and
+// centroids in the refine margin; 1 M passages: k-means 18.6 -> 7.1 s, compress 5.6 -> 2.3 s), the three-product bf16 split
+// of rounds 2-4 (256 points per tile) when a centroid component is outside the fp16 range -- then an exact re-evaluation
+// of the few candidates per point with the canonical arithmetic: the same codes as the all-fp32 kernel (kept as the small-K /
+// other-dim path), bit for bit.
 template <int MODE>
 int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim, int K, const float* dX, int64_t n,
                       uint32_t* dOut, NearestScratch* scratch = nullptr) {
@@ -63,7 +66,13 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
             x1 = dc > 0.f && std::isfinite(dc);
             if (!x1) CLB_HIP(hipMemsetAsync(w.cn.as<unsigned int>() + 1, 0, sizeof(unsigned int), st));
         }
-        if (x1) {
+        const char* staging = getenv("COLBERT_NEAREST_STAGING");          // "registers": the first form of the kernel (comparison runs)
+        const bool dma = x1 && !(staging && strcmp(staging, "registers") == 0);
+        if (dma) {          // the tiled table of nearest_top_f16_dma_kernel: whole tiles, the last one padded with copies of row K - 1
+            const int64_t n_chunks = (int64_t)((K + 31) / 32) * 512;
+            CLB_TRY(w.hi.ensure(16 * (size_t)n_chunks));
+            hipLaunchKernelGGL(to_f16_tiled_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, dC, K, w.hi.as<uint16_t>(), n_chunks);
+        } else if (x1) {
             hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC, w.hi.as<uint16_t>(), (int64_t)cel);
         } else {
             CLB_TRY(w.lo.ensure(sizeof(uint16_t) * cel));
@@ -77,6 +86,7 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)((std::min(n, chunk_max) + 31) / 32) * 2 * 32 * kTopPartial));
         CLB_TRY(w.ovf_list.ensure(sizeof(uint32_t) * (size_t)std::min(n, chunk_max)));
         CLB_TRY(w.ovf_count.ensure(sizeof(unsigned int)));
+        CLB_TRY(w.ovf_keys.ensure(sizeof(unsigned long long) * (size_t)std::min(n, chunk_max)));
         const size_t lds = 2 * 2 * 32 * kRowBytes16;
         for (int64_t p0 = 0; p0 < n; p0 += chunk_max) {
             const int64_t m = std::min(chunk_max, n - p0);
@@ -84,7 +94,13 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
             const dim3 grid(1, (unsigned)((groups32 + kMqQueries - 1) / kMqQueries));
             constexpr int kNq = 4;                                      // groups of 32 points per wave of the single-product kernel
             const dim3 grid1((unsigned)((groups32 + 4 * kNq - 1) / (4 * kNq)));
-            if (x1 && MODE == 1)
+if (dma && MODE == 1)
+                hipLaunchKernelGGL((nearest_top_f16_dma_kernel<true>), grid1, dim3(256), 3 * 8192, st, w.hi.as<uint16_t>(),
+                                   dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, w.bias.as<float>(), m);
+            else if (dma)
+                hipLaunchKernelGGL((nearest_top_f16_dma_kernel<false>), grid1, dim3(256), 3 * 8192, st, w.hi.as<uint16_t>(),
+                                   dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, (const float*)nullptr, m);
+            else if (x1 && MODE == 1)
                 hipLaunchKernelGGL((nearest_top_f16_kernel<true, kNq>), grid1, dim3(256), lds / 2, st, w.hi.as<uint16_t>(),
                                    dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, w.bias.as<float>(), m);
             else if (x1)
@@ -103,11 +119,23 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
             CLB_HIP(hipMemsetAsync(w.ovf_count.p, 0, sizeof(unsigned int), st));
             hipLaunchKernelGGL(nearest_refine_kernel<MODE>, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st,
                                w.partial.as<ValIdx>(), dC, dc2, dX + (size_t)p0 * kDim, m, K, w.cn.as<unsigned int>(),
-                               dOut + p0, w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>());
-            // the overflow list (normally empty: the launch reads a zero and ends) on the fp32 MFMA, all K centroids per point
-            hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3((unsigned)std::min<int64_t>(2048, (m + 63) / 64)), dim3(128),
+                               dOut + p0, w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>());
+            // the overflow list (a few dozen points per million; empty: the launch reads a zero and ends) on the fp32 MFMA, all K
+            // centroids per point, the centroid tiles dealt to `slices` work-groups per pair of 32-point tiles
+            const int slices = std::max(1, std::min(n_tiles / 8, 128));
+            const int pairs = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / slices, (m + 63) / 64));
+            hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3(pairs, slices), dim3(128),
                                2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX + (size_t)p0 * kDim,
-                               w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), dOut + p0);
+                               w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>());
+            hipLaunchKernelGGL(nearest_list_finalize_kernel, dim3(64), dim3(256), 0, st, w.ovf_list.as<uint32_t>(),
+                               w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>(), dOut + p0);
+            if (getenv("COLBERT_DEBUG_NEAREST")) {      // how many points took the exhaustive path (a wait per chunk: debugging only)
+                unsigned int cnt = 0;
+                CLB_HIP(hipMemcpyAsync(&cnt, w.ovf_count.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+                CLB_HIP(hipStreamSynchronize(st));
+                fprintf(stderr, "nearest_centroids<%d>: %lld points, K = %d, %s lists, %u re-scored against all centroids\n", MODE,
+                        (long long)m, K, x1 ? "fp16 x1" : "bf16 x3", cnt);
+            }
         }
     } else if (dim == kDim) {
         const int64_t ptiles = (n + 31) / 32;

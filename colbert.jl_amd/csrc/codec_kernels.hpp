@@ -492,8 +492,8 @@ static __global__ __launch_bounds__(256) void epilogue_query_fused_kernel(const 
 // partial: [group of 32 points][32 points][2 halves][kTopPartial].  grid = ceil(groups32 / (4 NQ)), block = 256,
 // LDS = 2 buffers x 32 rows x 272 B.
 // -------------------------------------------------------------------------------------------------------------
-template <bool BIAS, int NQ>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void nearest_top_f16_kernel(
+template <bool BIAS, int NQ, int WPE = 2>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nearest_top_f16_kernel(
     const uint16_t* __restrict__ C16, const float* __restrict__ X, ValIdx* __restrict__ partial, int K, int groups32,
     int n_tiles, const float* __restrict__ bias, int64_t n_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
@@ -531,6 +531,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     u32x4 p0, p1;
     tile_rows(0, p0, p1);
+    // the tile's 32 bias values come through the scalar cache one tile ahead (the address is uniform): as vector loads next to
+    // their use they exposed an L2 round trip per tile
+    float bcur[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) bcur[r] = BIAS ? bias[r] : 0.f;
     int buf = 0;
     for (int tile = 0; tile < n_tiles; ++tile) {
         unsigned char* my = lds16 + buf * (32 * kRowBytes16);
@@ -544,10 +549,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         // padded bias row) -- the first MFMA of every group reads it as its C operand: no add per score afterwards
         f32x16 init;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (BIAS) b4 = *reinterpret_cast<const float4*>(bias + c0 + 8 * qd + 4 * h);
-            init[4 * qd] = b4.x; init[4 * qd + 1] = b4.y; init[4 * qd + 2] = b4.z; init[4 * qd + 3] = b4.w;
+        for (int r = 0; r < 16; ++r) init[r] = h ? bcur[(r & 3) + 8 * (r >> 2) + 4] : bcur[(r & 3) + 8 * (r >> 2)];
+        if (BIAS) {
+            const float* bn = bias + (tile + 1 < n_tiles ? c0 + 32 : c0);      // (the bias row is padded by 32 entries)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bcur[r] = bn[r];
         }
         f32x16 acc[NQ];
 #pragma unroll
@@ -571,6 +577,133 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 // -------------------------------------------------------------------------------------------------------------
+// The same lists with the centroid tiles moved by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) from a
+// TILED fp16 table -- to_f16_tiled_kernel writes [tile of 32 centroids][16-byte chunk c of the row: dims 8c .. 8c+7][row][8 halfs],
+// 8 KB per tile, rows past K = copies of row K - 1 -- so that a tile is one contiguous block in memory AND lands in LDS
+// chunk-major: lane (i, h) reads its A fragment of k-step s at (8h + s) * 512 + 16 i, 32 lanes x 16 contiguous bytes per chunk
+// (no bank conflicts, no padding, one base address + immediate offsets).  Ring of three tile buffers, one barrier per tile as
+// in gemm_planes2_kernel (encoder_kernels.hpp): tile k waits for its own two DMAs (vmcnt(2): only those of tile k + 1 are
+// younger), meets the barrier -- every wave has left buffer (k - 1) % 3 -- and refills that buffer with tile k + 2.
+// The eight registers the staging took hold two more A fragments: four are in flight, re-filled three k-steps (12 MFMAs) ahead,
+// and the first four of tile k + 1 are requested BEFORE the list epilogue of tile k, which then runs under their latency.
+// grid = ceil(groups32 / 16), block = 256, LDS = 3 x 8 KB.
+// -------------------------------------------------------------------------------------------------------------
+static __global__ void to_f16_tiled_kernel(const float* __restrict__ C, int K, uint16_t* __restrict__ out, int64_t n_chunks) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread
+    if (g >= n_chunks) return;
+    const int row = (int)(g & 31), chunk = (int)((g >> 5) & 15);
+    const int64_t tile = g >> 9;
+    int64_t c = tile * 32 + row;
+    c = c < K ? c : K - 1;
+    const float4 a = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 8 * chunk);
+    const float4 b = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 8 * chunk + 4);
+    *reinterpret_cast<u32x4*>(out + g * 8) = u32x4{pack_f16(a.x, a.y), pack_f16(a.z, a.w), pack_f16(b.x, b.y), pack_f16(b.z, b.w)};
+}
+
+template <bool BIAS>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void nearest_top_f16_dma_kernel(
+    const uint16_t* __restrict__ C16t, const float* __restrict__ X, ValIdx* __restrict__ partial, int K, int groups32,
+    int n_tiles, const float* __restrict__ bias, int64_t n_rows) {
+    constexpr int NQ = 4, STAGES = 3, TILEB = 8192;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int bq0 = (int)blockIdx.x * (4 * NQ) + wave * NQ;
+    // this wave's two DMAs of a tile: bytes [2 wave, 2 wave + 2) KB of the tile, 16 per lane
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds16 + (uint32_t)wave * 2048u;
+    const char* tbase = reinterpret_cast<const char*>(C16t) + wave * 2048;
+#define CLB_ND_ISSUE(TL, BUF)                                                                                            \
+    {                                                                                                                    \
+        const char* t_ = tbase + (int64_t)(TL) * TILEB;                                                                  \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                                                \
+                     :: "v"(voff), "s"(t_), "s"(lds0 + (uint32_t)(BUF) * TILEB) : "memory");                             \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                                                \
+                     :: "v"(voff), "s"(t_ + 1024), "s"(lds0 + (uint32_t)(BUF) * TILEB + 1024u) : "memory");              \
+    }
+    u32x4 xq[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int b = bq0 + q < groups32 ? bq0 + q : groups32 - 1;   // past the input: a duplicate whose lists are dropped
+        int64_t row = (int64_t)b * 32 + i;
+        row = row < n_rows ? row : n_rows - 1;
+        const float* xrow = X + (size_t)row * kDim + 64 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * s);
+            const float4 c = *reinterpret_cast<const float4*>(xrow + 8 * s + 4);
+            xq[q][s] = u32x4{pack_f16(a.x, a.y), pack_f16(a.z, a.w), pack_f16(c.x, c.y), pack_f16(c.z, c.w)};
+        }
+    }
+    // (every point load above has been consumed by its conversion: nothing of this wave's is pending in front of the DMAs)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLB_ND_ISSUE(0, 0)
+    if (n_tiles > 1) CLB_ND_ISSUE(1, 1)
+    float bv[NQ][kTopPartial];
+    int bi[NQ][kTopPartial];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) { bv[q][p] = kNegInf; bi[q][p] = 0x7fffffff; }
+    // the tile's 32 bias values come through the scalar cache (uniform address), requested with the tile's first fragments
+    float bcur[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) bcur[r] = 0.f;
+    const unsigned char* a_lane = lds16 + h * 4096 + i * 16;
+    f32x16 acc[NQ];
+    u32x4 af[4];
+    int buf = 0;
+    // tile k has landed once at most the DMAs of tile k + 1 are pending; behind the barrier buffer (k - 1) % 3 is free
+#define CLB_ND_ENTER(KT)                                                                                                 \
+    {                                                                                                                    \
+        if ((KT) + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                               \
+        if ((KT) + 2 < n_tiles) CLB_ND_ISSUE((KT) + 2, buf == 0 ? STAGES - 1 : buf - 1)                                   \
+        if (BIAS) _Pragma("unroll") for (int r = 0; r < 32; ++r) bcur[r] = bias[(KT) * 32 + r];                          \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                    \
+            af[s] = *reinterpret_cast<const u32x4*>(a_lane + buf * TILEB + s * 512);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    CLB_ND_ENTER(0)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int c0 = tile * 32;
+        f32x16 init;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) init[r] = h ? bcur[(r & 3) + 8 * (r >> 2) + 4] : bcur[(r & 3) + 8 * (r >> 2)];
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* a_tile = a_lane + buf * TILEB;
+        // the scheduler is fenced off around every group: left alone it gathers the fragment reads into two bursts and waits
+        // for each right behind its issue
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f16x8 a = __builtin_bit_cast(f16x8, af[s & 3]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xq[q][s]), s == 0 ? init : acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 4 < 8) {
+                af[s & 3] = *reinterpret_cast<const u32x4*>(a_tile + (s + 4) * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        if (tile + 1 < n_tiles) CLB_ND_ENTER(tile + 1)          // the next tile's first fragments fly under the epilogue below
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) topn_insert_lazy<kTopPartial>(bv[q], bi[q], group_max16(acc[q], c0, h, K), 2 * tile + h);
+    }
+#undef CLB_ND_ENTER
+#undef CLB_ND_ISSUE
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (bq0 + q >= groups32) continue;
+        ValIdx* out = partial + (((size_t)(bq0 + q) * 32 + i) * 2 + h) * kTopPartial;
+#pragma unroll
+        for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv[q][p], bi[q][p]};
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
 // Index build: exact nearest centroid of every point from the group lists centroid_top_bf16x3_mq_kernel<false, BIAS>
 // wrote with gx = 1 (partial: [ceil(n/32)][32 points][2 halves][kTopPartial]).  MODE 0: argmax of the canonical dot
 // product, first index on ties (compress_into_codes!, residual.jl:67-81).  MODE 1: argmin of
@@ -582,19 +715,34 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // grid = ceil(n / 16), block = 256 (4 waves x 4 points).
 // -------------------------------------------------------------------------------------------------------------
 // nearest_centroid_mfma_kernel over a LIST of points (the overflow list of nearest_refine_kernel; `count` lives on the device):
-// the same exact arithmetic and tie rule, 32 listed points per wave, the grid loops over the list.
+// the same exact arithmetic and tie rule, 32 listed points per wave.  The list is normally a few dozen points of millions (near
+// ties inside the refine margin), and one wave walking all K centroids for them took 19 ms at K = 131 072 -- per chunk, 2 s of a
+// 1 M-passage build.  So the centroid tiles are dealt to gridDim.y work-groups per point tile: each scores its slice with the
+// canonical chain and merges its best (value, index) into the point's 64-bit key with one atomicMax -- larger key = better
+// value, then SMALLER index (first index on ties, as in the serial order); nearest_list_finalize_kernel turns keys into codes.
+// -0 and +0 compare equal in the serial rule, so values are canonicalised (v + 0) before they become keys.
+// grid = (point-tile pairs in flight, slices), block = 128; keys[slot] = 0 is set by the thread that appended the slot.
+template <int MODE>
+__device__ __forceinline__ unsigned long long nearest_key(float v, int c) {
+    const uint32_t k = f32_order_key(v + 0.0f);
+    return ((unsigned long long)(MODE == 1 ? ~k : k) << 32) | (0xffffffffu - (uint32_t)c);
+}
 template <int MODE>
 static __global__ __launch_bounds__(128) void nearest_centroid_mfma_list_kernel(const float* __restrict__ C,
                                                                          const float* __restrict__ c2, int K,
                                                                          const float* __restrict__ X,
                                                                          const uint32_t* __restrict__ list,
                                                                          const unsigned int* __restrict__ count_p,
-                                                                         uint32_t* __restrict__ out) {
+                                                                         unsigned long long* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     float* my = lds + wave * (32 * kCentTileStride);
     const int64_t count = (int64_t)*count_p;
+    const int n_tiles = (K + 31) / 32;
+    const int per = (n_tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_lo = (int)blockIdx.y * per, t_hi = t_lo + per < n_tiles ? t_lo + per : n_tiles;
+    if (t_lo >= t_hi) return;
     for (int64_t ptile = (int64_t)blockIdx.x * 2 + wave; ptile * 32 < count; ptile += (int64_t)gridDim.x * 2) {
         const int64_t slot = ptile * 32 + i;
         const int64_t pt = list[slot < count ? slot : count - 1];
@@ -610,8 +758,7 @@ static __global__ __launch_bounds__(128) void nearest_centroid_mfma_list_kernel(
         if (MODE == 1) x2 = sumsq_canonical(xrow, kDim);
         float bestv = 0.f;
         int best = 0x7fffffff;
-        const int n_tiles = (K + 31) / 32;
-        for (int tile = 0; tile < n_tiles; ++tile) {
+        for (int tile = t_lo; tile < t_hi; ++tile) {
             const int c0 = tile * 32;
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
@@ -650,12 +797,14 @@ static __global__ __launch_bounds__(128) void nearest_centroid_mfma_list_kernel(
                 }
             }
         }
-        const float ov = __shfl_xor(bestv, 32, 64);
-        const int oi = __shfl_xor(best, 32, 64);
-        const bool take = MODE == 1 ? (ov < bestv || (ov == bestv && oi < best)) : (ov > bestv || (ov == bestv && oi < best));
-        if (oi != 0x7fffffff && (best == 0x7fffffff || take)) { bestv = ov; best = oi; }
-        if (h == 0 && slot < count) out[pt] = (uint32_t)(best + 1);
+        if (slot < count && best != 0x7fffffff) atomicMax(keys + slot, nearest_key<MODE>(bestv, best));
     }
+}
+static __global__ void nearest_list_finalize_kernel(const uint32_t* __restrict__ list, const unsigned int* __restrict__ count_p,
+                                                    const unsigned long long* __restrict__ keys, uint32_t* __restrict__ out) {
+    const int64_t count = (int64_t)*count_p;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < count; s += (int64_t)gridDim.x * blockDim.x)
+        out[list[s]] = (0xffffffffu - (uint32_t)(keys[s] & 0xffffffffull)) + 1u;
 }
 template <int MODE>
 static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx* __restrict__ partial,
@@ -665,7 +814,8 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
                                                                    const unsigned int* __restrict__ cn_max_bits,
                                                                    uint32_t* __restrict__ out,
                                                                    uint32_t* __restrict__ ovf_list = nullptr,
-                                                                   unsigned int* __restrict__ ovf_count = nullptr) {
+                                                                   unsigned int* __restrict__ ovf_count = nullptr,
+                                                                   unsigned long long* __restrict__ ovf_keys = nullptr) {
     const int lane = threadIdx.x & 63, sub = lane & 15;
     const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const int64_t pp = p < n ? p : n - 1;                       // idle quarters shadow the last point
@@ -734,7 +884,11 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
         // mass ties (identical or nearly degenerate centroids: more qualifying groups than a list holds): the point is handed
         // to nearest_centroid_mfma_list_kernel, which scores it against ALL centroids on the fp32 MFMA -- 16 lanes walking K
         // centroids here took ~2 ms per point, and a sample whose embeddings are nearly degenerate sends thousands this way
-        if (sub == 0 && p < n) ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
+        if (sub == 0 && p < n) {
+            const unsigned int at = atomicAdd(ovf_count, 1u);
+            ovf_list[at] = (uint32_t)p;
+            ovf_keys[at] = 0ull;                                      // below every key nearest_key forms (index field >= 1)
+        }
         return;                                                       // uniform over the point's 16 lanes; no shuffle below is shared
     } else {
         for (int c = sub; c < K; c += 16) consider(c);

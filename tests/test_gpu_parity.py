@@ -146,14 +146,16 @@ def test_nearest_centroid_mass_ties_take_the_list_path(oracle):
     assert np.array_equal(codec.compress_into_codes(dup, data), oracle.compress_into_codes(dup, data))
 
 
-@pytest.mark.parametrize("products", ["1", "3"])
+@pytest.mark.parametrize("products", ["1", "1-registers", "3"])
 @pytest.mark.parametrize("scale", [1.0, 50.0, 2.0e-3, 1.0e3])
 def test_nearest_centroid_near_ties_below_the_fp16_product_error(oracle, monkeypatch, products, scale):
-    """The build's group lists come from ONE fp16 product per fp32 product (nearest_top_f16_kernel; COLBERT_NEAREST_PRODUCTS=3:
-    the bf16 split).  Points that sit between two centroids with a score gap (1e-7 .. 1e-4) far below that product's error
+    """The build's group lists come from ONE fp16 product per fp32 product (nearest_top_f16_dma_kernel, tiles by LDS-DMA;
+    COLBERT_NEAREST_STAGING=registers: nearest_top_f16_kernel, its first form; COLBERT_NEAREST_PRODUCTS=3: the bf16 split).  Points that sit between two centroids with a score gap (1e-7 .. 1e-4) far below that product's error
     (~4e-4) must still get the oracle's code -- the refine margin carries the measured conversion errors -- in both modes
     (argmax dot, k-means distance), with long, short and (x 1e3 + one component beyond the fp16 range: three products) centroids."""
-    monkeypatch.setenv("COLBERT_NEAREST_PRODUCTS", products)
+    monkeypatch.setenv("COLBERT_NEAREST_PRODUCTS", products[0])
+    if products.endswith("registers"):
+        monkeypatch.setenv("COLBERT_NEAREST_STAGING", "registers")
     rng = np.random.default_rng(211)
     K, n = 512, 6000
     cent = oracle.normalize_array(rng.normal(size=(128, K)).astype(np.float32))
