@@ -30,6 +30,15 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy rate the guide measures on this part (the practical ceiling of a stream)
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak
+
+
+def nearest_products():
+    """Products per fp32 product of the index build's nearest-centroid group lists: ONE fp16 product since round 5
+    (nearest_top_f16_dma_kernel), three bf16 ones when COLBERT_NEAREST_PRODUCTS=3 asks for the earlier kernel.  Both run at
+    the same dense 16-bit MFMA peak."""
+    n = 3 if os.environ.get("COLBERT_NEAREST_PRODUCTS") == "3" else 1
+    return n, ("bf16, 3 products per fp32 product" if n == 3 else "fp16, 1 product per fp32 product")
+
 BYTES_PER_EMB = 36.0         # 4-B code + 32-B packed residual (SURVEY 8d)
 BYTES_PER_PID = 16.0
 FLOP_PER_EMB = 8192.0        # 2 * 32 * 128
@@ -244,10 +253,11 @@ def build_config2_index(clb, docs, kmeans_iters, device):
     rec["kmeans_s"] = round(dt, 3)
     rec["kmeans_iters"] = it
     rec["kmeans_s_per_iter"] = round(dt / it, 3)
-    # assignment = three bf16 MFMA products per fp32 product (bf16x3 split): bf16 flops against the dense bf16 peak
-    bf16_tf = 3 * 2.0 * 128 * sample.shape[1] * K * it / dt / 1e12
+    # assignment = the MFMA flops the group lists really execute, against the dense 16-bit peak
+    n_prod, what = nearest_products()
+    bf16_tf = n_prod * 2.0 * 128 * sample.shape[1] * K * it / dt / 1e12
     rec["kmeans_roofline"] = {"bound": "mfma", "achieved": round(bf16_tf, 1), "peak": BF16_MFMA_PEAK_TF,
-                              "unit": "TFLOP/s (bf16, 3 products per fp32 product; host copies and the centroid update inside the time)",
+                              "unit": f"TFLOP/s ({what}; host copies and the centroid update inside the time)",
                               "frac": round(bf16_tf / BF16_MFMA_PEAK_TF, 4)}
     t0 = time.time()
     cut, w, avg, _ = codec.compute_avg_residuals(2, cent, held, device=device)
@@ -279,9 +289,10 @@ def build_device_index(torch, docs, kmeans_iters, dev):
     index, rec = indexer.index_device(src, nbits=2, kmeans_niters=kmeans_iters, seed=62)
     for stage, n_pts, secs in (("kmeans", rec["sample_points"] * rec["kmeans_iters"], rec["kmeans_s"]),
                                ("compress", rec["embeddings"], rec["compress_s"])):
-        tf = 3 * 2.0 * 128 * n_pts * rec["K"] / max(secs, 1e-9) / 1e12
+        n_prod, what = nearest_products()
+        tf = n_prod * 2.0 * 128 * n_pts * rec["K"] / max(secs, 1e-9) / 1e12
         rec[stage + "_roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF,
-                                    "unit": "TFLOP/s (bf16, 3 products per fp32 product; " +
+                                    "unit": f"TFLOP/s ({what}; " +
                                             ("the centroid update inside the time)" if stage == "kmeans" else "residual packing inside the time)"),
                                     "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
     rec["input"] = "generated on the device chunk by chunk (synthetic.DeviceMixtureSource); no host copy of the embeddings exists"
@@ -315,9 +326,10 @@ def sharded_index_build(torch, dist, rank, world, docs, kmeans_iters, dev):
                 "centroids_identical_on_all_ranks": bool(lo.item() == hi.item()),
                 "exchange": "staged through host memory (gloo rehearsal)" if staged else "RCCL all_gather_into_tensor",
                 "note": "seconds per stage are the MAX over the ranks; every rank builds and keeps its own shard"})
-    tf = 3 * 2.0 * 128 * rec["sample_points_total"] * rec["K"] * rec["kmeans_iters"] / max(out["kmeans_s"], 1e-9) / 1e12
+    n_prod, what = nearest_products()
+    tf = n_prod * 2.0 * 128 * rec["sample_points_total"] * rec["K"] * rec["kmeans_iters"] / max(out["kmeans_s"], 1e-9) / 1e12
     out["kmeans_roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF * world,
-                              "unit": "TFLOP/s over all ranks (bf16, 3 products per fp32 product; exchange and update inside the time)",
+                              "unit": f"TFLOP/s over all ranks ({what}; exchange and update inside the time)",
                               "frac": round(tf / (BF16_MFMA_PEAK_TF * world), 4)}
     return out
 
