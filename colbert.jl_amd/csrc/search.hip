@@ -100,8 +100,10 @@ struct clb_searcher {
     DevBuf cent_hi, cent_lo;  // bf16 [K][128] split of the centroids (bf16x3 centroid scoring)
     DevBuf cent_f16;          // fp16 [K][128]: the one operand of the single-product score table (batches of 16+ queries)
     float dc_f16 = 0.f;       // max ||c - fp16(c)|| over the centroids; approx_consts.dc_max carries it only for tables made from cent_f16
-    int s1_x1 = 0;            // 1: 16+ queries build the score table from ONE fp16 product (to_f16_kernel's comment); 0: three bf16 products.
-                              // Off: -0.020 ms on the centroid kernel, +0.01-0.02 ms on pass 2 through the wider bound (profiles/r05_experiments.md)
+    int s1_x1 = -1;           // 16+ queries: score table from ONE fp16 product (to_f16_kernel's comment)?  1 yes, 0 three bf16 products,
+                              // -1 by the handle's role: yes on a shard of a group (bounds_synced: the centroid stage is replicated on every
+                              // shard while the pass-2 rows its wider bound adds are divided among them), no on a single GPU, where
+                              // -0.020 ms on the centroid kernel meets +0.01-0.02 ms on pass 2 (profiles/r05_experiments.md)
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     int gather_lds = 0; // pass 1: score rows through LDS-DMA, four adjacent lanes per row (0: the per-lane VGPR gather); set at load
     double code_adjacency = 0.0;   // fraction of consecutive embeddings that share a 128-B line of the score table
@@ -273,7 +275,7 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         const bool teams = mq && want_half && B >= kTeamQueries && CLB_KNOB("CLB_DEBUG_S1_TEAMS", 1);
         const int team_groups = (B + kTeamQueries - 1) / kTeamQueries;
         if (teams) gx = std::max(1, std::min(n_tiles, std::min(256, std::max(256 / team_groups, 16))));
-        const bool x1 = teams && s->s1_x1 == 1 && s->cent_f16.p && s->dc_f16 > 0.f;
+        const bool x1 = teams && (s->s1_x1 == 1 || (s->s1_x1 < 0 && s->bounds_synced)) && s->cent_f16.p && s->dc_f16 > 0.f;
         w.x1_table = x1;
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
@@ -586,12 +588,18 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
 // up to 32 768 candidates in registers; shards whose queries can have several times that (candidate capacity >= 131 072:
 // roughly 3 M passages and up) take the wide selection -- kWideBlocks work-groups per query, one launch per radix pass.
 constexpr size_t kWideSelectCap = 131072;
+// The centroid side of the single-product score table in the error bound: when this batch's table was made that way -- and,
+// on a shard of a group, whenever a shard MAY make its tables that way (the threshold tau comes from every shard's
+// approximate scores, so one bound has to cover them all; set clb_searcher_set_centroid_products alike on all shards).
+inline float bound_dc(const clb_searcher* s, const Workspace& w) {
+    return (w.x1_table || (s->bounds_synced && s->s1_x1 != 0 && s->cent_f16.p)) ? s->dc_f16 : 0.f;
+}
 int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, int B, int T, int k, const float* tau_in,
                   bool coarse_tau = false) {
     const bool wide = s->wide_select == 1 || (s->wide_select < 0 && w.cand_cap >= kWideSelectCap);
     if (!wide) {
         ApproxConsts ac = s->approx_consts;
-        ac.dc_max = w.x1_table ? s->dc_f16 : 0.f;
+        ac.dc_max = bound_dc(s, w);
         // tuning builds: CLB_DEBUG_EPS_T_ADD_1E6 widens the per-(token, embedding) bound by about that many millionths
         // through the inv_norm quantisation term (1.01 * inv_qerr * qn * (cn + rn)) -- what a coarser score-table format
         // would cost pass 2 (lists and row masks grow), measured on the real pipeline with correct results
@@ -605,7 +613,7 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
     CLB_HIP(hipMemsetAsync(w.wsel.p, 0, sizeof(WideSel) * B, st));
     const dim3 grid(kWideBlocks, B);
     ApproxConsts acw = s->approx_consts;
-    acw.dc_max = w.x1_table ? s->dc_f16 : 0.f;
+    acw.dc_max = bound_dc(s, w);
     hipLaunchKernelGGL(wide_minmax_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, w.cand_cap,
                        acw, w.wsel.as<WideSel>(), w.eps_pair.as<float>());
     if (!tau_in)
@@ -1074,13 +1082,13 @@ int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
 int clb_searcher_set_centroid_products(clb_searcher* s, int n) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
     if (n != -1 && n != 1 && n != 3) return fail(CLB_EARGUMENT, "centroid products must be -1 (default), 1 (one fp16 product) or 3 (bf16 split)");
-    s->s1_x1 = n == 1 ? 1 : 0;
+    s->s1_x1 = n == 1 ? 1 : n == 3 ? 0 : -1;
     return CLB_OK;
 }
 int clb_searcher_get_centroid_products(const clb_searcher* s, float* max_f16_error) {
     if (!s) return -1;
     if (max_f16_error) *max_f16_error = s->dc_f16;
-    return s->s1_x1 == 1 && s->cent_f16.p && s->dc_f16 > 0.f ? 1 : 3;
+    return (s->s1_x1 == 1 || (s->s1_x1 < 0 && s->bounds_synced)) && s->cent_f16.p && s->dc_f16 > 0.f ? 1 : 3;
 }
 
 int clb_searcher_get_bound_consts(const clb_searcher* s, float* consts) {

@@ -115,7 +115,7 @@ class Searcher:
         return int(lib().clb_searcher_get_pass1_gather(self._h, C.byref(adj))), adj.value
 
     def set_centroid_products(self, n: int):
-        """Batches of 16+ queries, two-pass mode: 1 = score table from one fp16 product, 3 = the bf16 split (the default, -1)."""
+        """Batches of 16+ queries, two-pass mode: 1 = score table from one fp16 product, 3 = the bf16 split, -1 = default (1 on a shard of a group, 3 on one GPU)."""
         check(lib().clb_searcher_set_centroid_products(self._h, C.c_int(n)))
 
     @property

@@ -133,9 +133,11 @@ int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency);
 /* Products of the batched centroid stage (the Q x centroids GEMM of ranking.jl:9-13 for batches of 16 or more queries in
  * the two-pass mode; no call site of its own in the reference): n = 1, the fp16 score table of pass 1 is made from ONE fp16
  * product per fp32 product, with the measured conversion errors of both operands in the error bound; n = 3, from the
- * three-product bf16 split (every smaller batch always is); n = -1, the default: 3 -- measured on the 1 M-passage workload the
- * single product takes 0.020 ms off the centroid kernel (0.104 -> 0.084) and its wider bound (+12 % re-scored rows) puts
- * 0.01-0.02 ms back on pass 2.  n = 1 on an index with a centroid component outside the fp16 range stays at 3.  Results are
+ * three-product bf16 split (every smaller batch always is); n = -1, the default: 1 on a shard of a group (a handle that
+ * clb_searcher_set_bound_consts / clb_searcher_sync_bound_consts has been called on), 3 on a single GPU -- measured on the
+ * 1 M-passage workload the single product takes 0.020 ms off the centroid kernel (0.104 -> 0.084) and its wider bound
+ * (+12 % re-scored rows) puts 0.01-0.02 ms back on pass 2; on N shards the centroid stage is replicated and the extra rows
+ * are divided by N.  n = 1 on an index with a centroid component outside the fp16 range stays at 3.  Results are
  * identical either way (the nprobe best centroids are re-scored in canonical fp32, the table only feeds the approximate pass,
  * whose bound carries the difference).  The getter returns the count in use for such batches and, through *max_f16_error
  * (may be null), max over the centroids of ||c - fp16(c)|| (0: out of range). */

@@ -618,16 +618,18 @@ def test_bench_sharding_path_matches_unsharded(oracle):
         s.close()
 
 
-@pytest.mark.parametrize("world,k,wide", [(4, 200, -1), (8, 1000, -1), (2, 5000, -1), (4, 200, 1), (2, 5000, 1)])
-def test_two_phase_sharded_search(oracle, world, k, wide):
+@pytest.mark.parametrize("world,k,wide,nq", [(4, 200, -1, 9), (8, 1000, -1, 19), (2, 5000, -1, 9), (4, 200, 1, 19), (2, 5000, 1, 9),
+                                             (2, 300, -1, 32)])
+def test_two_phase_sharded_search(oracle, world, k, wide, nq):
     """clb_search_shard_phase1/2 on `world` shards of one index (the all-gather is simulated by stacking the shards'
     score blocks): every shard cuts at the global k-th approximate score, the merged result equals the oracle's on
     the full index, and the shards together list far fewer passages than with shard-local thresholds.  k = 5000
-    exceeds what some queries can return (padding, tau = -inf)."""
+    exceeds what some queries can return (padding, tau = -inf).  Batches of 16+ queries on shards that share a bound build
+    their score table from one fp16 product (clb_searcher_set_centroid_products' default on a shard group): nq = 19."""
     torch = pytest.importorskip("torch")
     from colbert_jl_amd.distributed import DeviceSearch, merge_packed, share_bound_consts
     full = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8)
-    Qs = synthetic.make_topic_queries(full["centroids"], seed=78, n_queries=9)
+    Qs = synthetic.make_topic_queries(full["centroids"], seed=78, n_queries=nq)
     Qdev = torch.from_numpy(np.ascontiguousarray(Qs.transpose(2, 1, 0))).cuda()
     per = 8 // world
     kk = min(k, 4096)
@@ -636,23 +638,24 @@ def test_two_phase_sharded_search(oracle, world, k, wide):
         sh = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8, blocks=range(per * rank, per * rank + per))
         s = clb.Searcher(index=sh, pid_offset=int(sh["pid_offset"]))
         s.set_wide_select(wide)                                          # 1: the sixteen-work-group selection in both phases
-        runs.append(DeviceSearch(s, 32, 9, kk, 2)); keep.append(s)
+        runs.append(DeviceSearch(s, 32, nq, kk, 2)); keep.append(s)
     tops = torch.stack([r.phase1(Qdev).clone() for r in runs])           # (world, B, k) as an all-gather delivers
     torch.cuda.synchronize()
     # the protocol checks itself: phase 2 against other shards' scores is refused until the shards share ONE error bound
     with pytest.raises(clb.ArgumentError):
         runs[0].phase2(Qdev, tops)
     share_bound_consts(keep)
+    assert all(s.centroid_products[0] == 1 for s in keep)                 # a shard group: single-product tables for 16+ queries
     runs[0].phase1(Qdev)                                                  # (the refused call consumed nothing; redo phase 1)
     packed = []
     for r in runs:
         r.phase2(Qdev, tops)
         torch.cuda.synchronize()
         packed.append(r.packed.clone())
-    mp, ms = merge_packed(torch.stack(packed), 9, kk)
+    mp, ms = merge_packed(torch.stack(packed), nq, kk)
     torch.cuda.synchronize()
     mp = mp.cpu().numpy(); ms = ms.cpu().numpy()
-    for j in range(9):
+    for j in range(nq):
         n_all = oracle.retrieve(full["ivf"], full["ivf_lengths"], full["centroids"],
                                 oracle.build_emb2pid(full["doclens"]), 2, Qs[:, :, j]).size
         ke = min(kk, n_all)
