@@ -27,6 +27,8 @@ struct Stream {
 struct NearestScratch {
     DevBuf hi, lo, bias, partial, cn;    // hi: the bf16 hi plane, or the one fp16 plane of the single-product lists (lo unused then)
     DevBuf ovf_list, ovf_count, ovf_keys;   // points whose candidate lists overflowed (near / mass ties): re-scored against all centroids
+    // second tier (single-product lists only): the undecided points as a dense block, decided by the three-product lists
+    DevBuf hi3, lo3, cn3, xc, codes_c, partial_c, ovf2_list, ovf2_count, ovf2_keys;
 };
 
 // device-side: codes (1-based UInt32) of n embeddings against K centroids; MODE 0 argmax dot, 1 k-means.
@@ -88,6 +90,7 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
         CLB_TRY(w.ovf_count.ensure(sizeof(unsigned int)));
         CLB_TRY(w.ovf_keys.ensure(sizeof(unsigned long long) * (size_t)std::min(n, chunk_max)));
         const size_t lds = 2 * 2 * 32 * kRowBytes16;
+        bool tier2_ready = false;       // the bf16 split of THIS call's centroids exists (built when the first chunk needs it)
         for (int64_t p0 = 0; p0 < n; p0 += chunk_max) {
             const int64_t m = std::min(chunk_max, n - p0);
             const int groups32 = (int)((m + 31) / 32);                  // "queries" of 32 points
@@ -120,21 +123,80 @@ if (dma && MODE == 1)
             hipLaunchKernelGGL(nearest_refine_kernel<MODE>, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st,
                                w.partial.as<ValIdx>(), dC, dc2, dX + (size_t)p0 * kDim, m, K, w.cn.as<unsigned int>(),
                                dOut + p0, w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>());
-            // the overflow list (a few dozen points per million; empty: the launch reads a zero and ends) on the fp32 MFMA, all K
-            // centroids per point, the centroid tiles dealt to `slices` work-groups per pair of 32-point tiles
+            // The undecided points.  Three-product lists: straight to the exhaustive scan (the list is normally empty: the launch
+            // reads a zero and ends).  Single-product lists: a few dozen points per million on well-spread data, but 2.5 % on nearly
+            // degenerate embeddings (a random-weight encoder), where the exhaustive scan of them cost as much as the lists of all
+            // points -- so more than a handful go through the three-product lists first (their margin is five times tighter) and
+            // only what THOSE cannot decide is scanned.  One 4-byte read-back per chunk of up to 4 M points.
             const int slices = std::max(1, std::min(n_tiles / 8, 128));
-            const int pairs = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / slices, (m + 63) / 64));
-            hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3(pairs, slices), dim3(128),
-                               2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX + (size_t)p0 * kDim,
-                               w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>());
-            hipLaunchKernelGGL(nearest_list_finalize_kernel, dim3(64), dim3(256), 0, st, w.ovf_list.as<uint32_t>(),
-                               w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>(), dOut + p0);
-            if (getenv("COLBERT_DEBUG_NEAREST")) {      // how many points took the exhaustive path (a wait per chunk: debugging only)
+            unsigned int undecided = 0, undecided2 = 0;
+            if (x1) {
+                CLB_HIP(hipMemcpyAsync(&undecided, w.ovf_count.p, sizeof undecided, hipMemcpyDeviceToHost, st));
+                CLB_HIP(hipStreamSynchronize(st));
+            }
+            if (x1 && undecided > 64) {
+                const int64_t mc = undecided;
+                if (!tier2_ready) {
+                    CLB_TRY(w.hi3.ensure(sizeof(uint16_t) * cel));
+                    CLB_TRY(w.lo3.ensure(sizeof(uint16_t) * cel));
+                    CLB_TRY(w.cn3.ensure(2 * sizeof(unsigned int)));
+                    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((cel + 255) / 256)), dim3(256), 0, st, dC,
+                                       w.hi3.as<uint16_t>(), w.lo3.as<uint16_t>(), (int64_t)cel);
+                    CLB_HIP(hipMemsetAsync(w.cn3.p, 0, 2 * sizeof(unsigned int), st));          // [1] = 0: the three-product margin
+                    CLB_HIP(hipMemcpyAsync(w.cn3.p, w.cn.p, sizeof(unsigned int), hipMemcpyDeviceToDevice, st));
+                    tier2_ready = true;
+                }
+                CLB_TRY(w.xc.ensure(sizeof(float) * kDim * (size_t)mc));
+                CLB_TRY(w.codes_c.ensure(sizeof(uint32_t) * (size_t)mc));
+                CLB_TRY(w.partial_c.ensure(sizeof(ValIdx) * (size_t)((mc + 31) / 32) * 2 * 32 * kTopPartial));
+                CLB_TRY(w.ovf2_list.ensure(sizeof(uint32_t) * (size_t)mc));
+                CLB_TRY(w.ovf2_keys.ensure(sizeof(unsigned long long) * (size_t)mc));
+                CLB_TRY(w.ovf2_count.ensure(sizeof(unsigned int)));
+                hipLaunchKernelGGL(gather_points_kernel, dim3(blocks_for(mc * 32)), dim3(256), 0, st, dX + (size_t)p0 * kDim,
+                                   w.ovf_list.as<uint32_t>(), mc, w.xc.as<float>());
+                const int groups_c = (int)((mc + 31) / 32);
+                const dim3 grid_c(1, (unsigned)((groups_c + kMqQueries - 1) / kMqQueries));
+                if (MODE == 1)
+                    hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, true>), grid_c, dim3(256), lds, st,
+                                       w.hi3.as<uint16_t>(), w.lo3.as<uint16_t>(), w.xc.as<float>(), w.partial_c.as<ValIdx>(),
+                                       (uint32_t*)nullptr, K, 32, groups_c, n_tiles, w.bias.as<float>(), mc);
+                else
+                    hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, false>), grid_c, dim3(256), lds, st,
+                                       w.hi3.as<uint16_t>(), w.lo3.as<uint16_t>(), w.xc.as<float>(), w.partial_c.as<ValIdx>(),
+                                       (uint32_t*)nullptr, K, 32, groups_c, n_tiles, (const float*)nullptr, mc);
+                CLB_HIP(hipMemsetAsync(w.ovf2_count.p, 0, sizeof(unsigned int), st));
+                hipLaunchKernelGGL(nearest_refine_kernel<MODE>, dim3((unsigned)((mc + 15) / 16)), dim3(256), 0, st,
+                                   w.partial_c.as<ValIdx>(), dC, dc2, w.xc.as<float>(), mc, K, w.cn3.as<unsigned int>(),
+                                   w.codes_c.as<uint32_t>(), w.ovf2_list.as<uint32_t>(), w.ovf2_count.as<unsigned int>(),
+                                   w.ovf2_keys.as<unsigned long long>());
+                const int pairs = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / slices, (mc + 63) / 64));
+                hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3(pairs, slices), dim3(128),
+                                   2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, w.xc.as<float>(),
+                                   w.ovf2_list.as<uint32_t>(), w.ovf2_count.as<unsigned int>(), w.ovf2_keys.as<unsigned long long>());
+                hipLaunchKernelGGL(nearest_list_finalize_kernel, dim3(64), dim3(256), 0, st, w.ovf2_list.as<uint32_t>(),
+                                   w.ovf2_count.as<unsigned int>(), w.ovf2_keys.as<unsigned long long>(), w.codes_c.as<uint32_t>());
+                hipLaunchKernelGGL(scatter_codes_kernel, dim3(blocks_for(mc)), dim3(256), 0, st, w.ovf_list.as<uint32_t>(), mc,
+                                   w.codes_c.as<uint32_t>(), dOut + p0);
+                if (getenv("COLBERT_DEBUG_NEAREST")) {
+                    CLB_HIP(hipMemcpyAsync(&undecided2, w.ovf2_count.p, sizeof undecided2, hipMemcpyDeviceToHost, st));
+                    CLB_HIP(hipStreamSynchronize(st));
+                }
+            } else {
+                // on the fp32 MFMA, all K centroids per point, the centroid tiles dealt to `slices` work-groups per pair of 32-point tiles
+                const int pairs = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / slices, (m + 63) / 64));
+                hipLaunchKernelGGL(nearest_centroid_mfma_list_kernel<MODE>, dim3(pairs, slices), dim3(128),
+                                   2 * 32 * kCentTileStride * sizeof(float), st, dC, dc2, K, dX + (size_t)p0 * kDim,
+                                   w.ovf_list.as<uint32_t>(), w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>());
+                hipLaunchKernelGGL(nearest_list_finalize_kernel, dim3(64), dim3(256), 0, st, w.ovf_list.as<uint32_t>(),
+                                   w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>(), dOut + p0);
+            }
+            if (getenv("COLBERT_DEBUG_NEAREST")) {      // how many points the lists left undecided (a wait per chunk: debugging only)
                 unsigned int cnt = 0;
                 CLB_HIP(hipMemcpyAsync(&cnt, w.ovf_count.p, sizeof cnt, hipMemcpyDeviceToHost, st));
                 CLB_HIP(hipStreamSynchronize(st));
-                fprintf(stderr, "nearest_centroids<%d>: %lld points, K = %d, %s lists, %u re-scored against all centroids\n", MODE,
-                        (long long)m, K, x1 ? "fp16 x1" : "bf16 x3", cnt);
+                fprintf(stderr, "nearest_centroids<%d>: %lld points, K = %d, %s lists, %u undecided, %u of them also by the bf16 x3 lists "
+                        "(scanned against all centroids: %u)\n", MODE, (long long)m, K, x1 ? "fp16 x1" : "bf16 x3", cnt,
+                        x1 && cnt > 64 ? undecided2 : 0u, x1 && cnt > 64 ? undecided2 : cnt);
             }
         }
     } else if (dim == kDim) {

@@ -758,15 +758,25 @@ static __global__ __launch_bounds__(128) void nearest_centroid_mfma_list_kernel(
         if (MODE == 1) x2 = sumsq_canonical(xrow, kDim);
         float bestv = 0.f;
         int best = 0x7fffffff;
+        // the next tile's 16 float4 per lane are requested before this tile's 64 MFMAs and stored to LDS after them
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));      // (an array of HIP's float4 structs stays in scratch here)
+        f32x4_t nx[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            int c = t_lo * 32 + 2 * m + h;
+            c = c < K ? c : K - 1;
+            nx[m] = *reinterpret_cast<const f32x4_t*>(C + (size_t)c * kDim + 4 * i);
+        }
         for (int tile = t_lo; tile < t_hi; ++tile) {
             const int c0 = tile * 32;
 #pragma unroll
+            for (int m = 0; m < 16; ++m) *reinterpret_cast<f32x4_t*>(my + (2 * m + h) * kCentTileStride + 4 * i) = nx[m];
+            const int cn0 = tile + 1 < t_hi ? c0 + 32 : c0;             // (the last iteration re-reads its own tile)
+#pragma unroll
             for (int m = 0; m < 16; ++m) {
-                const int row = 2 * m + h;
-                int c = c0 + row;
+                int c = cn0 + 2 * m + h;
                 c = c < K ? c : K - 1;
-                float4 v = *reinterpret_cast<const float4*>(C + (size_t)c * kDim + 4 * i);
-                *reinterpret_cast<float4*>(my + row * kCentTileStride + 4 * i) = v;
+                nx[m] = *reinterpret_cast<const f32x4_t*>(C + (size_t)c * kDim + 4 * i);
             }
             __builtin_amdgcn_wave_barrier();
             f32x16 acc;
@@ -902,6 +912,20 @@ static __global__ __launch_bounds__(256) void nearest_refine_kernel(const ValIdx
         if (take) { bestv = ov; best = oi; }
     }
     if (sub == 0 && p < n) out[p] = (uint32_t)(best + 1);
+}
+
+// Second tier of the nearest-centroid search (codec.hip): the points the single-product lists could not decide are copied
+// into a dense block, decided there by the three-product lists (a five times tighter margin), and their codes copied back.
+static __global__ __launch_bounds__(256) void gather_points_kernel(const float* __restrict__ X, const uint32_t* __restrict__ list,
+                                                                   int64_t count, float* __restrict__ Xc) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 per thread, 32 per point
+    if (t >= count * 32) return;
+    reinterpret_cast<float4*>(Xc)[t] = reinterpret_cast<const float4*>(X)[(size_t)list[t >> 5] * 32 + (t & 31)];
+}
+static __global__ void scatter_codes_kernel(const uint32_t* __restrict__ list, int64_t count, const uint32_t* __restrict__ codes_c,
+                                            uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[list[t]] = codes_c[t];
 }
 
 static __global__ void half_neg_kernel(const float* __restrict__ c2, int K, float* __restrict__ out, int n_out) {

@@ -134,6 +134,51 @@ def _device_route_fits(indexer: Indexer) -> bool:
     return need < 0.8 * free
 
 
+class _BackgroundWriter:
+    """The index directory's files are written by ONE worker thread while the device goes on (k-means runs while the 7-GB sample
+    is transposed and written, chunk i + 1 is encoded while chunk i's codes and residuals go to disk): a callback hands over
+    device tensors that nobody modifies any more (each chunk's residuals are their own allocation, the codes a slice of the
+    final array, both complete -- the caller has waited for the device), the worker copies them to the host and saves them.
+    At most `depth` jobs wait (a job holds a chunk's tensors alive).  The first exception is re-raised by finish()."""
+
+    def __init__(self, depth: int = 4):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=depth)
+        self.error = None
+        self.busy_s = 0.0
+        self.t = threading.Thread(target=self._run, name="colbert-index-writer", daemon=True)
+        self.t.start()
+
+    def _run(self):
+        import time
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            if self.error is None:
+                t0 = time.time()
+                try:
+                    job()
+                except BaseException as e:                   # noqa: BLE001 -- handed to the caller's thread by finish()
+                    self.error = e
+                self.busy_s += time.time() - t0
+
+    def submit(self, job):
+        if self.error is not None:
+            self.finish()
+        self.q.put(job)
+
+    def finish(self):
+        """Drain the queue, stop the worker, raise what it caught."""
+        if self.t.is_alive():
+            self.q.put(None)
+            self.t.join()
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+
 def _index_through_device(indexer: Indexer) -> str:
     """index() over index_device: the encoder's output, the sample, the codes and the residuals stay in HBM; what is
     written is the reference's directory (sample, sample_heldout, plan.json, config.json, the codec, per chunk codes /
@@ -146,34 +191,42 @@ def _index_through_device(indexer: Indexer) -> str:
     t_tok = time.time() - t0
     os.makedirs(path)
     state = {"write_s": 0.0}
+    writer = _BackgroundWriter()
 
     def on_sample(sample, heldout, plan):
         t1 = time.time()
-        storage._save(os.path.join(path, "sample"), np.asfortranarray(sample.cpu().numpy().T))
-        storage._save(os.path.join(path, "sample_heldout"), np.asfortranarray(heldout.cpu().numpy().T))
         storage.save_json(path, "plan.json", plan)
         cfg.save(path)
         state["plan"] = plan
+
+        def job():
+            storage._save(os.path.join(path, "sample"), np.asfortranarray(sample.cpu().numpy().T))
+            storage._save(os.path.join(path, "sample_heldout"), np.asfortranarray(heldout.cpu().numpy().T))
+        writer.submit(job)
         state["write_s"] += time.time() - t1
 
     counts = []
 
     def on_codec(centroids, cut, w, avg):
         t1 = time.time()
-        storage.save_codec(path, np.asfortranarray(centroids.cpu().numpy().T), cut, w, avg)
+        writer.submit(lambda: storage.save_codec(path, np.asfortranarray(centroids.cpu().numpy().T), cut, w, avg))
         state["write_s"] += time.time() - t1
 
     def on_chunk(ci, start, end, codes, residuals, doclens):
         # a chunk's files are written as soon as it is compressed (collection_indexer.jl:271-297): a failure later on leaves
         # nothing half-described, and only the codes (for the IVF) outlive the chunk on the device
         t1 = time.time()
-        storage.save_chunk(path, codes.cpu().numpy().view(np.uint32), np.asfortranarray(residuals.cpu().numpy().T), ci, start + 1, doclens)
+        writer.submit(lambda: storage.save_chunk(path, codes.cpu().numpy().view(np.uint32), np.asfortranarray(residuals.cpu().numpy().T),
+                                                 ci, start + 1, doclens))
         counts.append(int(codes.numel()))
         state["write_chunks_s"] = state.get("write_chunks_s", 0.0) + time.time() - t1
 
-    ix, rec = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
-                           nranks=cfg.nranks, on_sample=on_sample, on_codec=on_codec, on_chunk=on_chunk, keep_residuals=False)
-    t_w = time.time()
+    try:
+        ix, rec = index_device(source, nbits=cfg.nbits, kmeans_niters=cfg.kmeans_niters, chunksize=cfg.chunksize, rng=indexer.rng,
+                               nranks=cfg.nranks, on_sample=on_sample, on_codec=on_codec, on_chunk=on_chunk, keep_residuals=False)
+    finally:
+        t_w = time.time()
+        writer.finish()                  # every chunk's files exist (or the writer's exception surfaces) before the metadata pass
     plan = state["plan"]
     total, offsets = codec.collect_embedding_id_offset(counts)
     plan["num_embeddings"] = total
@@ -188,7 +241,8 @@ def _index_through_device(indexer: Indexer) -> str:
     assert storage.check_all_files_are_saved(path)
     # seconds per stage of this build (tools/bench_index_with_encoder.py): sample_and_split_s and chunks_s are encoder time
     rec.update({"tokenize_s": round(t_tok, 3), "write_sample_s": round(state["write_s"], 3),
-                "write_index_s": round(time.time() - t_w + state.get("write_chunks_s", 0.0), 3)})
+                "write_index_s": round(time.time() - t_w + state.get("write_chunks_s", 0.0), 3),
+                "writer_thread_busy_s": round(writer.busy_s, 3)})
     indexer.last_build_record = rec
     return path
 
