@@ -167,6 +167,8 @@ class _BackgroundWriter:
     def submit(self, job):
         if self.error is not None:
             self.finish()
+        if not self.t.is_alive():
+            raise RuntimeError("the index writer has been stopped")
         self.q.put(job)
 
     def finish(self):

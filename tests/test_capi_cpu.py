@@ -285,3 +285,38 @@ def test_hand_issued_lds_dma_is_the_only_user_of_m0():
     problems, kernels, dmas = mod.check(clb._lib.LIB_PATH, verbose=False)
     assert not problems, problems[:5]
     assert kernels >= 3 and dmas >= 8          # pass 1's GL = 1 gather and the plane GEMMs are in the library
+
+
+def test_index_file_writer_thread_keeps_order_and_hands_back_errors(tmp_path):
+    """indexer._BackgroundWriter (round 5: the index directory is written while the device goes on): jobs run in submission
+    order on one thread, finish() drains them, the first exception surfaces in the caller's thread (from a later submit or
+    from finish) and nothing after it runs."""
+    import threading
+    import time
+    from colbert_jl_amd.indexer import _BackgroundWriter
+    w = _BackgroundWriter(depth=2)
+    seen, main = [], threading.get_ident()
+
+    def job(i):
+        def run():
+            time.sleep(0.01)
+            seen.append((i, threading.get_ident() != main))
+        return run
+    for i in range(6):                       # more jobs than the queue holds: submit blocks instead of piling tensors up
+        w.submit(job(i))
+    w.finish()
+    assert seen == [(i, True) for i in range(6)] and w.busy_s > 0.05
+    w.finish()                               # idempotent
+
+    w = _BackgroundWriter()
+    ran = []
+    w.submit(lambda: ran.append(1))
+    w.submit(lambda: (_ for _ in ()).throw(OSError("disk full")))
+    with pytest.raises(OSError, match="disk full"):
+        for _ in range(50):                  # queued behind the failure: skipped (the directory is already known to be incomplete);
+            w.submit(lambda: ran.append(2))  # once the worker has met it, submit itself raises
+            time.sleep(0.005)
+        w.finish()
+    assert ran == [1]
+    with pytest.raises(RuntimeError):
+        w.submit(lambda: None)
