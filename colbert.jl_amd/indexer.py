@@ -125,8 +125,8 @@ def _device_route_fits(indexer: Indexer) -> bool:
     n_docs = len(indexer.collection)
     maxlen = int(getattr(indexer.encoder.config, "doc_maxlen", cfg.doc_maxlen))
     chunk = int(cfg.chunksize or min(25000, 1 + n_docs))
-    need = n_docs * maxlen * 28 + min(chunk, n_docs) * maxlen * (4 * cfg.dim + cfg.dim // 8 * cfg.nbits) \
-        + codec.num_sampled_pids(n_docs) * maxlen * 4 * cfg.dim * 2
+    need = n_docs * maxlen * 28 + min(chunk, n_docs) * maxlen * (2 * 4 * cfg.dim + cfg.dim // 8 * cfg.nbits) \
+        + codec.num_sampled_pids(n_docs) * maxlen * 4 * cfg.dim * 3
     try:
         free, _ = codec.device_memory(indexer.device)
     except Exception:
@@ -244,7 +244,8 @@ def _index_through_device(indexer: Indexer) -> str:
     # seconds per stage of this build (tools/bench_index_with_encoder.py): sample_and_split_s and chunks_s are encoder time
     rec.update({"tokenize_s": round(t_tok, 3), "write_sample_s": round(state["write_s"], 3),
                 "write_index_s": round(time.time() - t_w + state.get("write_chunks_s", 0.0), 3),
-                "writer_thread_busy_s": round(writer.busy_s, 3)})
+                "writer_thread_busy_s": round(writer.busy_s, 3),
+                "sampled_passages_not_encoded_twice": int(getattr(source, "reused_passages", 0))})
     indexer.last_build_record = rec
     return path
 
@@ -455,19 +456,22 @@ class EncoderSource(DeviceEmbeddingSource):
     def _expected(self, pids):
         return self._doclens[np.asarray(pids, dtype=np.int64)] if self._doclens is not None else self._doclens_of(pids)
 
-    def encode_pids(self, pids):
+    def encode_pids(self, pids, out=None):
         """encode_passages of the passages `pids` (batches of index_bsize, in this order) with the result left on the
-        device -> (n, dim) float32 CUDA tensor.  Only enqueues, then checks the device's doclens once."""
+        device -> (n, dim) float32 CUDA tensor (`out`, if given: a contiguous buffer of exactly that shape).  Only enqueues,
+        then checks the device's doclens once."""
         import torch
         pids = np.asarray(pids, dtype=np.int64)
         if pids.size == 0:
-            return torch.empty((0, self.dim), dtype=torch.float32, device=self.device)
+            return torch.empty((0, self.dim), dtype=torch.float32, device=self.device) if out is None else out
         # packed batches need no common length: several index_bsize batches go into one call (rows, not passages, fill the chip)
         bs = self.encoder.config.index_bsize * (self.pack_batches if self.packed else 1)
         # ONE output buffer: every batch's kept rows are written by the encoder's epilogue straight into its slice (what a
         # batch keeps follows from its tokens alone), no concatenation afterwards
         expected = self._expected(pids)
-        out = torch.empty((int(expected.sum()), self.dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((int(expected.sum()), self.dim), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and tuple(out.shape) == (int(expected.sum()), self.dim)
         lens, fill, first = [], 0, 0
         # whether the encoder packs at all is learnt from the first call's first batch (a fixed number of passages): if it does not,
         # every batch is a padded batch of index_bsize passages counted from the first one -- the batches of the host route
@@ -521,11 +525,61 @@ class EncoderSource(DeviceEmbeddingSource):
         """The whole collection -> ((n, dim) CUDA tensor, doclens)."""
         return self.encode_pids(np.arange(self.n_docs)), self.doclens.copy()
 
-    def chunk(self, start: int, end: int):
-        return self.encode_pids(np.arange(start, end))
+    # The sampled passages are encoded for training (collection_indexer.jl:56-79) and, in the reference, once more with their
+    # chunk.  Here their embeddings stay in HBM (1 M passages: 175 k of them, 7.4 GB) and a chunk encodes only its OTHER
+    # passages -- into the tail of the same buffer -- and is cut out of that buffer in passage order with one
+    # clb_gather_rows_device.  Packed batches only: their embeddings already depend on the batch a passage travels in (the tile
+    # plan's rounding); the padded route stays batch for batch what encode_passages does, so that its index directory is the host
+    # route's byte for byte.  COLBERT_REUSE_SAMPLE=0 encodes every chunk in full.
+    _cache = None
+
+    def _chunk_rows_bound(self):
+        return min(25000, self.n_docs) * self._maxlen                  # setup(): chunksize <= 25 000 passages
 
     def sample(self, pids):
-        return self.encode_pids(pids)
+        import torch
+        pids = np.asarray(pids, dtype=np.int64)
+        sorted_unique = pids.size > 0 and bool(np.all(np.diff(pids) > 0))
+        if not (self.packed and sorted_unique and os.environ.get("COLBERT_REUSE_SAMPLE", "1") != "0"):
+            return self.encode_pids(pids)
+        expected = self._expected(pids)
+        n_rows = int(expected.sum())
+        try:
+            buf = torch.empty((n_rows + self._chunk_rows_bound(), self.dim), dtype=torch.float32, device=self.device)
+        except RuntimeError:                                            # no room for the tail: the plain route
+            return self.encode_pids(pids)
+        self.encode_pids(pids, out=buf[:n_rows])
+        if self.packed:                                                 # (the first call may have found that the encoder cannot pack)
+            self._cache = {"pids": pids, "off": np.concatenate([[0], np.cumsum(expected)]).astype(np.int64), "buf": buf, "n": n_rows}
+        return buf[:n_rows]
+
+    def chunk(self, start: int, end: int):
+        from . import codec
+        c = self._cache
+        pids = np.arange(start, end, dtype=np.int64)
+        if c is None:
+            return self.encode_pids(pids)
+        if end >= self.n_docs:
+            self._cache = None                                          # the last chunk: the buffer goes with it
+        i0, i1 = (int(v) for v in np.searchsorted(c["pids"], [start, end]))
+        if i0 == i1:
+            return self.encode_pids(pids)
+        known = np.zeros(end - start, dtype=bool)
+        known[c["pids"][i0:i1] - start] = True
+        dl = np.asarray(self._expected(pids), dtype=np.int64)
+        assert np.array_equal(dl[known], np.diff(c["off"][i0:i1 + 1]))
+        n_new = int(dl[~known].sum())
+        if n_new > c["buf"].shape[0] - c["n"]:
+            return self.encode_pids(pids)                               # (a chunk larger than setup() makes them)
+        if n_new:
+            self.encode_pids(pids[~known], out=c["buf"][c["n"]:c["n"] + n_new])
+        src = np.empty(end - start, dtype=np.int64)                     # first source row of every passage
+        src[known] = c["off"][i0:i1]
+        src[~known] = c["n"] + np.concatenate([[0], np.cumsum(dl[~known])[:-1]])
+        dst = np.concatenate([[0], np.cumsum(dl)[:-1]])
+        rows = np.repeat(src - dst, dl) + np.arange(int(dl.sum()), dtype=np.int64)
+        self.reused_passages = getattr(self, "reused_passages", 0) + int(known.sum())
+        return codec.gather_rows_device(c["buf"], rows)
 
 
 def index_device(source: DeviceEmbeddingSource, nbits: int = 2, kmeans_niters: int = 20, chunksize=None, seed: int = 0,

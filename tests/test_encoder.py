@@ -582,7 +582,21 @@ def test_packed_passage_batches_match_padded_ones(tok):
     assert float((a - b).abs().max()) < 5e-5
     assert torch.allclose(a.norm(dim=1), torch.ones(a.shape[0], device=a.device), atol=1e-5)
     some = np.array([3, 4, 20, 36])
-    assert float((packed.sample(some) - padded.sample(some)).abs().max()) < 5e-5
+    smp = packed.sample(some)
+    assert float((smp - padded.sample(some)).abs().max()) < 5e-5
+    # round 5: the sampled passages' embeddings are kept and a chunk encodes only its other passages (packed route only):
+    # the chunk in passage order, the sampled passages' rows the sample's bit for bit, the others as any packed batch
+    assert packed._cache is not None and padded._cache is None
+    off = np.concatenate([[0], np.cumsum(packed.doclens)])
+    soff = np.concatenate([[0], np.cumsum(packed.doclens[some])])
+    for lo, hi in ((0, 20), (20, 37)):
+        x = packed.chunk(lo, hi)
+        assert x.shape[0] == off[hi] - off[lo]
+        assert float((x - a[off[lo]:off[hi]]).abs().max()) < 5e-5
+        for j, pid in enumerate(some):
+            if lo <= pid < hi:
+                assert torch.equal(x[off[pid] - off[lo]:off[pid + 1] - off[lo]], smp[soff[j]:soff[j + 1]])
+    assert packed.reused_passages == 4 and packed._cache is None      # released with the last chunk
     # packed sequences of different lengths through the LDS-shared K / V tiles == every wave loading its own, bit for bit
     enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_lds")
     a_pw = EncoderSource(enc_pw, collection, 0, packed=True).encode_pids(order)
