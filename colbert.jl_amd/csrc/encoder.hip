@@ -13,6 +13,8 @@
 
 using namespace clb;
 
+namespace clb { bool launch_planes2_wide(hipStream_t st, int ln_mode, const GemmPArgs& g, unsigned grid); }   // encoder_big.hip
+
 struct clb_encoder {
     int device = 0;
     int64_t vocab = 0, H = 0, layers = 0, heads = 0, I = 0, max_pos = 0, type_vocab = 0, dim = 0;
@@ -253,10 +255,19 @@ struct LnFold {
 
 // the LN instantiations: 1 = consumer (64 x 64 for the projection's 128 columns, 128 x 128 behind GELU, 128 x 256 in front of the
 // attention), 2 = producer (the big plain tiles)
+// COLBERT_ENC_WIDE_WAVES=1: the 256 x 256 tile as four waves of 128 x 128 (encoder_big.hip: a third fewer LDS reads per MFMA,
+// accumulators in AGPRs) instead of eight of 64 x 128 -- bit-identical and SLOWER (a 64 x 300 batch 16.6 against 13.9 ms: with
+// one wave per SIMD nothing covers the barrier and the DMA wait of every step); kept for comparison runs (tools/r5_wide_waves.py)
+static bool wide_waves() {
+    static const bool v = [] { const char* e = getenv("COLBERT_ENC_WIDE_WAVES"); return e && atoi(e) == 1; }();
+    return v;
+}
+
 bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
     const size_t lds = (size_t)c.stages * 2 * (c.bm + c.bn) * 64;
     const int mode = g.ln_u ? 1 : 2;
+    if (c.bm == 256 && c.bn == 256 && c.stages == 2 && wide_waves()) return launch_planes2_wide(st, mode, g, grid.x);
 #define CLB_GPL_CASE(MODE_, BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                      \
     if (mode == MODE_ && c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                             \
         auto kern = gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, 2, ST_, 0, true, MODE_>;                                \
@@ -275,6 +286,7 @@ bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
     const size_t lds = (size_t)c.stages * NS * (c.bm + c.bn) * 64;
     const bool second = g.N % 4 == 0 && !planes_first_form();
+    if (NS == 2 && F16 && second && c.bm == 256 && c.bn == 256 && c.stages == 2 && wide_waves()) return launch_planes2_wide(st, 0, g, grid.x);
 #define CLB_GP_CASE(BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                              \
     if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
         auto kern = second ? gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16> : gemm_planes_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16>; \
