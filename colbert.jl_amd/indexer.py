@@ -294,6 +294,19 @@ def _sample_from_chunks(source, pids, step: Optional[int] = None):
     return out
 
 
+def _chunk_source_rows(known, doclens, known_first_row, n_cached_rows):
+    """Row of the buffer [cached sample rows | this chunk's newly encoded rows] behind every embedding of a chunk, in passage order:
+    passage j (doclens[j] rows) comes from the cache at known_first_row[its rank among the known ones] if known[j], else from the
+    tail (the new passages back to back, in order, from row n_cached_rows)."""
+    known = np.asarray(known, dtype=bool)
+    dl = np.asarray(doclens, dtype=np.int64)
+    src = np.empty(known.size, dtype=np.int64)                          # first source row of every passage
+    src[known] = np.asarray(known_first_row, dtype=np.int64)
+    src[~known] = n_cached_rows + np.concatenate([[0], np.cumsum(dl[~known])[:-1]]) if (~known).any() else 0
+    dst = np.concatenate([[0], np.cumsum(dl)[:-1]]) if dl.size else np.zeros(0, np.int64)
+    return np.repeat(src - dst, dl) + np.arange(int(dl.sum()), dtype=np.int64)
+
+
 class EncoderSource(DeviceEmbeddingSource):
     """The BERT checkpoint as a device-resident source.  The collection is tokenised ONCE on the host (tensorize_docs in
     batches of index_bsize, checkpoint.jl:159-189); the token ids of every passage are kept (a few hundred bytes per
@@ -573,11 +586,7 @@ class EncoderSource(DeviceEmbeddingSource):
             return self.encode_pids(pids)                               # (a chunk larger than setup() makes them)
         if n_new:
             self.encode_pids(pids[~known], out=c["buf"][c["n"]:c["n"] + n_new])
-        src = np.empty(end - start, dtype=np.int64)                     # first source row of every passage
-        src[known] = c["off"][i0:i1]
-        src[~known] = c["n"] + np.concatenate([[0], np.cumsum(dl[~known])[:-1]])
-        dst = np.concatenate([[0], np.cumsum(dl)[:-1]])
-        rows = np.repeat(src - dst, dl) + np.arange(int(dl.sum()), dtype=np.int64)
+        rows = _chunk_source_rows(known, dl, c["off"][i0:i1], c["n"])
         self.reused_passages = getattr(self, "reused_passages", 0) + int(known.sum())
         return codec.gather_rows_device(c["buf"], rows)
 

@@ -320,3 +320,25 @@ def test_index_file_writer_thread_keeps_order_and_hands_back_errors(tmp_path):
     assert ran == [1]
     with pytest.raises(RuntimeError):
         w.submit(lambda: None)
+
+
+def test_chunk_rows_from_cached_sample_and_new_passages():
+    """indexer._chunk_source_rows (round 5: a chunk of index() is cut out of [the sample's embeddings | its newly encoded
+    passages] instead of being encoded in full): against a plain loop, with empty passages, all-known and none-known chunks."""
+    from colbert_jl_amd.indexer import _chunk_source_rows
+    rng = np.random.default_rng(5)
+    for trial in range(30):
+        n = int(rng.integers(1, 40))
+        dl = rng.integers(0, 6, size=n)
+        known = rng.random(n) < (0.0 if trial == 0 else 1.0 if trial == 1 else 0.4)
+        n_cached = int(rng.integers(0, 500))
+        first = np.sort(rng.choice(max(n_cached, 1) + 50, size=int(known.sum()), replace=False)) if known.any() else np.zeros(0, np.int64)
+        want, tail = [], n_cached
+        ki = 0
+        for j in range(n):
+            if known[j]:
+                want.extend(range(int(first[ki]), int(first[ki]) + int(dl[j]))); ki += 1
+            else:
+                want.extend(range(tail, tail + int(dl[j]))); tail += int(dl[j])
+        got = _chunk_source_rows(known, dl, first, n_cached)
+        assert got.dtype == np.int64 and np.array_equal(got, np.asarray(want, dtype=np.int64)), trial
