@@ -33,6 +33,9 @@ _searcher_destroy(h::Ptr{Cvoid}) = ccall((:clb_searcher_destroy, libcolbert), Ci
 "selection step by one (0) or sixteen (1) work-groups per query; -1 (default): chosen by the candidate capacity"
 _searcher_set_wide_select(h::Ptr{Cvoid}, on::Integer) =
     _check(ccall((:clb_searcher_set_wide_select, libcolbert), Cint, (Ptr{Cvoid}, Cint), h, on))
+"batches of 16+ queries: the fp16 score table from one fp16 product (1) or the three-product bf16 split (3); -1 (default): 1 on a shard of a group, 3 on one GPU -- alike on every shard"
+_searcher_set_centroid_products(h::Ptr{Cvoid}, n::Integer) =
+    _check(ccall((:clb_searcher_set_centroid_products, libcolbert), Cint, (Ptr{Cvoid}, Cint), h, n))
 
 "search() after encode_queries (src/searching.jl:102-127): one library call."
 function _search(handle::Ptr{Cvoid}, Q::Matrix{Float32}, nprobe::Int, k::Int)
