@@ -665,33 +665,45 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
     CLB_ND_ENTER(0)
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int c0 = tile * 32;
-        f32x16 init;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) init[r] = h ? bcur[(r & 3) + 8 * (r >> 2) + 4] : bcur[(r & 3) + 8 * (r >> 2)];
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* a_tile = a_lane + buf * TILEB;
-        // the scheduler is fenced off around every group: left alone it gathers the fragment reads into two bursts and waits
-        // for each right behind its issue
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f16x8 a = __builtin_bit_cast(f16x8, af[s & 3]);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xq[q][s]), s == 0 ? init : acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 4 < 8) {
-                af[s & 3] = *reinterpret_cast<const u32x4*>(a_tile + (s + 4) * 512);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-        if (tile + 1 < n_tiles) CLB_ND_ENTER(tile + 1)          // the next tile's first fragments fly under the epilogue below
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) topn_insert_lazy<kTopPartial>(bv[q], bi[q], group_max16(acc[q], c0, h, K), 2 * tile + h);
+    // the last tile alone can be partial (its group maxima mask the rows past K): it is peeled off the loop, whose tiles take the
+    // plain maximum -- inside one loop hipcc computes the mask's sixteen row compares in FRONT of the branch, for every tile
+#define CLB_ND_BODY(LAST)                                                                                                \
+    {                                                                                                                    \
+        const int c0 = tile * 32;                                                                                        \
+        f32x16 init;                                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) init[r] = h ? bcur[(r & 3) + 8 * (r >> 2) + 4] : bcur[(r & 3) + 8 * (r >> 2)]; \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        const unsigned char* a_tile = a_lane + buf * TILEB;                                                              \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                                  \
+            const f16x8 a = __builtin_bit_cast(f16x8, af[s & 3]);                                                        \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                               \
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, xq[q][s]), s == 0 ? init : acc[q], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            if (s + 4 < 8) {                                                                                             \
+                af[s & 3] = *reinterpret_cast<const u32x4*>(a_tile + (s + 4) * 512);                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                       \
+            }                                                                                                            \
+        }                                                                                                                \
+        buf = buf + 1 == STAGES ? 0 : buf + 1;                                                                           \
+        if (!(LAST)) CLB_ND_ENTER(tile + 1)          /* the next tile's first fragments fly under the epilogue below */   \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                                 \
+            float gm_;                                                                                                   \
+            if (LAST) gm_ = group_max16(acc[q], c0, h, K);                                                               \
+            else {                                                                                                       \
+                const f32x16& v_ = acc[q];                                                                               \
+                gm_ = fmaxf(fmaxf(v_[0], v_[1]), v_[2]);                                                                 \
+                gm_ = fmaxf(fmaxf(gm_, v_[3]), v_[4]); gm_ = fmaxf(fmaxf(gm_, v_[5]), v_[6]);                             \
+                gm_ = fmaxf(fmaxf(gm_, v_[7]), v_[8]); gm_ = fmaxf(fmaxf(gm_, v_[9]), v_[10]);                            \
+                gm_ = fmaxf(fmaxf(gm_, v_[11]), v_[12]); gm_ = fmaxf(fmaxf(gm_, v_[13]), v_[14]);                         \
+                gm_ = fmaxf(gm_, v_[15]);                                                                                \
+            }                                                                                                            \
+            topn_insert_lazy<kTopPartial>(bv[q], bi[q], gm_, 2 * tile + h);                                              \
+        }                                                                                                                \
     }
+    int tile = 0;
+    for (; tile + 1 < n_tiles; ++tile) CLB_ND_BODY(0)
+    CLB_ND_BODY(1)
+#undef CLB_ND_BODY
 #undef CLB_ND_ENTER
 #undef CLB_ND_ISSUE
 #pragma unroll
