@@ -230,6 +230,41 @@ static __global__ __launch_bounds__(256) void max_row_f16_err_kernel(const float
     if (lane == 0) atomicMax(out_bits, __float_as_uint(m));
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Round 6, "8-bit score rows": the score table of the batched centroid stage as 32-BYTE rows [K][32 tokens] of 8-bit
+// cells instead of 64-byte fp16 rows -- half the bytes pass 1 gathers per embedding, half the table per query (4 MB at
+// K = 131 072: one XCD's L2).  On an index whose codes are not id-adjacent (uniform codes, any k-means-built index) the
+// row gather is the largest term of pass 1 (profiles/r05_pass1_ablations.jsonl: -0.61 of 3.46 ms on the built 1 M index).
+// Per (query, token) the cells are LINEAR in the score with a range known BEFORE any centroid is scored:
+//     |Q_t . c| <= ||Q_t|| * max ||c||  =: R_t   (1.002 x: the norm's and the split products' rounding, ~1e-4 relative)
+//     step_t = 2 R_t / 255 ;   cell = clamp(rint(score / step_t + 127.5), 0, 255) ;   score ~ (cell - 127.5) * step_t
+// so |dequantised - computed score| <= step_t / 2 (+ the rounding of the two operations: 0.5005 step_t in query_bound).
+// The range a token's K scores really span is ~0.7 R_t on the corpora at hand, but it is only known after the last centroid
+// (a second sweep over a 268-MB fp16 table costs more than the narrower step returns: profiles/r05_experiments.md 1c).
+// tscale[b][t] = {step_t, 1 / step_t}, t < 32 (zeros past T and for an all-zero token: its cells dequantise to 0, its
+// scaled query operand is 0).  One writer -- the centroid kernel, pass 1, the row sweep and the bound all READ these words,
+// so every stage scales by the same bits.  grid = B, block = 1024 (32 threads per token).
+// -------------------------------------------------------------------------------------------------------------
+constexpr float kCell8Range = 2.004f / 255.0f;      // step_t = kCell8Range * ||Q_t|| * cn_max
+constexpr float kCell8MinNorm = 1.0e-20f;           // ||Q_t|| * cn_max below this (and not zero): the query is searched exactly
+static __global__ __launch_bounds__(1024) void token_scale_kernel(const float* __restrict__ Q, int T, float cn_max,
+                                                                 float2* __restrict__ tscale) {
+    const int b = blockIdx.x, t = threadIdx.x >> 5, part = threadIdx.x & 31;
+    float a = 0.f;
+    if (t < T) {
+        const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
+        a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (part == 0) {
+        const float step = (sqrtf(a) * 1.001f) * (cn_max * kCell8Range);
+        // (a step too small to invert is the mark of a query query_bound declares unsafe: nothing downstream trusts its cells)
+        const bool ok = t < T && step >= 1.0e-30f && step < 1.0e30f;
+        tscale[(size_t)b * 32 + t] = ok ? make_float2(step, 1.0f / step) : make_float2(0.f, 0.f);
+    }
+}
+
 // Insert into a lane's descending list of approximate scores.  Ordering is by value only: which of several EQUAL
 // approximate scores survives at the end of a list is irrelevant, because top_refine_kernel re-scores everything above
 // its cut and treats a list whose last entry reaches the cut as overflowed.  Branch-free shift (3 compares, 14
@@ -597,10 +632,14 @@ typedef _Float16 f16x8_c __attribute__((ext_vector_type(8)));
 // X1 = true (round 5, "f16x1"): Chi is the fp16 table, Clo is not read -- one v_mfma_f32_32x32x16_f16 per 16 dims and query
 // instead of three bf16 ones (see to_f16_kernel); one tile load per stage (the hand-counted waits stay: behind it are still
 // exactly the four stores of an MFMA phase).  Same tiles, lists, table layout and stores.
-template <bool X1>
+// CELL8 = true (round 6): the table leaves as 32-byte rows of 8-bit cells (token_scale_kernel's comment): TWO stores per
+// tile and wave instead of four -- the waits count two -- and the epilogue quantises (fma, round, saturating convert)
+// where it converted to fp16.  Lists, refine and the arithmetic of the scores are unchanged.
+template <bool X1, bool CELL8 = false>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_teams_kernel(
     const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
-    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles) {
+    ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles,
+    const float2* __restrict__ tscale = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int team = wave >> 2;
@@ -678,11 +717,12 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
             }                                                                                             \
-            /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue) */            \
+            /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue); CELL8: two */ \
             if (s == 0) CLB_TM_STORE(o0, a0)                                                              \
-            if (s == 2) CLB_TM_STORE(o1, a1)                                                              \
-            if (s == 4) CLB_TM_STORE(o2, a2)                                                              \
-            if (s == 6) CLB_TM_STORE(o3, a3)                                                              \
+            if (s == 2 && !CELL8) CLB_TM_STORE(o1, a1)                                                    \
+            if (s == 4 && !CELL8) CLB_TM_STORE(o2, a2)                                                    \
+            if (s == 4 && CELL8) CLB_TM_STORE(o1, a1)                                                     \
+            if (s == 6 && !CELL8) CLB_TM_STORE(o3, a3)                                                    \
         }                                                                                                 \
     }
     // epilogue of tile TL: group lists, then the 32 x 32 scores of each query become one 2-KB block of fp16 rows
@@ -694,6 +734,22 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * (TL) + h);               \
         topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * (TL) + h);               \
         __builtin_amdgcn_wave_barrier();                                                                  \
+        if (CELL8) {                                                                                      \
+            /* one 1-KB block of 32-byte rows [centroid][token] per query: byte i of row cl                */ \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;                                            \
+                patch[cl * 32 + i] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(acc0[r], rs0, 127.5f)), 0u, 0u);        \
+                patch[1024 + cl * 32 + i] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(acc1[r], rs1, 127.5f)), 0u, 0u); \
+            }                                                                                             \
+            __builtin_amdgcn_wave_barrier();                                                              \
+            o0 = *reinterpret_cast<const u32x4*>(patch + lane * 16);                                      \
+            o1 = *reinterpret_cast<const u32x4*>(patch + 1024 + lane * 16);                               \
+            unsigned char* d0_ = reinterpret_cast<unsigned char*>(cells16 + ((size_t)bq0 * K + c0) * 8) + lane * 16;  \
+            unsigned char* sp_ = spill + lane * 16;                                                       \
+            const bool in_ = c0 + (lane >> 1) < K;                      /* centroid of the 16-B piece */     \
+            a0 = bq0 < B && in_ ? d0_ : sp_;                                                              \
+            a1 = bq0 + 1 < B && in_ ? d0_ + (size_t)K * 32 : sp_;                                         \
+        } else {                                                                                          \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
             const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;                                                \
             *reinterpret_cast<__half*>(patch + cl * 64 + i * 2) = __float2half_rn(acc0[r]);               \
@@ -712,9 +768,16 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         a1 = bq0 < B && in1_ ? d0_ + 1024 : sp_ + 1024;                                                   \
         a2 = bq0 + 1 < B && in0_ ? d1_ : sp_;                                                             \
         a3 = bq0 + 1 < B && in1_ ? d1_ + 1024 : sp_ + 1024;                                               \
+        }                                                                                                 \
     }
     unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 4096;      // one 2-KB patch per query
-    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * 16);
+    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * (CELL8 ? 8 : 16));
+    // CELL8: 1 / step of token i of the wave's two queries (0 past T and past the batch: those cells are never read)
+    float rs0 = 0.f, rs1 = 0.f;
+    if (CELL8) {
+        rs0 = tscale[(size_t)(bq0 < B ? bq0 : B - 1) * 32 + i].y;
+        rs1 = tscale[(size_t)(bq0 + 1 < B ? bq0 + 1 : B - 1) * 32 + i].y;
+    }
     f32x16 acc0, acc1;
     // the table stores of a tile are issued during the NEXT tile's MFMA phase (data in o0..o3, addresses in a0..a3; the
     // first phase stores zeros to the spill block, the last tile's stores follow the loop)
@@ -725,10 +788,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // epilogue.  Between two barriers team 0 therefore runs MFMA(k), epilogue(k) and team 1 epilogue(k-1), MFMA(k).
     // The buffer written before barrier k+1 held tile k-1, whose last reads (MFMA(k-1), either team) precede barrier k.
     // stage: the registers hold the tile after the staged one (requested one stage ago); behind those two loads are
-    // exactly the four stores of one MFMA phase, hence vmcnt(4)
+    // exactly the four stores of one MFMA phase, hence vmcnt(4) (CELL8: two stores, vmcnt(2))
 #define CLB_TM_STAGE()                                                                                    \
     {                                                                                                     \
-        CLB_TM_WAIT(4)                                                                                    \
+        if (CELL8) CLB_TM_WAIT(2) else CLB_TM_WAIT(4)                                                     \
         unsigned char* nb_ = lds16 + (buf ^ 1) * (2 * 32 * kRowBytes16);                                  \
         *reinterpret_cast<u32x4*>(nb_ + prow * kRowBytes16 + 16 * pchunk) = ph;                           \
         if (!X1) *reinterpret_cast<u32x4*>(nb_ + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;           \
@@ -757,7 +820,8 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // the last stage requested one more (clamped) tile: its two loads must have landed before their destination
     // registers die -- hipcc does not know they are in flight and would hand the registers to the code below
     CLB_TM_WAIT(0)
-    CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1) CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3)    // the last tile's
+    CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1)                                              // the last tile's
+    if (!CELL8) { CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3) }
 #undef CLB_TM_STAGE
 #undef CLB_TM_LOAD
 #undef CLB_TM_WAIT
@@ -1034,11 +1098,9 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
 // stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
 // access in the loop at all; 8 no result stores (what the passage-end stores and the waits they widen cost).
-// Round 5 (profiles/r05_pass1_ablations.jsonl): 9 = the score rows as 32-BYTE rows (8-bit cells: one 16-byte load per lane
-// from a table of half the size, bytes expanded to fp16 1024 + b with 8 v_perm_b32 -- the timing side of the "8-bit rows"
-// trial, the accuracy side is CLB_DEBUG_EPS_T_ADD); 10 = the row-mask sweep folded into pass 1 (every step compares its
-// 16 values against the RUNNING per-token maximum and the passage's 256-bit mask is stored at its last step: what that
-// costs the dominant kernel).
+// Round 5 (profiles/r05_pass1_ablations.jsonl): 10 = the row-mask sweep folded into pass 1 (every step compares its 16 values
+// against the RUNNING per-token maximum and the passage's 256-bit mask is stored at its last step: what that costs the
+// dominant kernel).  (Variant 9 of that round, the timing side of the 8-bit score rows, became CELL8.)
 // GL = 1 ("LDS-DMA gather", round 3): the score rows reach the wave through LDS instead of VGPRs.  Four ADJACENT lanes
 // fetch the 64 bytes of one row with global_load_lds_dwordx4 (16 rows per instruction, 2 instructions per step) -- one
 // L1 tag look-up per row where the VGPR form (lane (r, h) fetching 2 x 16 B of row r, the lanes of a row 32 apart)
@@ -1062,13 +1124,21 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // two streams, but the second accumulator set takes the kernel to the 168-VGPR cap of three waves per SIMD (7-24 spilled
 // registers) and the pass got SLOWER on every workload (0.662 -> 0.672 ms, uniform codes 1.46 -> 1.56, built index
 // 0.653 -> 0.699; the row sweep 0.069 -> 0.107): the pass is not short of issue slots, it waits on memory.
-template <bool ROWS, int ABL = 0, int GL = 0, int PIPE = 0>
+// CELL8 = true (round 6): the score rows are 32-byte rows of 8-bit cells (token_scale_kernel's comment).  Lane (r, h) fetches
+// ONE 16-byte piece (tokens 16h .. 16h+15 of row code_r) and expands it with eight v_perm_b32 to the fp16 values 1024 + cell
+// (0x6400 | cell), which the two selection MFMAs add into an accumulator that starts at -1151.5 = -(1024 + 127.5): after
+// them it holds cell - 127.5 EXACTLY.  The query operand is fp16(Q_t / step_t), so the eight Q.r MFMAs add Q_t.r / step_t and
+// acc * step_t is the token's score: the positive per-token factor commutes with the maximum over a passage's embeddings and
+// is applied once per passage (the row sweep applies it per value: the same product for the row that holds the maximum).
+// GL = 1: two adjacent lanes fetch a row -- ONE DMA instruction per step, a 1-KB ring slot, vmcnt(3).
+template <bool ROWS, int ABL = 0, int GL = 0, int PIPE = 0, bool CELL8 = false>
 static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
     int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
     int B, size_t cand_cap, uint16_t* __restrict__ tokmax, const int* __restrict__ list,
-    const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask) {
+    const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask,
+    const float2* __restrict__ tscale = nullptr) {
     const uint32_t cmask = (1u << cbits) - 1u;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -1083,7 +1153,9 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     __shared__ __attribute__((aligned(16))) unsigned char lut_s[kApproxLdsLut];
     __shared__ __attribute__((aligned(16))) float invx[kApproxThreads / 64][2 * kStepRows];   // two patches (PIPE)
     static_assert(GL == 0 || ABL == 0, "the ablation variants exist for the VGPR gather only");
-    constexpr int kRingBytes = 3 * 2048;                 // three steps in flight x 32 rows x 64 B, per wave
+    static_assert(!CELL8 || ABL == 0, "the ablation variants exist for the fp16 score rows only");
+    constexpr int kSlotBytes = CELL8 ? 1024 : 2048;      // 32 rows x 32 B / 64 B
+    constexpr int kRingBytes = 3 * kSlotBytes;           // three steps in flight, per wave
     static_assert(GL == 0 || CLB_APPROX_WAVES <= 12, "the 3-slot ring of the LDS-DMA form fits 160 KB of LDS up to 12 waves");
     __shared__ __attribute__((aligned(16))) unsigned char ring_s[GL ? (kApproxThreads / 64) * kRingBytes : 16];
     for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
@@ -1105,14 +1177,21 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     const uint32_t gl_rot = ((uint32_t)r >> 2) & 3u;
     const uint32_t gl_x0 = (uint32_t)r * 64u + 16u * (((uint32_t)h + gl_rot) & 3u);
     const uint32_t gl_x1 = (uint32_t)r * 64u + 16u * (((uint32_t)h + 2u + gl_rot) & 3u);
+    // CELL8 + GL: lane l = 2 m + q of the ONE DMA fetches piece q ^ rot8(m) of row m (the code of lane m), rot8(m) = (m >> 3) & 1;
+    // it lands at 32 m + 16 q, and lane (r, h) reads its piece h at 32 r + 16 (h ^ rot8(r)): 16 consecutive lanes then cover
+    // all 64 banks once (rows 0..7 at 32 r, rows 8..15 at 32 r + 16)
+    const int gl8_src = (int)(((uint32_t)lane >> 1) << 2);
+    const uint32_t gl8_poff = 16u * (((uint32_t)lane ^ ((uint32_t)lane >> 4)) & 1u);
+    const uint32_t gl8_x = (uint32_t)r * 32u + 16u * (((uint32_t)h ^ ((uint32_t)r >> 3)) & 1u);
 
     // selection matrices of the two score-row MFMAs: B1[k][col] = (col == k), B2[k][col] = (col == 16 + k), with
     // k = 8h + j held by lane (col = r, h) in element j
     f16x8 sel1, sel2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        sel1[j] = (r == 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
-        sel2[j] = (r == 16 + 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
+        // (CELL8: the lane's one piece holds tokens 16h .. 16h+15 -- its low half feeds the first MFMA, its high half the second)
+        sel1[j] = (r == (CELL8 ? 16 * h + j : 8 * h + j)) ? (_Float16)1.0f : (_Float16)0.0f;
+        sel2[j] = (r == (CELL8 ? 16 * h + 8 + j : 16 + 8 * h + j)) ? (_Float16)1.0f : (_Float16)0.0f;
     }
 
     int b_first, b_step, sub, nsub;
@@ -1128,6 +1207,9 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     for (int b = b_first; b < B; b += b_step) {
         // B operand: fp16 Q[t = r][64h + 8s + j], k-steps s = 0..7
         u32x4 qb[8];
+        // CELL8: token r's step (score units per cell) and its inverse, the factor of the fp16 query operand
+        const float2 ts = CELL8 ? tscale[(size_t)b * 32 + r] : make_float2(1.f, 1.f);
+        const float stp = ts.x;
         {
             const float* qrow = Q + ((size_t)b * T + (r < T ? r : T - 1)) * kDim + 64 * h;
 #pragma unroll
@@ -1135,12 +1217,16 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                 float4 lo = *reinterpret_cast<const float4*>(qrow + 8 * s);
                 float4 hi = *reinterpret_cast<const float4*>(qrow + 8 * s + 4);
                 if (r >= T) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+                if (CELL8) {     // (the same products query_bound measures the fp16 rounding of)
+                    lo.x *= ts.y; lo.y *= ts.y; lo.z *= ts.y; lo.w *= ts.y;
+                    hi.x *= ts.y; hi.y *= ts.y; hi.z *= ts.y; hi.w *= ts.y;
+                }
                 qb[s] = u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)};
             }
         }
         const uint2* hdr = cand_hdr + (size_t)b * cand_cap;
         // uniform base + 32-bit per-lane byte offset (code * 64 + 16h): the scalar-base form of global_load
-        const char* c16 = reinterpret_cast<const char*>(cells16 + (size_t)b * K * 16);
+        const char* c16 = reinterpret_cast<const char*>(cells16 + (size_t)b * K * (CELL8 ? 8 : 16));
         const uint32_t h16 = 16u * (uint32_t)h;
         float* out = scores + (size_t)b * cand_cap;
         uint16_t* tmax = tokmax + (size_t)b * cand_cap * 32 + r;
@@ -1203,7 +1289,11 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     }
         // stage G: the score row of the lane's embedding: tokens 8h..8h+7 and 16+8h..16+8h+7 (fp16), 2 x 16 B
 #define CLB_STAGE_G(CV, X0, X1, SLOT)                                                                       \
-    if (GL) {                                                                                               \
+    if (GL && CELL8) {                                                                                      \
+        const uint32_t ca_ = (uint32_t)__builtin_amdgcn_ds_bpermute(gl8_src, (int)CV) & cmask;              \
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"                                  \
+                     :: "v"(c16 + ((ca_ << 5) + gl8_poff)), "s"(ring_lds + (SLOT) * 1024u) : "memory");     \
+    } else if (GL) {                                                                                        \
         const uint32_t ca_ = (uint32_t)__builtin_amdgcn_ds_bpermute(gl_src0, (int)CV) & cmask;              \
         const uint32_t cb_ = (uint32_t)__builtin_amdgcn_ds_bpermute(gl_src1, (int)CV) & cmask;              \
         /* hand-issued (see the kernel header): M0 = LDS byte address of the slot, lane l lands at M0 + 16 l  */ \
@@ -1212,13 +1302,10 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                      :: "v"(c16 + ((ca_ << 6) + gl_poff)), "v"(c16 + ((cb_ << 6) + gl_poff)),               \
                         "s"(ring_lds + (SLOT) * 2048u) : "memory", "scc");                                   \
     } else {                                                                                                \
-        const char* row_ = ABL == 9 ? c16 + (((CV & cmask) << 5) + h16)                                     \
-                                    : c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);        \
+        const char* row_ = CELL8 ? c16 + (((CV & cmask) << 5) + h16)                                        \
+                                 : c16 + (((ABL == 2 ? (CV & 1023u) : (CV & cmask)) << 6) + h16);           \
         if (ABL == 1 || ABL == 7) { X0 = u32x4{CV, CV, CV, CV}; X1 = X0; }                                  \
-        else if (ABL == 9) {                                                                                \
-            X0 = *reinterpret_cast<const u32x4*>(row_);      /* 16 one-byte cells: tokens 8h..8h+7, 16+8h.. */ \
-            X1 = X0;                                                                                        \
-        }                                                                                                   \
+        else if (CELL8) X0 = *reinterpret_cast<const u32x4*>(row_);      /* 16 one-byte cells: tokens 16h .. 16h+15 */ \
         else {                                                                                              \
         X0 = *reinterpret_cast<const u32x4*>(row_);                                                         \
         X1 = *reinterpret_cast<const u32x4*>(row_ + 32);                                                    \
@@ -1227,7 +1314,11 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
 #define CLB_LUT(W, N) (*reinterpret_cast<const uint2*>(lut + lut_offset<N>(W, lane8)))
 #define CLB_STAGE_CM(RB, CV, X0, X1, SLOT, ACC, INVB)                                                       \
     {                                                                                                       \
-        if (GL) {                                                                                           \
+        if (GL && CELL8) {                                                                                  \
+            /* one DMA per step: behind it are at least the next stage A's two loads and the next stage G's DMA */ \
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                \
+            X0 = *reinterpret_cast<const u32x4*>(myring + (SLOT) * 1024 + gl8_x);                           \
+        } else if (GL) {                                                                                    \
             /* this step's two DMAs have landed once at most the 4 youngest VMEM operations are pending     */ \
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                \
             X0 = *reinterpret_cast<const u32x4*>(myring + (SLOT) * 2048 + gl_x0);                           \
@@ -1250,8 +1341,8 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
-        if (ABL == 9) {      /* byte b -> fp16 1024 + b (0x6400 | b): two cells per v_perm_b32 */            \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = CELL8 ? -1151.5f : 0.f;                     \
+        if (CELL8) {         /* byte b -> fp16 1024 + b (0x6400 | b): two cells per v_perm_b32 */            \
             const u32x4 raw_ = X0;                                                                          \
             X0 = u32x4{__builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04030402u), \
                        __builtin_amdgcn_perm(0x64646464u, raw_[1], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[1], 0x04030402u)}; \
@@ -1298,7 +1389,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             /* each lane half with 4 DPP steps + 2 readlanes (16 wave-wide ballots cost ~130 scalar instructions per */ \
             /* step, and a wave issues one instruction per ~5.7 cycles whatever its type)                            */ \
             uint32_t lm = 0;                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) lm |= !(v[i] < lo) ? (1u << i) : 0u;             \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) lm |= !((CELL8 ? v[i] * stp : v[i]) < lo) ? (1u << i) : 0u; \
             lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0xB1, 0xf, 0xf, true);    /* lane ^ 1 */     \
             lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x4E, 0xf, 0xf, true);    /* lane ^ 2 */     \
             lm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lm, 0x141, 0xf, 0xf, true);   /* row_half_mirror */ \
@@ -1358,6 +1449,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                     wm0 = wm1 = wm2 = wm3 = 0;                                                              \
                 }                                                                                           \
                 mx = max_lane_halves(mx);                                                                   \
+                if (CELL8) mx *= stp;                /* cells -> score units, once per passage and token */    \
                 const float sum = sum_lanes_0_31(r < T ? mx : 0.f);     /* valid in lanes 16..31 */         \
                 if (ABL == 8) { if (sum == 12345.678f) out[0] = mx; }    /* ablation: no result stores */     \
                 else {                                                                                      \
@@ -1473,29 +1565,51 @@ struct ApproxConsts {
 // The error bound of one query (see the header of this file): eps_t bounds |approx - canonical| of ONE (token, embedding)
 // score, eps_sum the same for a passage score (T tokens); `unsafe` = the fp16 score table cannot be trusted for this
 // query.  Called by all 1 024 threads of a work-group (two barriers); s_qn / s_dq are two shared floats.
+// tscale != nullptr: the batch's score table holds 8-bit cells (token_scale_kernel) and pass 1 multiplies fp16(Q_t / step_t):
+//   cells:  computed score vs canonical (the product bound) + half a step + the rounding of fma / rint: 0.5005 * max_t step_t
+//   Q.r:    Q_t . r - step_t * (fp16(q'_t) . r')  =  (Q_t - step_t fp16(q'_t)) . r' + Q_t . (r - r'),  q'_t = fl(Q_t * (1 / step_t)):
+//           ||Q_t - step_t fp16(q'_t)|| <= step_t * ||q'_t - fp16(q'_t)|| (measured: dq8) + 2 u ||Q_t|| (the two roundings of q'_t)
+//   MFMA:   the accumulator holds cell - 127.5 exactly after the two selection products; the 128 products that follow add up
+//           to at most 127.5 + |q'_t . r'| in cell units = (R_t + qn rn) in score units: 2 * 130 * u of that
+// and the query is unsafe when a token's range is too small to invert or its scaled operand could leave the fp16 range.
 struct QueryBound { float eps_t, eps_sum; bool unsafe; };
 __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, int b, int T, const ApproxConsts& ac,
-                                                  float* s_qn, float* s_dq) {
+                                                  float* s_qn, float* s_dq, const float2* __restrict__ tscale = nullptr,
+                                                  float* s_aux = nullptr /* 3 shared floats when tscale is given */) {
     const int tid = threadIdx.x;
     // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
     if (tid == 0) { *s_qn = 0.f; *s_dq = 0.f; }
+    if (tscale && tid < 3) s_aux[tid] = 0.f;     // [0] max_t step_t ||q'_t - fp16(q'_t)||, [1] max_t step_t, [2] bad-token flag
     __syncthreads();
     {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - fp16(Q_t)||: what the
         // fp16 query operand of pass 1 really loses (at most 2^-12 ||Q_t|| in the normal range)
         const int t = tid >> 5, part = tid & 31;
-        float a = 0.f, dd = 0.f;
+        float a = 0.f, dd = 0.f, d8 = 0.f;
         if (t < T) {
             const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
             a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
             const float dx = v.x - round_f16(v.x), dy = v.y - round_f16(v.y);
             const float dz = v.z - round_f16(v.z), dw = v.w - round_f16(v.w);
             dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
+            if (tscale) {
+                const float2 ts = tscale[(size_t)b * 32 + t];
+                const float sx = v.x * ts.y, sy = v.y * ts.y, sz = v.z * ts.y, sw = v.w * ts.y;   // pass 1's operand before its fp16 rounding
+                const float ex = sx - round_f16(sx), ey = sy - round_f16(sy), ez = sz - round_f16(sz), ew = sw - round_f16(sw);
+                d8 = fmaf(ex, ex, fmaf(ey, ey, fmaf(ez, ez, ew * ew)));
+            }
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); dd += __shfl_xor(dd, o, 64); }
+        for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); dd += __shfl_xor(dd, o, 64); d8 += __shfl_xor(d8, o, 64); }
         if (t < T && part == 0) {
             atomicMax(reinterpret_cast<unsigned int*>(s_qn), __float_as_uint(sqrtf(a) * 1.001f));
             atomicMax(reinterpret_cast<unsigned int*>(s_dq), __float_as_uint(sqrtf(dd) * 1.001f));
+            if (tscale) {
+                const float2 ts = tscale[(size_t)b * 32 + t];
+                atomicMax(reinterpret_cast<unsigned int*>(s_aux), __float_as_uint(ts.x * sqrtf(d8) * 1.001f));
+                atomicMax(reinterpret_cast<unsigned int*>(s_aux + 1), __float_as_uint(ts.x));
+                // a non-zero token whose range cannot be inverted (token_scale_kernel wrote zeros), or is close to that
+                if (a > 0.f && !(sqrtf(a) * ac.cn_max >= 100.f * kCell8MinNorm && ts.x > 0.f)) s_aux[2] = 1.f;
+            }
         }
     }
     __syncthreads();
@@ -1506,16 +1620,25 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     // Q.r:  sum_d (Q_d w_d - Q'_d w'_d) = dQ . r' + Q . (r - r')  with Q', w' the fp16 operands (their products are exact
     // in fp32): <= dq * max ||r'|| + qn * sqrt(dim) * max_b |w_b - w'_b|, both factors measured (dq here, the
     // other two at index load) instead of the generic 2^-9 relative bounds; plus the fp32 accumulation of the MFMA
-    const float e_qr = 1.001f * (*s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
+    float e_qr = 1.001f * (*s_dq * ac.rb_max + qn * ac.dw_rn) + 2.f * 128.f * u * qn * ac.rn_max;
+    float e_tab = e_cells;
+    bool bad8 = false;
+    if (tscale) {
+        const float dq8 = s_aux[0], step_max = s_aux[1];
+        e_tab = kEpsSafety * centroid_product_bound(qn, *s_dq, ac.cn_max, ac.dc_max) + 0.5005f * step_max;
+        e_qr = 1.001f * ((dq8 + 2.f * u * qn) * ac.rb_max + qn * ac.dw_rn) + 2.f * 130.f * u * (128.f * step_max + qn * ac.rn_max);
+        // |q'| <= 127.5 / cn_max must stay inside the fp16 range (cn_max is checked at index load as well)
+        bad8 = s_aux[2] != 0.f || !(127.5f < 3.0e4f * ac.cn_max);
+    }
     // the packed inv_norm is off by at most inv_qerr: it scales P = X + Q.r, |P| <= qn (cn + rn), and the other terms
-    const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_cells + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 328.f * u * qn;
+    const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_tab + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 332.f * u * qn;
     QueryBound r;
     r.eps_t = eps_t;
     // Guard of the fp16 score table: its entries are bounded by qn * cn and must stay finite in fp16 (max 65504);
     // the bound itself must be a finite number.  A query that fails either test (un-normalised or non-finite Q,
     // huge centroid norms) is not pre-filtered at all: every candidate is listed and every row selected, i.e. it is
     // scored by the exact kernel alone, exactly as in mode 0.  (NaN-safe: written with negated comparisons.)
-    r.unsafe = !(qn * ac.cn_max < 3.0e4f) || !(qn < 6.0e4f) /* the fp16 query operand */ || !(eps_t < 1.0e30f);
+    r.unsafe = !(qn * ac.cn_max < 3.0e4f) || !(qn < 6.0e4f) /* the fp16 query operand */ || !(eps_t < 1.0e30f) || bad8;
     r.eps_sum = kEpsSafety * ((float)T * eps_t + 2.f * (float)T * (float)T * u * qn);
     return r;
 }
@@ -1528,8 +1651,10 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    float* __restrict__ thresh,
                                                                    float* __restrict__ eps_pair,
                                                                    const float* __restrict__ tau_in = nullptr,
-                                                                   int coarse_tau = 0) {
+                                                                   int coarse_tau = 0,
+                                                                   const float2* __restrict__ tscale = nullptr) {
     __shared__ __attribute__((aligned(16))) int hist[256];
+    __shared__ float s_aux[3];
     __shared__ int sh_scan[16];
     __shared__ int sh_big[2][8][16];
     __shared__ uint32_t s_prefix, s_kmin, s_kmax;
@@ -1540,7 +1665,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const float* sc = scores + (size_t)b * cand_cap;
     int* lst = list + (size_t)b * cand_cap;
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
-    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq);
+    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux);
     float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
     const bool unsafe = qb.unsafe;
     if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
@@ -1757,9 +1882,10 @@ static __global__ __launch_bounds__(1024) void wide_minmax_kernel(const float* _
                                                                  const int* __restrict__ ncand,
                                                                  const float* __restrict__ Q, int T, size_t cand_cap,
                                                                  ApproxConsts ac, WideSel* __restrict__ wsel,
-                                                                 float* __restrict__ eps_pair) {
+                                                                 float* __restrict__ eps_pair,
+                                                                 const float2* __restrict__ tscale = nullptr) {
     __shared__ uint32_t s_kmin, s_kmax;
-    __shared__ float s_qn, s_dq;
+    __shared__ float s_qn, s_dq, s_aux[3];
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int n = ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
@@ -1767,7 +1893,7 @@ static __global__ __launch_bounds__(1024) void wide_minmax_kernel(const float* _
     if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0u; }
     __syncthreads();
     if (g == 0) {                                         // uniform over the work-group
-        const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq);
+        const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux);
         if (tid == 0) {
             eps_pair[b] = qb.unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
             w.unsafe = qb.unsafe ? 1 : 0;

@@ -64,11 +64,12 @@ struct Workspace {
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
     bool x1_table = false;      // the score table in cells_q came from the single-fp16-product kernel: the bound carries its terms
+    bool cell8 = false;         // the score table in cells_q holds 32-byte rows of 8-bit cells (tscale: their per-token steps)
     bool stats_keep = false;    // set for the 2nd, 3rd ... sub-batch of one call: the work counters accumulate over the call
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds, tscale;
     DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch, g_sort_tmp;   // general-shape path (generic_kernels.hpp)
 };
 
@@ -107,6 +108,10 @@ struct clb_searcher {
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     int gather_lds = 0; // pass 1: score rows through LDS-DMA, four adjacent lanes per row (0: the per-lane VGPR gather); set at load
     double code_adjacency = 0.0;   // fraction of consecutive embeddings that share a 128-B line of the score table
+    int cell8 = -1;     // batches of 16+ queries: score rows as 32 bytes of 8-bit cells?  1 yes, 0 fp16 rows, -1 by the code statistics
+                        // (yes when the row gather dominates pass 1: codes that are not id-adjacent) -- on a shard of a group
+                        // (bounds_synced) -1 means no: every shard's bound must cover every shard's table, so the group's driver
+                        // sets the form alike on all shards (clb_searcher_set_score_rows)
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
     Workspace ws[kWorkspaceSlots];   // per-batch scratch, grown on demand (ensure_workspace); slots 1..: further batches in flight
@@ -148,6 +153,13 @@ struct Timed {
 
 // token tiles of 32 for the cells table: Tpad in {32, 64, 128} so that it divides the 256-thread scan
 inline int token_tiles(int64_t T) { return T <= 32 ? 1 : T <= 64 ? 2 : 4; }
+
+// 8-bit score rows for this handle's batches of 16+ queries?  (cn_max >= 0.01: the scaled fp16 query operand of pass 1,
+// |q'| <= 127.5 / cn_max, stays far inside the fp16 range)
+inline bool cell8_rows(const clb_searcher* s) {
+    const bool by_codes = s->code_adjacency < 0.2 && !s->bounds_synced;
+    return (s->cell8 == 1 || (s->cell8 < 0 && by_codes)) && s->approx_ok && s->approx_consts.cn_max >= 0.01f;
+}
 
 // the top-k kernel sorts up to kMaxTopK 8-byte keys in LDS: beyond 64 KB the attribute has to be raised
 void allow_large_topk_lds() {
@@ -277,6 +289,11 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         if (teams) gx = std::max(1, std::min(n_tiles, std::min(256, std::max(256 / team_groups, 16))));
         const bool x1 = teams && (s->s1_x1 == 1 || (s->s1_x1 < 0 && s->bounds_synced)) && s->cent_f16.p && s->dc_f16 > 0.f;
         w.x1_table = x1;
+        w.cell8 = teams && cell8_rows(s);
+        if (w.cell8) {
+            CLB_TRY(w.tscale.ensure(sizeof(float2) * 32 * B));
+            hipLaunchKernelGGL(token_scale_kernel, dim3(B), dim3(1024), 0, st, dQ, T, s->approx_consts.cn_max, w.tscale.as<float2>());
+        }
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
         const size_t lds_f32 = 2 * 32 * kCentTileStride * sizeof(float);
@@ -288,19 +305,16 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
             {
                 Timed t(s, KID_CENTROID_SCORES, st);
                 const size_t lds_b16 = 2 * 2 * 32 * kRowBytes16;
-                if (teams && x1) {
-                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel<true>),
-                                      2 * 2 * 32 * kRowBytes16 + 8 * 4096);
-                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel<true>, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
-                                       s->cent_f16.as<uint16_t>(), (const uint16_t*)nullptr, dQ,
-                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
-                } else if (teams) {
+                if (teams) {
                     // 66 KB of dynamic LDS: above the 64-KB default limit of a launch
-                    allow_dynamic_lds(reinterpret_cast<const void*>(centroid_top_bf16x3_teams_kernel<false>),
-                                      2 * 2 * 32 * kRowBytes16 + 8 * 4096);
-                    hipLaunchKernelGGL(centroid_top_bf16x3_teams_kernel<false>, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
-                                       s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
-                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles);
+                    auto kern = x1 ? (w.cell8 ? centroid_top_bf16x3_teams_kernel<true, true> : centroid_top_bf16x3_teams_kernel<true, false>)
+                                   : (w.cell8 ? centroid_top_bf16x3_teams_kernel<false, true> : centroid_top_bf16x3_teams_kernel<false, false>);
+                    allow_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * 2 * 32 * kRowBytes16 + 8 * 4096);
+                    hipLaunchKernelGGL(kern, dim3(gx, team_groups), dim3(512), lds_b16 + 8 * 4096, st,
+                                       x1 ? s->cent_f16.as<uint16_t>() : s->cent_hi.as<uint16_t>(),
+                                       x1 ? (const uint16_t*)nullptr : (const uint16_t*)s->cent_lo.as<uint16_t>(), dQ,
+                                       w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles,
+                                       (const float2*)w.tscale.as<float2>());
                 } else if (mq && want_half)
                     hipLaunchKernelGGL(centroid_top_bf16x3_mq_kernel<true>, dim3(gx, groups), dim3(256), lds_b16 + 4 * 2048, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
@@ -588,6 +602,22 @@ int run_search_general(clb_searcher* s, Workspace& w, hipStream_t st, const floa
 // up to 32 768 candidates in registers; shards whose queries can have several times that (candidate capacity >= 131 072:
 // roughly 3 M passages and up) take the wide selection -- kWideBlocks work-groups per query, one launch per radix pass.
 constexpr size_t kWideSelectCap = 131072;
+
+// Pass 1 over every candidate of the batch: the gather form by the index's code statistics, the row format by the batch's table
+void launch_pass1(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, dim3 grid, int B, int T) {
+#if CLB_APPROX_WAVES <= 12
+    auto kern = w.cell8 ? (s->gather_lds ? score_approx32_kernel<false, 0, 1, 0, true> : score_approx32_kernel<false, 0, 0, 0, true>)
+                        : (s->gather_lds ? score_approx32_kernel<false, 0, 1, 0, false> : score_approx32_kernel<false, 0, 0, 0, false>);
+#else
+    auto kern = w.cell8 ? score_approx32_kernel<false, 0, 0, 0, true> : score_approx32_kernel<false, 0, 0, 0, false>;
+#endif
+    hipLaunchKernelGGL(kern, grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
+                       s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
+                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
+                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr,
+                       (const float2*)w.tscale.as<float2>());
+}
 // The centroid side of the single-product score table in the error bound: when this batch's table was made that way -- and,
 // on a shard of a group, whenever a shard MAY make its tables that way (the threshold tau comes from every shard's
 // approximate scores, so one bound has to cover them all; set clb_searcher_set_centroid_products alike on all shards).
@@ -606,7 +636,8 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
         if (const int add = CLB_KNOB("CLB_DEBUG_EPS_T_ADD_1E6", 0)) ac.inv_qerr += add * 1e-6f / (1.01f * (ac.cn_max + ac.rn_max));
         hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
                            w.cand_cap, ac, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
-                           w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0);
+                           w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0,
+                           w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
         return CLB_OK;
     }
     CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
@@ -615,7 +646,8 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
     ApproxConsts acw = s->approx_consts;
     acw.dc_max = bound_dc(s, w);
     hipLaunchKernelGGL(wide_minmax_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, w.cand_cap,
-                       acw, w.wsel.as<WideSel>(), w.eps_pair.as<float>());
+                       acw, w.wsel.as<WideSel>(), w.eps_pair.as<float>(),
+                       w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
     if (!tau_in)
         for (int pass = 0; pass < 4; ++pass)
             hipLaunchKernelGGL(wide_hist_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
@@ -700,7 +732,6 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 case 6: CLB_LAUNCH_APPROX(6); break;
                 case 7: CLB_LAUNCH_APPROX(7); break;
                 case 8: CLB_LAUNCH_APPROX(8); break;
-                case 9: CLB_LAUNCH_APPROX(9); break;
                 case 10:     // the fused row mask writes the slot-indexed row-mask buffer (4 words per candidate slot)
                     hipLaunchKernelGGL((score_approx32_kernel<false, 10>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
@@ -708,21 +739,10 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                                        (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
                                        (const int*)nullptr, (const float*)nullptr, w.rowmask.as<unsigned long long>());
                     break;
-                default: CLB_LAUNCH_APPROX(0);
+                default: launch_pass1(s, w, st, dQ, approx_grid, B, T);
             }
 #else
-            {
-#if CLB_APPROX_WAVES <= 12
-                auto kern = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
-#else
-                auto kern = score_approx32_kernel<false, 0, 0, 0>;
-#endif
-                hipLaunchKernelGGL(kern, approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
-                                   s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
-                                   w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                                   (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
-                                   (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
-            }
+            launch_pass1(s, w, st, dQ, approx_grid, B, T);
 #endif
 #undef CLB_LAUNCH_APPROX
         }
@@ -747,12 +767,12 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         const int rows_gx = CLB_KNOB("CLB_DEBUG_ROWS_GX", 256);
         const dim3 rows_grid = B > 1 ? dim3(std::max(1, rows_gx / B), B) : dim3(8 * 32);
         // (the row sweep keeps the VGPR gather: its ~1 200 passages per query are faster with it on every workload measured)
-        auto rows_kernel = score_approx32_kernel<true, 0, 0, 0>;
+        auto rows_kernel = w.cell8 ? score_approx32_kernel<true, 0, 0, 0, true> : score_approx32_kernel<true, 0, 0, 0, false>;
         hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                            s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
                            w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
                            (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
-                           w.rowmask.as<unsigned long long>());
+                           w.rowmask.as<unsigned long long>(), (const float2*)w.tscale.as<float2>());
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
@@ -1032,7 +1052,7 @@ int64_t clb_searcher_device_bytes(const clb_searcher* s) {
     int64_t tot = s->index_bytes;
     for (const auto& w : s->ws) {
         const DevBuf* bufs[] = {&w.Qdev, &w.cells, &w.cells_q, &w.partial, &w.sel, &w.bitmap, &w.blocksum, &w.ncand, &w.cand,
-                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax, &w.tau_glob};
+                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax, &w.tau_glob, &w.tscale};
         for (auto* b : bufs) tot += (int64_t)b->bytes;
     }
     return tot;
@@ -1078,6 +1098,16 @@ int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
     if (adjacency) *adjacency = s->code_adjacency;
     return s->gather_lds;
 }
+
+int clb_searcher_set_score_rows(clb_searcher* s, int form) {
+    if (!s) return fail(CLB_EARGUMENT, "null searcher");
+    if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "score rows must be -1 (by the code statistics), 0 (64-byte fp16 rows) or 1 (32-byte rows of 8-bit cells)");
+    if (form == 1 && !(s->approx_ok && s->approx_consts.cn_max >= 0.01f))
+        return fail(CLB_EUNSUPPORTED, "8-bit score rows need the two-pass mode and centroids of norm >= 0.01");
+    s->cell8 = form;
+    return CLB_OK;
+}
+int clb_searcher_get_score_rows(const clb_searcher* s) { return s ? (cell8_rows(s) ? 1 : 0) : -1; }
 
 int clb_searcher_set_centroid_products(clb_searcher* s, int n) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
@@ -1296,24 +1326,20 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     CLB_TRY(use_device(s->device));
     Workspace& w = s->ws[0];
     w.pending.valid = false;
-    CLB_TRY(ensure_workspace(s, w, 1, T, nprobe, k));
+    // 8-bit score rows exist for batches of 16+ queries only: the query then runs as sixteen copies of itself (the report is
+    // copy 0's), so that this hook sees the table format, the scaled query operand and the bound a real batch gets
+    const int Bd = cell8_rows(s) ? kTeamQueries : 1;
+    CLB_TRY(ensure_workspace(s, w, Bd, T, nprobe, k));
     hipStream_t st = s->stream;
-    CLB_HIP(hipMemcpyAsync(w.Qdev.p, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
+    for (int c = 0; c < Bd; ++c)
+        CLB_HIP(hipMemcpyAsync(w.Qdev.as<float>() + (size_t)c * T * kDim, Q, sizeof(float) * T * kDim, hipMemcpyHostToDevice, st));
     const float* dQ = w.Qdev.as<float>();
-    CLB_TRY(run_retrieve(s, w, st, dQ, 1, (int)T, (int)nprobe));
-#if CLB_APPROX_WAVES <= 12
-    auto dbg_kernel = s->gather_lds ? score_approx32_kernel<false, 0, 1, 0> : score_approx32_kernel<false, 0, 0, 0>;
-#else
-    auto dbg_kernel = score_approx32_kernel<false, 0, 0, 0>;
-#endif
-    hipLaunchKernelGGL(dbg_kernel, dim3(8 * 32), dim3(kApproxThreads), 0, st, s->weights.as<float>(),
-                       s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
-                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                       (int)s->K, (int)T, 1, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
-                       (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr);
+    CLB_TRY(run_retrieve(s, w, st, dQ, Bd, (int)T, (int)nprobe));
+    launch_pass1(s, w, st, dQ, dim3(8 * 32), Bd, (int)T);
     hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ,
                        (int)T, (int)k, w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(),
-                       w.thresh.as<float>(), w.eps_pair.as<float>());
+                       w.thresh.as<float>(), w.eps_pair.as<float>(), (const float*)nullptr, 0,
+                       w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
     int nc = 0, nl = 0;
     float th[2];
     CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));

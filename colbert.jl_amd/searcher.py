@@ -114,6 +114,16 @@ class Searcher:
         adj = C.c_double(0)
         return int(lib().clb_searcher_get_pass1_gather(self._h, C.byref(adj))), adj.value
 
+    def set_score_rows(self, form: int):
+        """Batches of 16+ queries, two-pass mode: 0 = 64-byte fp16 score rows, 1 = 32-byte rows of 8-bit cells, -1 = default
+        (1 when the index's codes are not id-adjacent; 0 on a shard of a group: set it alike on every shard)."""
+        check(lib().clb_searcher_set_score_rows(self._h, C.c_int(form)))
+
+    @property
+    def score_rows(self) -> int:
+        """row format batches of 16+ queries take: 0 fp16 (64 B), 1 8-bit cells (32 B)"""
+        return int(lib().clb_searcher_get_score_rows(self._h))
+
     def set_centroid_products(self, n: int):
         """Batches of 16+ queries, two-pass mode: 1 = score table from one fp16 product, 3 = the bf16 split, -1 = default (1 on a shard of a group, 3 on one GPU)."""
         check(lib().clb_searcher_set_centroid_products(self._h, C.c_int(n)))

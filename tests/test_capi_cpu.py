@@ -79,6 +79,8 @@ def test_round3_entry_points_check_their_arguments_first():
     null = C.c_void_p()
     assert l.clb_searcher_set_pass1_gather(null, 0) == 4
     assert l.clb_searcher_get_pass1_gather(null, None) == -1
+    assert l.clb_searcher_set_score_rows(null, 1) == 4
+    assert l.clb_searcher_get_score_rows(null) == -1
     assert l.clb_searcher_set_centroid_products(null, 1) == 4
     assert l.clb_searcher_get_centroid_products(null, None) == -1
     assert l.clb_searcher_sync_bound_consts(null, null) == 4

@@ -271,21 +271,37 @@ def test_encoder_epilogue_bit_exact(oracle):
 # ---------------------------------------------------------------------------------------------------
 def check_search(oracle, idx, Qs, k, nprobe=2, modes=(0, 1), pid_offset=0, wide=None):
     """Both search modes against the oracle; the two-pass mode with BOTH gather forms of pass 1 (mode 2 below = two-pass
-    with the form the index statistics did not pick)."""
+    with the form the index statistics did not pick) and BOTH score-row formats (modes 3 / 4 = 8-bit cells with either gather
+    form; the format of batches of 16+ queries, so their batch is the queries repeated up to 18)."""
     s = clb.Searcher(index=idx, pid_offset=pid_offset)
     if wide is not None:
         s.set_wide_select(wide)
     refs = [oracle.search(idx, Qs[:, :, j], nprobe=nprobe, k=k) for j in range(Qs.shape[2])]   # the oracle, once per query
     auto_form = s.pass1_gather[0]
     try:
-        for mode in tuple(modes) + ((2,) if 1 in modes else ()):
+        for mode in tuple(modes) + ((2, 3, 4) if 1 in modes else ()):
             if mode >= 1 and s.mode != 1:
                 try:
                     s.set_mode(1)
                 except clb.Unsupported:
                     continue
             s.set_mode(min(mode, 1))
-            s.set_pass1_gather(-1 if mode < 2 else 1 - auto_form)
+            s.set_pass1_gather(-1 if mode not in (2, 4) else 1 - auto_form)
+            if mode >= 3:
+                try:
+                    s.set_score_rows(1)
+                except clb.Unsupported:                    # centroids of norm < 0.01
+                    continue
+                nq = Qs.shape[2]
+                Qb = np.asfortranarray(np.concatenate([Qs] * (-(-18 // nq)), axis=2))
+                bp, bs, bn = s.search_batch(Qb, k, nprobe=nprobe)
+                for j in range(Qb.shape[2]):
+                    rp, rs, rn = refs[j % nq]
+                    assert np.array_equal(bp[:, j], rp + pid_offset) and bn[j] == rn, (mode, j)
+                    assert_same_f32(bs[:, j], rs, f"batch scores mode={mode} q={j}")
+                s.set_score_rows(0)
+                continue
+            s.set_score_rows(0)
             for j in range(Qs.shape[2]):
                 rp, rs, rn = refs[j]
                 pids, scores = s.search_embeddings(Qs[:, :, j], k, nprobe=nprobe)

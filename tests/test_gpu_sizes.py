@@ -45,11 +45,15 @@ def _adversarial_index(seed, cent_scale, weights):
     return idx
 
 
-@pytest.mark.parametrize("case", ["mixed_norms", "big_weights", "unnormalised_q", "huge_q", "tiny_q"])
-def test_two_pass_adversarial(oracle, case):
+@pytest.mark.parametrize("rows", [0, 1], ids=["fp16_rows", "cell8_rows"])
+@pytest.mark.parametrize("case", ["mixed_norms", "big_weights", "unnormalised_q", "huge_q", "tiny_q", "outlier_centroid"])
+def test_two_pass_adversarial(oracle, case, rows):
     """Centroid norms from 0.01 to 50, bucket weights +-0.5, un-normalised queries (token norms 1e-3 .. 1e3; and
     1e5, where the fp16 score table would overflow and the guard must route the query to the exact kernel), duplicated
-    passages: the observed error stays within the proven bound, and mode 1 == mode 0 == oracle bit for bit."""
+    passages: the observed error stays within the proven bound, and mode 1 == mode 0 == oracle bit for bit.
+    rows = 1: the score table of batches of 16+ queries as 32-byte rows of 8-bit cells (clb_searcher_set_score_rows) -- the
+    bound check runs the query as sixteen copies of itself, the batch below is the three queries six times over.
+    outlier_centroid: ONE centroid of norm 40 among unit ones blows every token's cell range (and step) up 40 times."""
     weights = [-0.041035336, -0.009812315, 0.008938393, 0.039779153]
     scale = [1.0]
     qscale = None
@@ -64,6 +68,10 @@ def test_two_pass_adversarial(oracle, case):
     elif case == "tiny_q":
         qscale = (1e-20, 1e-18)
     idx = _adversarial_index(101, scale, weights)
+    if case == "outlier_centroid":
+        C = idx["centroids"].copy(order="F")
+        C[:, 137] *= np.float32(40.0)
+        idx["centroids"] = np.asfortranarray(C)
     Qs = synthetic.make_queries(idx, 102, 3)
     if qscale is not None:
         rng = np.random.default_rng(103)
@@ -72,6 +80,8 @@ def test_two_pass_adversarial(oracle, case):
     k = 60
     s = clb.Searcher(index=idx)
     try:
+        s.set_score_rows(rows)
+        assert s.score_rows == rows
         for j in range(Qs.shape[2]):
             rp, rs, rn = oracle.search(idx, Qs[:, :, j], nprobe=2, k=k)
             out = {}
@@ -86,12 +96,13 @@ def test_two_pass_adversarial(oracle, case):
             if np.isfinite(d["eps"]):                              # guarded queries report eps = inf
                 err = np.abs(d["approx"].astype(np.float64) - d["exact"].astype(np.float64))
                 assert err.max() <= d["eps"], (case, j, err.max(), d["eps"])
-            else:
-                assert case == "huge_q" and d["n_rescore"] == rn     # everything goes to the exact kernel
+            else:                                                  # everything goes to the exact kernel
+                assert (case == "huge_q" or (rows == 1 and case == "tiny_q")) and d["n_rescore"] == rn
         s.set_mode(1)
-        bp, bs, _ = s.search_batch(Qs, k)
-        for j in range(Qs.shape[2]):
-            rp, rs, _ = oracle.search(idx, Qs[:, :, j], nprobe=2, k=k)
+        Qb = np.asfortranarray(np.concatenate([Qs] * 6, axis=2)) if rows else Qs      # 18 queries: the 16-query centroid kernel
+        bp, bs, _ = s.search_batch(Qb, k)
+        for j in range(Qb.shape[2]):
+            rp, rs, _ = oracle.search(idx, Qs[:, :, j % Qs.shape[2]], nprobe=2, k=k)
             assert np.array_equal(bp[:, j], rp)
             same_f32(bs[:, j], rs, f"{case} batch q={j}")
     finally:

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--set", action="append", default=[], help="NAME=v1,v2,...")
+    ap.add_argument("--api", action="append", default=[],
+                    help="score_rows=0,1 / pass1_gather=0,1 / centroid_products=1,3: product-library setters swept like --set "
+                         "(results stay correct; works on the product build)")
     ap.add_argument("--uniform-codes", action="store_true")
     ap.add_argument("--built-docs", type=int, default=0,
                     help="instead of the generator-made index: this many passages of mixture embeddings through the repo's own "
@@ -66,8 +69,8 @@ def main():
                                               "note": "(max - min over the K centroids of Q_t.c) / 510, per (query, token)"}}), flush=True)
         del Cd
     run = DeviceSearch(s, T, B, k, 2)
-    names = [x.split("=")[0] for x in args.set]
-    values = [x.split("=")[1].split(",") for x in args.set]
+    names = [x.split("=")[0] for x in args.set] + ["api:" + x.split("=")[0] for x in args.api]
+    values = [x.split("=")[1].split(",") for x in args.set + args.api]
     # the first measurement of a process used to come out ~8 % slow (0.72 against 0.665 ms for the same pass 1: the device
     # has just spent seconds in host-side index generation and idles at a low clock): one second of untimed batches first
     import time
@@ -78,7 +81,10 @@ def main():
         torch.cuda.synchronize()
     for combo in itertools.product(*values) if values else [()]:
         for n, v in zip(names, combo):
-            os.environ[n] = v
+            if n.startswith("api:"):
+                getattr(s, "set_" + n[4:])(int(v))
+            else:
+                os.environ[n] = v
         for i in range(3):
             run(Qdev[i * B:(i + 1) * B])
         torch.cuda.synchronize()
