@@ -231,37 +231,80 @@ static __global__ __launch_bounds__(256) void max_row_f16_err_kernel(const float
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// Round 6, "8-bit score rows": the score table of the batched centroid stage as 32-BYTE rows [K][32 tokens] of 8-bit
-// cells instead of 64-byte fp16 rows -- half the bytes pass 1 gathers per embedding, half the table per query (4 MB at
-// K = 131 072: one XCD's L2).  On an index whose codes are not id-adjacent (uniform codes, any k-means-built index) the
-// row gather is the largest term of pass 1 (profiles/r05_pass1_ablations.jsonl: -0.61 of 3.46 ms on the built 1 M index).
-// Per (query, token) the cells are LINEAR in the score with a range known BEFORE any centroid is scored:
-//     |Q_t . c| <= ||Q_t|| * max ||c||  =: R_t   (1.002 x: the norm's and the split products' rounding, ~1e-4 relative)
-//     step_t = 2 R_t / 255 ;   cell = clamp(rint(score / step_t + 127.5), 0, 255) ;   score ~ (cell - 127.5) * step_t
-// so |dequantised - computed score| <= step_t / 2 (+ the rounding of the two operations: 0.5005 step_t in query_bound).
-// The range a token's K scores really span is ~0.7 R_t on the corpora at hand, but it is only known after the last centroid
-// (a second sweep over a 268-MB fp16 table costs more than the narrower step returns: profiles/r05_experiments.md 1c).
-// tscale[b][t] = {step_t, 1 / step_t}, t < 32 (zeros past T and for an all-zero token: its cells dequantise to 0, its
-// scaled query operand is 0).  One writer -- the centroid kernel, pass 1, the row sweep and the bound all READ these words,
-// so every stage scales by the same bits.  grid = B, block = 1024 (32 threads per token).
+// Round 6, "8-bit score rows": the score table pass 1 gathers from as 32-BYTE rows [K][32 tokens] of 8-bit cells instead of
+// 64-byte fp16 rows -- half the bytes per gathered row, half the table per query (4 MB at K = 131 072: one XCD's L2).  On an
+// index whose codes are not id-adjacent (uniform codes, any k-means-built index) the row gather is the largest term of pass 1
+// (profiles/r05_pass1_ablations.jsonl: -0.61 of 3.46 ms on the built 1 M index).
+// The cells of a (query, token) are LINEAR in the score over the range [lo_t, hi_t] the token's K scores REALLY span:
+//     step_t = (hi_t - lo_t) / 254 ;   k_t = lo_t / step_t ;   cell = clamp(rint(score / step_t - k_t), 0, 255) ;
+//     score ~ (cell + k_t) * step_t ,   off by at most half a step (+ the rounding of the operations: 0.5005 step_t in query_bound)
+// A first form took the range from norms alone, +-||Q_t|| max||c|| (profiles/r06_score_rows_apriori_range_ab.jsonl): on a
+// k-means-built index max||c|| is an outlier (~1 where the typical centroid has norm 0.35) and the a-priori step came out 5x
+// the one below -- pass 2 re-scored 3.6x the rows and the search got slower.  The measured range is only known after the
+// last centroid, so the batched centroid kernel keeps writing its fp16 table and tracks every token's running minimum and
+// maximum on the way (centroid_top_bf16x3_teams_kernel: `rangep`); token_range_kernel reduces the work-groups' partial
+// ranges and requantise_cells_kernel rewrites the table as 8-bit rows (268 MB read, 134 MB written per 32 queries at
+// K = 131 072: ~0.08 ms, which the halved gather has to earn back -- the format is chosen per index, search.hip).
+// tscale[b][t] = {step_t, 1 / step_t, k_t, A_t = max |score|}, t < 32.  One writer: the requantisation, pass 1, the row
+// sweep and the bound all READ these words, so every stage scales by the same bits.  The fp16 format uses A_t alone: its
+// storage error is 2^-11 A_t, where the bound used to assume |score| <= ||Q_t|| max||c||.
 // -------------------------------------------------------------------------------------------------------------
-constexpr float kCell8Range = 2.004f / 255.0f;      // step_t = kCell8Range * ||Q_t|| * cn_max
-constexpr float kCell8MinNorm = 1.0e-20f;           // ||Q_t|| * cn_max below this (and not zero): the query is searched exactly
-static __global__ __launch_bounds__(1024) void token_scale_kernel(const float* __restrict__ Q, int T, float cn_max,
-                                                                 float2* __restrict__ tscale) {
+constexpr float kCell8Steps = 254.0f;               // cells 0 .. 254 span [lo_t, hi_t]; 255 absorbs the rounding of k_t
+// grid = B, block = 1024 (32 threads per token).  rangep: [b][t][nparts] {min, max} as left by the centroid kernel.
+static __global__ __launch_bounds__(1024) void token_range_kernel(const float2* __restrict__ rangep, int nparts, int T,
+                                                                 float4* __restrict__ tscale) {
     const int b = blockIdx.x, t = threadIdx.x >> 5, part = threadIdx.x & 31;
-    float a = 0.f;
-    if (t < T) {
-        const float4 v = *reinterpret_cast<const float4*>(Q + ((size_t)b * T + t) * kDim + 4 * part);
-        a = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    const float2* rp = rangep + ((size_t)b * 32 + t) * nparts;
+    for (int i = part; i < nparts; i += 32) {
+        const float2 v = rp[i];
+        lo = fminf(lo, v.x);
+        hi = fmaxf(hi, v.y);
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    for (int o = 16; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
     if (part == 0) {
-        const float step = (sqrtf(a) * 1.001f) * (cn_max * kCell8Range);
-        // (a step too small to invert is the mark of a query query_bound declares unsafe: nothing downstream trusts its cells)
-        const bool ok = t < T && step >= 1.0e-30f && step < 1.0e30f;
-        tscale[(size_t)b * 32 + t] = ok ? make_float2(step, 1.0f / step) : make_float2(0.f, 0.f);
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float amax = fmaxf(fabsf(lo), fabsf(hi));
+        // a range that is not a pair of finite numbers (a NaN / infinite query): zeros -- query_bound declares the query unsafe
+        if (t < T && hi >= lo && amax < 1.0e30f) {
+            // never a step below 1e-6 of the magnitude: k_t stays a number whose sum with a cell is exact to 1/16 cell
+            const float step = fmaxf(fmaxf((hi - lo) * (1.0f / kCell8Steps), amax * 1.0e-6f), 1.0e-30f);
+            const float rstep = 1.0f / step;
+            out = make_float4(step, rstep, lo * rstep, amax);
+        }
+        tscale[(size_t)b * 32 + t] = out;
+    }
+}
+
+// fp16 rows [K][32 tokens] (64 B) -> 8-bit rows [K][32 tokens] (32 B), per query.  Thread = 16 tokens of one centroid: two
+// 16-byte loads, one 16-byte store.  grid = (blocks, B), block = 256.
+static __global__ __launch_bounds__(256) void requantise_cells_kernel(const uint32_t* __restrict__ cells16,
+                                                                     const float4* __restrict__ tscale,
+                                                                     uint32_t* __restrict__ cells8, int K) {
+    __shared__ float2 sc[32];                        // {1 / step_t, k_t}
+    const int b = blockIdx.y;
+    if (threadIdx.x < 32) {
+        const float4 ts = tscale[(size_t)b * 32 + threadIdx.x];
+        sc[threadIdx.x] = make_float2(ts.y, ts.z);
+    }
+    __syncthreads();
+    const int hsel = threadIdx.x & 1;                // tokens 16 hsel .. 16 hsel + 15
+    const u32x4* src = reinterpret_cast<const u32x4*>(cells16 + (size_t)b * K * 16);
+    u32x4* dst = reinterpret_cast<u32x4*>(cells8 + (size_t)b * K * 8);
+    const int64_t total = (int64_t)K * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const u32x4 a = __builtin_nontemporal_load(src + 2 * i), c = __builtin_nontemporal_load(src + 2 * i + 1);
+        const uint32_t w[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t hbits = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const __half hv = *reinterpret_cast<const __half*>(&hbits);
+            const float2 s2 = sc[16 * hsel + j];
+            o[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(__half2float(hv), s2.x, -s2.y)), (uint32_t)(j & 3), o[j >> 2]);
+        }
+        dst[i] = u32x4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -306,6 +349,18 @@ __device__ __forceinline__ float group_max16(const f32x16& acc, int c0, int h, i
     m = fmaxf(fmaxf(m, acc[11]), acc[12]);
     m = fmaxf(fmaxf(m, acc[13]), acc[14]);
     return fmaxf(m, acc[15]);
+}
+
+// smallest of the 16 scores a lane holds of one tile (plain fminf: see group_max16 about the accumulator hazard)
+__device__ __forceinline__ float group_min16(const f32x16& acc) {
+    float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+    m = fminf(fminf(m, acc[3]), acc[4]);
+    m = fminf(fminf(m, acc[5]), acc[6]);
+    m = fminf(fminf(m, acc[7]), acc[8]);
+    m = fminf(fminf(m, acc[9]), acc[10]);
+    m = fminf(fminf(m, acc[11]), acc[12]);
+    m = fminf(fminf(m, acc[13]), acc[14]);
+    return fminf(m, acc[15]);
 }
 
 // grid = (gx, B), block = 128 (2 waves), LDS = 2 waves * (2 arrays * 32 rows * 272 B + a 2-KB patch with WRITE_HALF).
@@ -632,14 +687,14 @@ typedef _Float16 f16x8_c __attribute__((ext_vector_type(8)));
 // X1 = true (round 5, "f16x1"): Chi is the fp16 table, Clo is not read -- one v_mfma_f32_32x32x16_f16 per 16 dims and query
 // instead of three bf16 ones (see to_f16_kernel); one tile load per stage (the hand-counted waits stay: behind it are still
 // exactly the four stores of an MFMA phase).  Same tiles, lists, table layout and stores.
-// CELL8 = true (round 6): the table leaves as 32-byte rows of 8-bit cells (token_scale_kernel's comment): TWO stores per
-// tile and wave instead of four -- the waits count two -- and the epilogue quantises (fma, round, saturating convert)
-// where it converted to fp16.  Lists, refine and the arithmetic of the scores are unchanged.
-template <bool X1, bool CELL8 = false>
+// RANGE (round 6): every token's running minimum and maximum over the work-group's tiles go to rangep, [query][token][gridDim.x]
+// {min, max} (token_range_kernel's comment): eight v_min3 per query and tile beside the group maximum the lists take anyway --
+// +5 % on the kernel, so only batches whose table will be requantised track it.
+template <bool X1, bool RANGE = false>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void centroid_top_bf16x3_teams_kernel(
     const uint16_t* __restrict__ Chi, const uint16_t* __restrict__ Clo, const float* __restrict__ Q,
     ValIdx* __restrict__ partial, uint32_t* __restrict__ cells16, int K, int T, int B, int n_tiles,
-    const float2* __restrict__ tscale = nullptr) {
+    float2* __restrict__ rangep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int team = wave >> 2;
@@ -717,12 +772,11 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[0][s]), acc0, 0, 0, 0); \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, qh[1][s]), acc1, 0, 0, 0); \
             }                                                                                             \
-            /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue); CELL8: two */ \
+            /* the previous tile's four table stores, one every twelve MFMAs (see the epilogue) */            \
             if (s == 0) CLB_TM_STORE(o0, a0)                                                              \
-            if (s == 2 && !CELL8) CLB_TM_STORE(o1, a1)                                                    \
-            if (s == 4 && !CELL8) CLB_TM_STORE(o2, a2)                                                    \
-            if (s == 4 && CELL8) CLB_TM_STORE(o1, a1)                                                     \
-            if (s == 6 && !CELL8) CLB_TM_STORE(o3, a3)                                                    \
+            if (s == 2) CLB_TM_STORE(o1, a1)                                                              \
+            if (s == 4) CLB_TM_STORE(o2, a2)                                                              \
+            if (s == 6) CLB_TM_STORE(o3, a3)                                                              \
         }                                                                                                 \
     }
     // epilogue of tile TL: group lists, then the 32 x 32 scores of each query become one 2-KB block of fp16 rows
@@ -731,25 +785,14 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #define CLB_TM_EPI(TL)                                                                                    \
     {                                                                                                     \
         const int c0 = (TL) * 32;                                                                         \
-        topn_insert_lazy<kTopPartial>(bv0, bi0, group_max16(acc0, c0, h, K), 2 * (TL) + h);               \
-        topn_insert_lazy<kTopPartial>(bv1, bi1, group_max16(acc1, c0, h, K), 2 * (TL) + h);               \
+        const float g0_ = group_max16(acc0, c0, h, K), g1_ = group_max16(acc1, c0, h, K);                 \
+        topn_insert_lazy<kTopPartial>(bv0, bi0, g0_, 2 * (TL) + h);                                       \
+        topn_insert_lazy<kTopPartial>(bv1, bi1, g1_, 2 * (TL) + h);                                       \
+        if (RANGE) {    /* the token's range (rows past K are copies of row K - 1: they cannot widen it) */ \
+            rmax0 = fmaxf(rmax0, g0_); rmax1 = fmaxf(rmax1, g1_);                                         \
+            rmin0 = fminf(rmin0, group_min16(acc0)); rmin1 = fminf(rmin1, group_min16(acc1));             \
+        }                                                                                                 \
         __builtin_amdgcn_wave_barrier();                                                                  \
-        if (CELL8) {                                                                                      \
-            /* one 1-KB block of 32-byte rows [centroid][token] per query: byte i of row cl                */ \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;                                            \
-                patch[cl * 32 + i] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(acc0[r], rs0, 127.5f)), 0u, 0u);        \
-                patch[1024 + cl * 32 + i] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(acc1[r], rs1, 127.5f)), 0u, 0u); \
-            }                                                                                             \
-            __builtin_amdgcn_wave_barrier();                                                              \
-            o0 = *reinterpret_cast<const u32x4*>(patch + lane * 16);                                      \
-            o1 = *reinterpret_cast<const u32x4*>(patch + 1024 + lane * 16);                               \
-            unsigned char* d0_ = reinterpret_cast<unsigned char*>(cells16 + ((size_t)bq0 * K + c0) * 8) + lane * 16;  \
-            unsigned char* sp_ = spill + lane * 16;                                                       \
-            const bool in_ = c0 + (lane >> 1) < K;                      /* centroid of the 16-B piece */     \
-            a0 = bq0 < B && in_ ? d0_ : sp_;                                                              \
-            a1 = bq0 + 1 < B && in_ ? d0_ + (size_t)K * 32 : sp_;                                         \
-        } else {                                                                                          \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
             const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;                                                \
             *reinterpret_cast<__half*>(patch + cl * 64 + i * 2) = __float2half_rn(acc0[r]);               \
@@ -768,16 +811,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         a1 = bq0 < B && in1_ ? d0_ + 1024 : sp_ + 1024;                                                   \
         a2 = bq0 + 1 < B && in0_ ? d1_ : sp_;                                                             \
         a3 = bq0 + 1 < B && in1_ ? d1_ + 1024 : sp_ + 1024;                                               \
-        }                                                                                                 \
     }
     unsigned char* patch = lds16 + 2 * (2 * 32 * kRowBytes16) + wave * 4096;      // one 2-KB patch per query
-    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * (CELL8 ? 8 : 16));
-    // CELL8: 1 / step of token i of the wave's two queries (0 past T and past the batch: those cells are never read)
-    float rs0 = 0.f, rs1 = 0.f;
-    if (CELL8) {
-        rs0 = tscale[(size_t)(bq0 < B ? bq0 : B - 1) * 32 + i].y;
-        rs1 = tscale[(size_t)(bq0 + 1 < B ? bq0 + 1 : B - 1) * 32 + i].y;
-    }
+    unsigned char* spill = reinterpret_cast<unsigned char*>(cells16 + (size_t)B * K * 16);
+    float rmin0 = __builtin_inff(), rmin1 = rmin0, rmax0 = -__builtin_inff(), rmax1 = rmax0;
     f32x16 acc0, acc1;
     // the table stores of a tile are issued during the NEXT tile's MFMA phase (data in o0..o3, addresses in a0..a3; the
     // first phase stores zeros to the spill block, the last tile's stores follow the loop)
@@ -788,10 +825,10 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // epilogue.  Between two barriers team 0 therefore runs MFMA(k), epilogue(k) and team 1 epilogue(k-1), MFMA(k).
     // The buffer written before barrier k+1 held tile k-1, whose last reads (MFMA(k-1), either team) precede barrier k.
     // stage: the registers hold the tile after the staged one (requested one stage ago); behind those two loads are
-    // exactly the four stores of one MFMA phase, hence vmcnt(4) (CELL8: two stores, vmcnt(2))
+    // exactly the four stores of one MFMA phase, hence vmcnt(4)
 #define CLB_TM_STAGE()                                                                                    \
     {                                                                                                     \
-        if (CELL8) CLB_TM_WAIT(2) else CLB_TM_WAIT(4)                                                     \
+        CLB_TM_WAIT(4)                                                                                    \
         unsigned char* nb_ = lds16 + (buf ^ 1) * (2 * 32 * kRowBytes16);                                  \
         *reinterpret_cast<u32x4*>(nb_ + prow * kRowBytes16 + 16 * pchunk) = ph;                           \
         if (!X1) *reinterpret_cast<u32x4*>(nb_ + (32 + prow) * kRowBytes16 + 16 * pchunk) = pl;           \
@@ -820,8 +857,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // the last stage requested one more (clamped) tile: its two loads must have landed before their destination
     // registers die -- hipcc does not know they are in flight and would hand the registers to the code below
     CLB_TM_WAIT(0)
-    CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1)                                              // the last tile's
-    if (!CELL8) { CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3) }
+    CLB_TM_STORE(o0, a0) CLB_TM_STORE(o1, a1) CLB_TM_STORE(o2, a2) CLB_TM_STORE(o3, a3)    // the last tile's
 #undef CLB_TM_STAGE
 #undef CLB_TM_LOAD
 #undef CLB_TM_WAIT
@@ -841,6 +877,12 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int p = 0; p < kTopPartial; ++p) out[p] = ValIdx{bv1[p], bi1[p]};
     }
+    if (!RANGE) return;
+    // the work-group's range of token i, both lane halves combined (a work-group without a tile leaves +inf / -inf)
+    rmin0 = fminf(rmin0, __shfl_xor(rmin0, 32, 64)); rmax0 = fmaxf(rmax0, __shfl_xor(rmax0, 32, 64));
+    rmin1 = fminf(rmin1, __shfl_xor(rmin1, 32, 64)); rmax1 = fmaxf(rmax1, __shfl_xor(rmax1, 32, 64));
+    if (h == 0 && bq0 < B) rangep[((size_t)bq0 * 32 + i) * gridDim.x + blockIdx.x] = make_float2(rmin0, rmax0);
+    if (h == 0 && bq0 + 1 < B) rangep[((size_t)(bq0 + 1) * 32 + i) * gridDim.x + blockIdx.x] = make_float2(rmin1, rmax1);
 }
 
 // One wave per (token, query).  The partial lists hold GROUPS (16 centroids of one tile, see group_max16) keyed by
@@ -1124,10 +1166,10 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // two streams, but the second accumulator set takes the kernel to the 168-VGPR cap of three waves per SIMD (7-24 spilled
 // registers) and the pass got SLOWER on every workload (0.662 -> 0.672 ms, uniform codes 1.46 -> 1.56, built index
 // 0.653 -> 0.699; the row sweep 0.069 -> 0.107): the pass is not short of issue slots, it waits on memory.
-// CELL8 = true (round 6): the score rows are 32-byte rows of 8-bit cells (token_scale_kernel's comment).  Lane (r, h) fetches
+// CELL8 = true (round 6): the score rows are 32-byte rows of 8-bit cells (token_range_kernel's comment).  Lane (r, h) fetches
 // ONE 16-byte piece (tokens 16h .. 16h+15 of row code_r) and expands it with eight v_perm_b32 to the fp16 values 1024 + cell
-// (0x6400 | cell), which the two selection MFMAs add into an accumulator that starts at -1151.5 = -(1024 + 127.5): after
-// them it holds cell - 127.5 EXACTLY.  The query operand is fp16(Q_t / step_t), so the eight Q.r MFMAs add Q_t.r / step_t and
+// (0x6400 | cell), which the two selection MFMAs add into an accumulator that starts at k_t - 1024 (lane = token): after
+// them it holds cell + k_t.  The query operand is fp16(Q_t / step_t), so the eight Q.r MFMAs add Q_t.r / step_t and
 // acc * step_t is the token's score: the positive per-token factor commutes with the maximum over a passage's embeddings and
 // is applied once per passage (the row sweep applies it per value: the same product for the row that holds the maximum).
 // GL = 1: two adjacent lanes fetch a row -- ONE DMA instruction per step, a 1-KB ring slot, vmcnt(3).
@@ -1138,7 +1180,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,
     int B, size_t cand_cap, uint16_t* __restrict__ tokmax, const int* __restrict__ list,
     const int* __restrict__ nlist, const float* __restrict__ eps_pair, unsigned long long* __restrict__ rowmask,
-    const float2* __restrict__ tscale = nullptr) {
+    const float4* __restrict__ tscale = nullptr) {
     const uint32_t cmask = (1u << cbits) - 1u;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -1208,8 +1250,9 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
         // B operand: fp16 Q[t = r][64h + 8s + j], k-steps s = 0..7
         u32x4 qb[8];
         // CELL8: token r's step (score units per cell) and its inverse, the factor of the fp16 query operand
-        const float2 ts = CELL8 ? tscale[(size_t)b * 32 + r] : make_float2(1.f, 1.f);
+        const float4 ts = CELL8 ? tscale[(size_t)b * 32 + r] : make_float4(1.f, 1.f, 0.f, 0.f);
         const float stp = ts.x;
+        const float acc_init = CELL8 ? ts.z - 1024.0f : 0.f;
         {
             const float* qrow = Q + ((size_t)b * T + (r < T ? r : T - 1)) * kDim + 64 * h;
 #pragma unroll
@@ -1341,7 +1384,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = CELL8 ? -1151.5f : 0.f;                     \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = acc_init;                                   \
         if (CELL8) {         /* byte b -> fp16 1024 + b (0x6400 | b): two cells per v_perm_b32 */            \
             const u32x4 raw_ = X0;                                                                          \
             X0 = u32x4{__builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04010400u), __builtin_amdgcn_perm(0x64646464u, raw_[0], 0x04030402u), \
@@ -1565,21 +1608,26 @@ struct ApproxConsts {
 // The error bound of one query (see the header of this file): eps_t bounds |approx - canonical| of ONE (token, embedding)
 // score, eps_sum the same for a passage score (T tokens); `unsafe` = the fp16 score table cannot be trusted for this
 // query.  Called by all 1 024 threads of a work-group (two barriers); s_qn / s_dq are two shared floats.
-// tscale != nullptr: the batch's score table holds 8-bit cells (token_scale_kernel) and pass 1 multiplies fp16(Q_t / step_t):
-//   cells:  computed score vs canonical (the product bound) + half a step + the rounding of fma / rint: 0.5005 * max_t step_t
+// tscale != nullptr: the batch's score table came from the batched centroid kernel, which measured every token's score range
+// (token_range_kernel: {step_t, 1 / step_t, k_t, A_t = max_c |score|}).  The fp16 table's storage error is then 2^-11 A_t.
+// cell8: the table holds 8-bit cells requantised FROM that fp16 table, and pass 1 multiplies fp16(Q_t / step_t):
+//   cells:  computed score vs canonical (the product bound) + the fp16 rounding (2^-11 A_t) + half a step + the rounding of
+//           fma / rint / k_t: 0.5005 * max_t step_t + 8 u A_t
 //   Q.r:    Q_t . r - step_t * (fp16(q'_t) . r')  =  (Q_t - step_t fp16(q'_t)) . r' + Q_t . (r - r'),  q'_t = fl(Q_t * (1 / step_t)):
 //           ||Q_t - step_t fp16(q'_t)|| <= step_t * ||q'_t - fp16(q'_t)|| (measured: dq8) + 2 u ||Q_t|| (the two roundings of q'_t)
-//   MFMA:   the accumulator holds cell - 127.5 exactly after the two selection products; the 128 products that follow add up
-//           to at most 127.5 + |q'_t . r'| in cell units = (R_t + qn rn) in score units: 2 * 130 * u of that
-// and the query is unsafe when a token's range is too small to invert or its scaled operand could leave the fp16 range.
+//   MFMA:   the accumulator starts at k_t - 1024 and holds cell + k_t after the two selection products; the partial sums of
+//           the 130 accumulations stay below |k_t| + 255 + |q'_t . r'| in cell units = A_t + 255 step_t + qn rn in score
+//           units (|k_t| step_t = |lo_t| <= A_t): 2 * 130 * u of that, and 1280 u step_t for the start value's own rounding
+// and the query is unsafe when a token's range is not a pair of finite numbers or its scaled operand could leave the fp16 range.
 struct QueryBound { float eps_t, eps_sum; bool unsafe; };
 __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, int b, int T, const ApproxConsts& ac,
-                                                  float* s_qn, float* s_dq, const float2* __restrict__ tscale = nullptr,
-                                                  float* s_aux = nullptr /* 3 shared floats when tscale is given */) {
+                                                  float* s_qn, float* s_dq, const float4* __restrict__ tscale = nullptr,
+                                                  float* s_aux = nullptr /* 4 shared floats when tscale is given */,
+                                                  bool cell8 = false) {
     const int tid = threadIdx.x;
     // qn = max_t ||Q_t||  (plain fp32 sum, upper-bounded by the 1.001 factor below)
     if (tid == 0) { *s_qn = 0.f; *s_dq = 0.f; }
-    if (tscale && tid < 3) s_aux[tid] = 0.f;     // [0] max_t step_t ||q'_t - fp16(q'_t)||, [1] max_t step_t, [2] bad-token flag
+    if (tscale && tid < 4) s_aux[tid] = 0.f;     // [0] max_t step_t ||q'_t - fp16(q'_t)||, [1] max_t step_t, [2] bad-token flag, [3] max_t A_t
     __syncthreads();
     {   // 32 threads per token, one float4 each (T <= 32 in this mode).  dq = max_t ||Q_t - fp16(Q_t)||: what the
         // fp16 query operand of pass 1 really loses (at most 2^-12 ||Q_t|| in the normal range)
@@ -1591,8 +1639,8 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
             const float dx = v.x - round_f16(v.x), dy = v.y - round_f16(v.y);
             const float dz = v.z - round_f16(v.z), dw = v.w - round_f16(v.w);
             dd = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, dw * dw)));
-            if (tscale) {
-                const float2 ts = tscale[(size_t)b * 32 + t];
+            if (tscale && cell8) {
+                const float4 ts = tscale[(size_t)b * 32 + t];
                 const float sx = v.x * ts.y, sy = v.y * ts.y, sz = v.z * ts.y, sw = v.w * ts.y;   // pass 1's operand before its fp16 rounding
                 const float ex = sx - round_f16(sx), ey = sy - round_f16(sy), ez = sz - round_f16(sz), ew = sw - round_f16(sw);
                 d8 = fmaf(ex, ex, fmaf(ey, ey, fmaf(ez, ez, ew * ew)));
@@ -1604,11 +1652,13 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
             atomicMax(reinterpret_cast<unsigned int*>(s_qn), __float_as_uint(sqrtf(a) * 1.001f));
             atomicMax(reinterpret_cast<unsigned int*>(s_dq), __float_as_uint(sqrtf(dd) * 1.001f));
             if (tscale) {
-                const float2 ts = tscale[(size_t)b * 32 + t];
+                const float4 ts = tscale[(size_t)b * 32 + t];
                 atomicMax(reinterpret_cast<unsigned int*>(s_aux), __float_as_uint(ts.x * sqrtf(d8) * 1.001f));
                 atomicMax(reinterpret_cast<unsigned int*>(s_aux + 1), __float_as_uint(ts.x));
-                // a non-zero token whose range cannot be inverted (token_scale_kernel wrote zeros), or is close to that
-                if (a > 0.f && !(sqrtf(a) * ac.cn_max >= 100.f * kCell8MinNorm && ts.x > 0.f)) s_aux[2] = 1.f;
+                atomicMax(reinterpret_cast<unsigned int*>(s_aux + 3), __float_as_uint(ts.w));
+                // no usable range (token_range_kernel wrote zeros), or a scaled operand |q'_t| <= ||Q_t|| / step_t that could
+                // leave the fp16 range
+                if (!(ts.x > 0.f) || !(sqrtf(a) * ts.y < 3.0e4f)) s_aux[2] = 1.f;
             }
         }
     }
@@ -1624,11 +1674,17 @@ __device__ __forceinline__ QueryBound query_bound(const float* __restrict__ Q, i
     float e_tab = e_cells;
     bool bad8 = false;
     if (tscale) {
-        const float dq8 = s_aux[0], step_max = s_aux[1];
-        e_tab = kEpsSafety * centroid_product_bound(qn, *s_dq, ac.cn_max, ac.dc_max) + 0.5005f * step_max;
-        e_qr = 1.001f * ((dq8 + 2.f * u * qn) * ac.rb_max + qn * ac.dw_rn) + 2.f * 130.f * u * (128.f * step_max + qn * ac.rn_max);
-        // |q'| <= 127.5 / cn_max must stay inside the fp16 range (cn_max is checked at index load as well)
-        bad8 = s_aux[2] != 0.f || !(127.5f < 3.0e4f * ac.cn_max);
+        // the measured magnitude of the computed scores (never above what the norms allow; NaN-safe: fminf returns the number)
+        const float amax = s_aux[2] != 0.f ? qn * ac.cn_max : fminf(s_aux[3] * 1.0001f, qn * ac.cn_max);
+        const float e_f16 = kEpsSafety * centroid_product_bound(qn, *s_dq, ac.cn_max, ac.dc_max) + 4.8828125e-04f * amax + 2.9802322e-08f;
+        e_tab = e_f16;
+        if (cell8) {
+            const float dq8 = s_aux[0], step_max = s_aux[1];
+            e_tab = e_f16 + 0.5005f * step_max + 8.f * u * amax;
+            e_qr = 1.001f * ((dq8 + 2.f * u * qn) * ac.rb_max + qn * ac.dw_rn) +
+                   2.f * 130.f * u * (amax + 255.f * step_max + qn * ac.rn_max) + 1280.f * u * step_max;
+            bad8 = s_aux[2] != 0.f;
+        }
     }
     // the packed inv_norm is off by at most inv_qerr: it scales P = X + Q.r, |P| <= qn (cn + rn), and the other terms
     const float eps_t = (ac.inv_max + ac.inv_qerr) * (e_tab + e_qr) + 1.01f * ac.inv_qerr * qn * (ac.cn_max + ac.rn_max) + 332.f * u * qn;
@@ -1652,9 +1708,10 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    float* __restrict__ eps_pair,
                                                                    const float* __restrict__ tau_in = nullptr,
                                                                    int coarse_tau = 0,
-                                                                   const float2* __restrict__ tscale = nullptr) {
+                                                                   const float4* __restrict__ tscale = nullptr,
+                                                                   int cell8 = 0) {
     __shared__ __attribute__((aligned(16))) int hist[256];
-    __shared__ float s_aux[3];
+    __shared__ float s_aux[4];
     __shared__ int sh_scan[16];
     __shared__ int sh_big[2][8][16];
     __shared__ uint32_t s_prefix, s_kmin, s_kmax;
@@ -1665,7 +1722,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const float* sc = scores + (size_t)b * cand_cap;
     int* lst = list + (size_t)b * cand_cap;
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
-    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux);
+    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux, cell8 != 0);
     float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
     const bool unsafe = qb.unsafe;
     if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
@@ -1883,9 +1940,10 @@ static __global__ __launch_bounds__(1024) void wide_minmax_kernel(const float* _
                                                                  const float* __restrict__ Q, int T, size_t cand_cap,
                                                                  ApproxConsts ac, WideSel* __restrict__ wsel,
                                                                  float* __restrict__ eps_pair,
-                                                                 const float2* __restrict__ tscale = nullptr) {
+                                                                 const float4* __restrict__ tscale = nullptr,
+                                                                 int cell8 = 0) {
     __shared__ uint32_t s_kmin, s_kmax;
-    __shared__ float s_qn, s_dq, s_aux[3];
+    __shared__ float s_qn, s_dq, s_aux[4];
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int n = ncand[b];
     const float* sc = scores + (size_t)b * cand_cap;
@@ -1893,7 +1951,7 @@ static __global__ __launch_bounds__(1024) void wide_minmax_kernel(const float* _
     if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0u; }
     __syncthreads();
     if (g == 0) {                                         // uniform over the work-group
-        const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux);
+        const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux, cell8 != 0);
         if (tid == 0) {
             eps_pair[b] = qb.unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
             w.unsafe = qb.unsafe ? 1 : 0;

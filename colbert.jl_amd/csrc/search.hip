@@ -64,12 +64,13 @@ struct Workspace {
     size_t cand_cap = 0;
     int W = 0, nblk_bitmap = 0, topn_blocks = 0;
     bool x1_table = false;      // the score table in cells_q came from the single-fp16-product kernel: the bound carries its terms
-    bool cell8 = false;         // the score table in cells_q holds 32-byte rows of 8-bit cells (tscale: their per-token steps)
+    bool have_range = false;    // tscale holds this batch's measured score ranges (the batched centroid kernel ran)
+    bool cell8 = false;         // pass 1 gathers from cells8: 32-byte rows of 8-bit cells requantised from cells_q by tscale
     bool stats_keep = false;    // set for the 2nd, 3rd ... sub-batch of one call: the work counters accumulate over the call
     // two-phase sharded search: what clb_search_shard_phase1 left behind (phase 2 must continue exactly that batch)
     struct { bool valid = false; const float* dQ = nullptr; int64_t T = 0, B = 0, nprobe = 0, k = 0; void* stream = nullptr; } pending;
     DevBuf Qdev, cells, cells_q, partial, sel, bitmap, blocksum, ncand, cand, cand_hdr, scores, list, nlist, thresh,
-        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds, tscale;
+        outp, outs, flags, stats, redo, rowmask, eps_pair, tokmax, tau_glob, wsel, bounds, tscale, rangep, cells8;
     DevBuf g_cells, g_keys, g_keys2, g_vals, g_vals2, g_scratch, g_sort_tmp;   // general-shape path (generic_kernels.hpp)
 };
 
@@ -108,10 +109,8 @@ struct clb_searcher {
     int s1_mode = 1;    // 1: bf16x3 + exact refine, 0: fp32 MFMA
     int gather_lds = 0; // pass 1: score rows through LDS-DMA, four adjacent lanes per row (0: the per-lane VGPR gather); set at load
     double code_adjacency = 0.0;   // fraction of consecutive embeddings that share a 128-B line of the score table
-    int cell8 = -1;     // batches of 16+ queries: score rows as 32 bytes of 8-bit cells?  1 yes, 0 fp16 rows, -1 by the code statistics
-                        // (yes when the row gather dominates pass 1: codes that are not id-adjacent) -- on a shard of a group
-                        // (bounds_synced) -1 means no: every shard's bound must cover every shard's table, so the group's driver
-                        // sets the form alike on all shards (clb_searcher_set_score_rows)
+    int cell8 = -1;     // batches of 16+ queries: score rows as 32 bytes of 8-bit cells?  1 yes, 0 / -1 (default) fp16 rows.  On the
+                        // shards of a group every shard's bound must cover every shard's table: set it alike on all shards
     ApproxConsts approx_consts{};
     std::vector<uint32_t> ivf_len_sorted;  // descending, for the candidate-capacity bound
     Workspace ws[kWorkspaceSlots];   // per-batch scratch, grown on demand (ensure_workspace); slots 1..: further batches in flight
@@ -154,12 +153,9 @@ struct Timed {
 // token tiles of 32 for the cells table: Tpad in {32, 64, 128} so that it divides the 256-thread scan
 inline int token_tiles(int64_t T) { return T <= 32 ? 1 : T <= 64 ? 2 : 4; }
 
-// 8-bit score rows for this handle's batches of 16+ queries?  (cn_max >= 0.01: the scaled fp16 query operand of pass 1,
-// |q'| <= 127.5 / cn_max, stays far inside the fp16 range)
-inline bool cell8_rows(const clb_searcher* s) {
-    const bool by_codes = s->code_adjacency < 0.2 && !s->bounds_synced;
-    return (s->cell8 == 1 || (s->cell8 < 0 && by_codes)) && s->approx_ok && s->approx_consts.cn_max >= 0.01f;
-}
+// 8-bit score rows for this handle's batches of 16+ queries?
+// (round 6: only when asked for -- measured end to end the format loses on all four workloads, profiles/r06_experiments.md)
+inline bool cell8_rows(const clb_searcher* s) { return s->cell8 == 1 && s->approx_ok; }
 
 // the top-k kernel sorts up to kMaxTopK 8-byte keys in LDS: beyond 64 KB the attribute has to be raised
 void allow_large_topk_lds() {
@@ -271,6 +267,8 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
     const int n_tiles = (int)((s->K + 31) / 32);
     const bool want_half = s->mode == 1 && s->approx_ok && T <= 32;
     w.x1_table = false;
+    w.have_range = false;
+    w.cell8 = false;
     if (nprobe <= 2 && T <= 32) {
         // fused S1+S2: no fp32 score matrix; fp16 pairs only when pass 1 will gather them
         // batches of 8+ queries share each staged centroid tile between 8 queries (centroid_top_bf16x3_mq_kernel)
@@ -290,9 +288,11 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
         const bool x1 = teams && (s->s1_x1 == 1 || (s->s1_x1 < 0 && s->bounds_synced)) && s->cent_f16.p && s->dc_f16 > 0.f;
         w.x1_table = x1;
         w.cell8 = teams && cell8_rows(s);
+        w.have_range = w.cell8;
         if (w.cell8) {
-            CLB_TRY(w.tscale.ensure(sizeof(float2) * 32 * B));
-            hipLaunchKernelGGL(token_scale_kernel, dim3(B), dim3(1024), 0, st, dQ, T, s->approx_consts.cn_max, w.tscale.as<float2>());
+            CLB_TRY(w.tscale.ensure(sizeof(float4) * 32 * B));
+            CLB_TRY(w.rangep.ensure(sizeof(float2) * 32 * B * gx));
+            CLB_TRY(w.cells8.ensure((size_t)B * s->K * 32));
         }
         const int nslots = mq ? gx * 2 : gx * 4;
         CLB_TRY(w.partial.ensure(sizeof(ValIdx) * (size_t)B * nslots * 32 * kTopPartial));
@@ -314,7 +314,14 @@ int run_retrieve(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ,
                                        x1 ? s->cent_f16.as<uint16_t>() : s->cent_hi.as<uint16_t>(),
                                        x1 ? (const uint16_t*)nullptr : (const uint16_t*)s->cent_lo.as<uint16_t>(), dQ,
                                        w.partial.as<ValIdx>(), w.cells_q.as<uint32_t>(), (int)s->K, T, B, n_tiles,
-                                       (const float2*)w.tscale.as<float2>());
+                                       w.rangep.as<float2>());
+                    if (w.cell8) {     // 8-bit rows: every token's measured score range, then the table rewritten by it
+                        hipLaunchKernelGGL(token_range_kernel, dim3(B), dim3(1024), 0, st, (const float2*)w.rangep.as<float2>(), gx, T,
+                                           w.tscale.as<float4>());
+                        hipLaunchKernelGGL(requantise_cells_kernel, dim3(std::max(1, 2048 / B), B), dim3(256), 0, st,
+                                           (const uint32_t*)w.cells_q.as<uint32_t>(), (const float4*)w.tscale.as<float4>(),
+                                           w.cells8.as<uint32_t>(), (int)s->K);
+                    }
                 } else if (mq && want_half)
                     hipLaunchKernelGGL(centroid_top_bf16x3_mq_kernel<true>, dim3(gx, groups), dim3(256), lds_b16 + 4 * 2048, st,
                                        s->cent_hi.as<uint16_t>(), s->cent_lo.as<uint16_t>(), dQ,
@@ -613,10 +620,10 @@ void launch_pass1(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
 #endif
     hipLaunchKernelGGL(kern, grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
-                       w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                       (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
+                       w.cell8 ? w.cells8.as<uint32_t>() : w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(),
+                       w.scores.as<float>(), (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), (const int*)nullptr,
                        (const int*)nullptr, (const float*)nullptr, (unsigned long long*)nullptr,
-                       (const float2*)w.tscale.as<float2>());
+                       (const float4*)w.tscale.as<float4>());
 }
 // The centroid side of the single-product score table in the error bound: when this batch's table was made that way -- and,
 // on a shard of a group, whenever a shard MAY make its tables that way (the threshold tau comes from every shard's
@@ -637,7 +644,7 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
         hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
                            w.cand_cap, ac, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
                            w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0,
-                           w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
+                           w.have_range ? (const float4*)w.tscale.as<float4>() : (const float4*)nullptr, w.cell8 ? 1 : 0);
         return CLB_OK;
     }
     CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
@@ -647,7 +654,7 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
     acw.dc_max = bound_dc(s, w);
     hipLaunchKernelGGL(wide_minmax_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, w.cand_cap,
                        acw, w.wsel.as<WideSel>(), w.eps_pair.as<float>(),
-                       w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
+                       w.have_range ? (const float4*)w.tscale.as<float4>() : (const float4*)nullptr, w.cell8 ? 1 : 0);
     if (!tau_in)
         for (int pass = 0; pass < 4; ++pass)
             hipLaunchKernelGGL(wide_hist_kernel, grid, dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), k, w.cand_cap,
@@ -770,9 +777,9 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
         auto rows_kernel = w.cell8 ? score_approx32_kernel<true, 0, 0, 0, true> : score_approx32_kernel<true, 0, 0, 0, false>;
         hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                            s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
-                           w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(), w.scores.as<float>(),
-                           (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist, w.eps_pair.as<float>(),
-                           w.rowmask.as<unsigned long long>(), (const float2*)w.tscale.as<float2>());
+                           w.cell8 ? w.cells8.as<uint32_t>() : w.cells_q.as<uint32_t>(), w.cand_hdr.as<uint2>(), w.ncand.as<int>(),
+                           w.scores.as<float>(), (int)s->K, T, B, w.cand_cap, w.tokmax.as<uint16_t>(), list, nlist,
+                           w.eps_pair.as<float>(), w.rowmask.as<unsigned long long>(), (const float4*)w.tscale.as<float4>());
     }
     {
         Timed t(s, KID_SCORE_EXACT, st);
@@ -1052,7 +1059,7 @@ int64_t clb_searcher_device_bytes(const clb_searcher* s) {
     int64_t tot = s->index_bytes;
     for (const auto& w : s->ws) {
         const DevBuf* bufs[] = {&w.Qdev, &w.cells, &w.cells_q, &w.partial, &w.sel, &w.bitmap, &w.blocksum, &w.ncand, &w.cand,
-                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax, &w.tau_glob, &w.tscale};
+                                &w.cand_hdr, &w.scores, &w.list, &w.nlist, &w.thresh, &w.outp, &w.outs, &w.flags, &w.stats, &w.redo, &w.rowmask, &w.eps_pair, &w.tokmax, &w.tau_glob, &w.tscale, &w.rangep, &w.cells8};
         for (auto* b : bufs) tot += (int64_t)b->bytes;
     }
     return tot;
@@ -1101,9 +1108,8 @@ int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency) {
 
 int clb_searcher_set_score_rows(clb_searcher* s, int form) {
     if (!s) return fail(CLB_EARGUMENT, "null searcher");
-    if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "score rows must be -1 (by the code statistics), 0 (64-byte fp16 rows) or 1 (32-byte rows of 8-bit cells)");
-    if (form == 1 && !(s->approx_ok && s->approx_consts.cn_max >= 0.01f))
-        return fail(CLB_EUNSUPPORTED, "8-bit score rows need the two-pass mode and centroids of norm >= 0.01");
+    if (form < -1 || form > 1) return fail(CLB_EARGUMENT, "score rows must be -1 (default: fp16), 0 (64-byte fp16 rows) or 1 (32-byte rows of 8-bit cells)");
+    if (form == 1 && !s->approx_ok) return fail(CLB_EUNSUPPORTED, "8-bit score rows need the two-pass mode (dim=128, nbits=2)");
     s->cell8 = form;
     return CLB_OK;
 }
@@ -1339,7 +1345,7 @@ int clb_debug_scores(clb_searcher* s, const float* Q, int64_t T, int64_t nprobe,
     hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ,
                        (int)T, (int)k, w.cand_cap, s->approx_consts, w.list.as<int>(), w.nlist.as<int>(),
                        w.thresh.as<float>(), w.eps_pair.as<float>(), (const float*)nullptr, 0,
-                       w.cell8 ? (const float2*)w.tscale.as<float2>() : (const float2*)nullptr);
+                       w.have_range ? (const float4*)w.tscale.as<float4>() : (const float4*)nullptr, w.cell8 ? 1 : 0);
     int nc = 0, nl = 0;
     float th[2];
     CLB_HIP(hipMemcpyAsync(&nc, w.ncand.p, sizeof(int), hipMemcpyDeviceToHost, st));

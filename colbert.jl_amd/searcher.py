@@ -116,7 +116,7 @@ class Searcher:
 
     def set_score_rows(self, form: int):
         """Batches of 16+ queries, two-pass mode: 0 = 64-byte fp16 score rows, 1 = 32-byte rows of 8-bit cells, -1 = default
-        (1 when the index's codes are not id-adjacent; 0 on a shard of a group: set it alike on every shard)."""
+        (0: the 8-bit format is faster in pass 1 only; set it alike on every shard of a group)."""
         check(lib().clb_searcher_set_score_rows(self._h, C.c_int(form)))
 
     @property

@@ -132,11 +132,11 @@ int clb_searcher_set_pass1_gather(clb_searcher* s, int form);
 int clb_searcher_get_pass1_gather(const clb_searcher* s, double* adjacency);
 /* Row format of the centroid-score table pass 1 gathers from, for batches of 16 or more queries in the two-pass mode (the
  * (32, K) cells matrix of ranking.jl:27-30; no call site of its own in the reference): form = 0, 64-byte rows of fp16 scores;
- * form = 1, 32-byte rows of 8-bit cells, linear per (query, token) over the range +-||Q_t|| max||c|| with half a step in the
- * error bound -- half the gathered bytes, a few more passages re-scored exactly; form = -1, the default: 1 when the index's
- * codes are not id-adjacent (the statistic of clb_searcher_get_pass1_gather below 0.2: the row gather then dominates pass 1),
- * 0 otherwise and on a shard of a group (set the form alike on all shards).  Returned pids and scores are identical either
- * way.  The getter returns the form batches of 16+ queries take. */
+ * form = 1, 32-byte rows of 8-bit cells, linear per (query, token) over the range that token's K scores span (measured by the
+ * centroid kernel; the fp16 table is requantised), with half a step in the error bound -- half the gathered bytes, pass 1
+ * 12-20 % faster where the codes are not id-adjacent, but about twice the rows re-scored exactly: measured end to end it
+ * loses on every workload of bench.py, so form = -1, the default, is 0.  Returned pids and scores are identical either
+ * way; on the shards of a group set the form alike on all shards.  The getter returns the form batches of 16+ queries take. */
 int clb_searcher_set_score_rows(clb_searcher* s, int form);
 int clb_searcher_get_score_rows(const clb_searcher* s);
 /* Products of the batched centroid stage (the Q x centroids GEMM of ranking.jl:9-13 for batches of 16 or more queries in

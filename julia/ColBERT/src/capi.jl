@@ -33,7 +33,7 @@ _searcher_destroy(h::Ptr{Cvoid}) = ccall((:clb_searcher_destroy, libcolbert), Ci
 "selection step by one (0) or sixteen (1) work-groups per query; -1 (default): chosen by the candidate capacity"
 _searcher_set_wide_select(h::Ptr{Cvoid}, on::Integer) =
     _check(ccall((:clb_searcher_set_wide_select, libcolbert), Cint, (Ptr{Cvoid}, Cint), h, on))
-"batches of 16+ queries: score rows as 64-byte fp16 rows (0) or 32-byte rows of 8-bit cells (1); -1 (default): by the index's code statistics, 0 on a shard of a group -- alike on every shard"
+"batches of 16+ queries: score rows as 64-byte fp16 rows (0) or 32-byte rows of 8-bit cells (1); -1 (default): 0 -- alike on every shard"
 _searcher_set_score_rows(h::Ptr{Cvoid}, form::Integer) =
     _check(ccall((:clb_searcher_set_score_rows, libcolbert), Cint, (Ptr{Cvoid}, Cint), h, form))
 "batches of 16+ queries: the fp16 score table from one fp16 product (1) or the three-product bf16 split (3); -1 (default): 1 on a shard of a group, 3 on one GPU -- alike on every shard"
