@@ -27,7 +27,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-HBM_COPY_GBS = 6290.0        # ... and the copy rate the guide measures on this part (the practical ceiling of a stream)
+GUIDE_COPY_GBS = 6290.0      # ... and the copy rate the guide quotes for this part; the line carries the rate MEASURED in the run
+MEASURED_COPY = {}           # device -> GB/s of a 1-GB device-to-device copy kernel, measured once per process (measured_copy_rate)
+
+
+def measured_copy_rate(clb, device):
+    """GB/s of clb_measure_copy_rate on this device: five 1-GB copies between two HIP events, once per run (~2 ms of copies)."""
+    if device not in MEASURED_COPY:
+        from colbert_jl_amd._lib import measure_copy_rate
+        MEASURED_COPY[device] = round(measure_copy_rate(device, 1 << 30, 5), 1)
+    return MEASURED_COPY[device]
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak
 
@@ -89,8 +98,9 @@ def launch_ranks(args):
     return failed[1] if failed else next((rc for rc in rcs if rc), 0)
 
 
-def roofline_of(kname, prof, stats, mode, T, K, B):
-    """Roofline record of one search kernel: ALGORITHMIC bytes / flops of a launch over its HIP-event time."""
+def roofline_of(kname, prof, stats, mode, T, K, B, copy_gbs=None):
+    """Roofline record of one search kernel: ALGORITHMIC bytes / flops of a launch over its HIP-event time.
+    copy_gbs: the copy rate measured in this run on this device (measured_copy_rate)."""
     ms_launch = prof[kname]["ms"] / max(prof[kname]["launches"], 1)
     embs, docs = stats["cand_embs"], stats["cand_docs"]
     if kname == "score_exact" and mode == 1:
@@ -110,8 +120,12 @@ def roofline_of(kname, prof, stats, mode, T, K, B):
         alg_bytes = BYTES_PER_EMB * embs + BYTES_PER_PID * docs
         ach = alg_bytes / (ms_launch * 1e-3) / 1e9
         r = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "measured_copy_rate": HBM_COPY_GBS,
-             "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4)}
+             "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if copy_gbs:
+            r["measured_copy_rate"] = copy_gbs
+            r["measured_copy_rate_how"] = "clb_measure_copy_rate in this run: 5 x 1 GB device-to-device, 16 B per lane, HIP events"
+            r["frac_of_measured_copy_rate"] = round(ach / copy_gbs, 4)
+        r["guide_copy_rate"] = GUIDE_COPY_GBS
     r["ms_per_launch"] = round(ms_launch, 4)
     r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
     return r
@@ -192,7 +206,7 @@ def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_q
                                     "rescored_passages": round(stats["rescored_docs"] / B, 1)}}
     if prof:
         dom = "score_approx" if "score_approx" in prof and prof["score_approx"]["launches"] else max(prof.items(), key=lambda kv: kv[1]["ms"])[0]
-        roof = roofline_of(dom, prof, stats, s.mode, T, K, B)
+        roof = roofline_of(dom, prof, stats, s.mode, T, K, B, copy_gbs=measured_copy_rate(clb, dev.index or 0))
         roof["traffic"] = None
         if pmc_key:      # profiles/pmc_summary_<workload>.json: the PMC passes of this sub-record's workload (tools/gpu_profile.sh)
             traffic_from_pmc(os.path.join(ROOT, "profiles", f"pmc_summary_{pmc_key}.json"), dom, stats, roof)
@@ -411,6 +425,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
+
+    def first_contact(what, fn):
+        """Run one step of the N-rank set-up; a failure names the rank and the step on stderr and ends THIS rank with code 3 at
+        once (the launcher -- launch_ranks above, or torchrun -- then stops the others): a first run on new hardware that
+        cannot form its communicator costs a minute and says why, instead of a timeout somewhere inside the timed region."""
+        try:
+            return fn()
+        except BaseException as e_:     # noqa: BLE001 -- including RuntimeError from RCCL and KeyboardInterrupt from a watchdog
+            print(f"[bench preflight] rank {rank}/{world} (device {local_rank}): {what} FAILED: {type(e_).__name__}: {e_}",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
     if world > 1 or args.force_gather:
         import torch.distributed as dist
         # COLBERT_BENCH_BACKEND / COLBERT_BENCH_DEVICE: test hooks to run several ranks on ONE GPU over gloo
@@ -424,11 +449,13 @@ def main():
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("COLBERT_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank), **kw)
+            first_contact("init_process_group(nccl = RCCL)", lambda: dist.init_process_group(
+                backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw))
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+            first_contact(f"init_process_group({backend})", lambda: dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw))
     if world != args.gpus:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different job size",
               file=sys.stderr)
@@ -439,7 +466,7 @@ def main():
     if world > 1 or args.force_gather:
         # counted by the communicator that moves the data (RCCL when the backend is nccl): every rank adds one
         one_t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(one_t, op=dist.ReduceOp.SUM)
+        first_contact("first all-reduce (rank count)", lambda: (dist.all_reduce(one_t, op=dist.ReduceOp.SUM), torch.cuda.synchronize()))
         ranks_seen = int(one_t.item())
         if ranks_seen != args.gpus and not args.force_gather:
             print(f"[bench] the communicator counts {ranks_seen} ranks, --gpus {args.gpus}", file=sys.stderr)
@@ -475,7 +502,8 @@ def main():
         s.set_mode(args.mode)
     if world > 1:
         from colbert_jl_amd.distributed import sync_bound_consts
-        sync_bound_consts(s)            # one error bound on every shard (the threshold of the two-phase search is global)
+        # one error bound on every shard (the threshold of the two-phase search is global)
+        first_contact("all-reduce of the error-bound constants", lambda: sync_bound_consts(s))
     t_load = time.time() - t0
     # the timed region (warmup + steps batches) never issues a query twice; longer legs (sustained, sweeps) cycle the pool
     n_queries = max(B * 8, 768, -(-B * (args.steps + args.warmup + 1) // 256) * 256)      # 768 at the default 3 + 20 steps of 32: profiling runs (fewer steps) see the same queries
@@ -595,6 +623,68 @@ def main():
             reps = int(r_t.item())
         n = reps * args.steps
         return n, timed(n, args.warmup + args.steps, pl)
+
+    # ---- N > 1, BEFORE any timing: one line per rank on stderr -- device, RCCL version, ranks seen, shard
+    # sizes, centroid checksum -- then ONE batch through every shard's search, the exchange and the merge, checked on rank 0
+    # against the CPU oracle's search of the UNSHARDED index.  Any failing collective, a rank whose replicated centroids differ,
+    # shards that do not tile the corpus, or a merged result that is not the oracle's end the run with a non-zero code here.
+    merged_check = None
+    if gather:
+        import zlib
+        cen = np.ascontiguousarray(shard["centroids"])
+        me = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "backend": backend,
+              "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+              "ranks_seen": ranks_seen, "passages": int(shard["doclens"].size), "embeddings": int(shard["codes"].size),
+              "pid_offset": int(shard["pid_offset"]), "centroids_crc32": f"{zlib.crc32(cen.tobytes()) & 0xffffffff:08x}",
+              "exchange": "two-phase" if two_phase else "single", "batch": B}
+        print("[bench preflight] " + json.dumps(me), file=sys.stderr, flush=True)
+        everyone = [None] * world
+        first_contact("all_gather_object of the rank descriptions", lambda: dist.all_gather_object(everyone, me))
+        problems = []
+        if len({e_["centroids_crc32"] for e_ in everyone}) != 1:
+            problems.append("the replicated centroids differ between ranks: " + ", ".join(f"rank {e_['rank']}: {e_['centroids_crc32']}" for e_ in everyone))
+        if world > 1:
+            order = sorted(everyone, key=lambda e_: e_["pid_offset"])
+            if order[0]["pid_offset"] != 0 or any(a["pid_offset"] + a["passages"] != b_["pid_offset"] for a, b_ in zip(order, order[1:])) \
+                    or order[-1]["pid_offset"] + order[-1]["passages"] != n_docs_total:
+                problems.append("the shards do not tile the corpus: " + ", ".join(f"rank {e_['rank']}: [{e_['pid_offset']}, +{e_['passages']})" for e_ in everyone))
+            if len({e_["device"] for e_ in everyone}) != world and backend == "nccl":
+                problems.append("two ranks share a device: " + ", ".join(f"rank {e_['rank']}: device {e_['device']}" for e_ in everyone))
+        if problems:
+            if rank == 0:
+                for p_ in problems:
+                    print("[bench preflight] FAILED: " + p_, file=sys.stderr, flush=True)
+            os._exit(4)
+        mp_, ms_ = first_contact("one batch: search of every shard + exchange + merge", lambda: (lambda o_: (barrier(), o_)[1])(plan.step(0)))
+        verdict = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        if rank == 0 and world > 1 and not args.no_cpu and not args.built_index:
+            from oracle import oracle as orc
+            orc.build()
+            t1 = time.time()
+            full = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks, blocks=range(n_blocks), topical=not args.uniform_codes)
+            full["emb2pid"] = orc.build_emb2pid(full["doclens"])
+            mp_h, ms_h = mp_.cpu().numpy(), ms_.cpu().numpy()
+            n_chk = min(plan.B, 8 if args.docs <= 400_000 else 4)
+            ok = True
+            for b in range(n_chk):
+                rp, rs, _ = orc.search(full, Q[:, :, b], args.nprobe, k)
+                ok = ok and bool(np.array_equal(rp, mp_h[b])) and bool(np.array_equal(rs.view(np.uint32), ms_h[b].view(np.uint32)))
+            merged_check = {"queries": n_chk, "merged_equals_oracle_on_the_unsharded_index": ok, "seconds": round(time.time() - t1, 1),
+                            "when": "before any timing (preflight)",
+                            "note": "pids identical and fp32 score bits identical, exchange = " + ("two-phase" if two_phase else "single")}
+            del full
+            print("[bench preflight] merged_vs_oracle " + json.dumps(merged_check), file=sys.stderr, flush=True)
+            verdict[0] = 1 if ok else 0
+        first_contact("broadcast of the preflight verdict", lambda: dist.broadcast(verdict, src=0))
+        if int(verdict.item()) != 1:
+            if rank == 0:
+                print("[bench preflight] FAILED: the merged top-k of one batch is not the CPU oracle's on the unsharded index: no timing is reported",
+                      file=sys.stderr, flush=True)
+            os._exit(5)
+        if rank == 0:
+            print(f"[bench preflight] ok: {world} rank(s), {ranks_seen} seen by the communicator, centroids identical, shards tile {n_docs_total} passages"
+                  + ("" if merged_check is None else f", merged result of one batch == oracle on {merged_check['queries']} queries"),
+                  file=sys.stderr, flush=True)
 
     # (0) pre-conditioning + the sustained figure (a 20-step region is ~25 ms: too short to trust on its own, and a GPU
     #     that has just come out of index generation idles at a low clock)
@@ -816,6 +906,60 @@ def main():
                 e2e["larger_batches"][str(Bs)] = {"value": round(Bs * args.steps / dtb, 2), "ms_per_step": round(dtb / args.steps * 1e3, 4),
                                                   "encoder_ms_per_step": round(dte / args.steps * 1e3, 4)}
                 del pl, qb
+        # The serving shape (searcher.TextSearch.search_many does the same for texts): ONE encode of 128 queries
+        # on the encoder's own stream, its four 32-query search batches on the compute streams behind it, and the NEXT encode
+        # enqueued behind the first of those batches -- the encoder's Linear layers fill the chip at 4 096 rows (0.34 of the
+        # matrix peak against 0.18 at 1 024), the search keeps its 32-query batches, and an encode runs beside the three
+        # remaining search batches of the group before it.  Latency of a query = from its group's encode entering the stream to
+        # the end of its own search batch (HIP events), under this sustained load.
+        if world == 1 and not args.no_sub and n_queries >= 256 and B == 32:
+            Be, per = 128, 128 // B
+            enc_stream = torch.cuda.Stream(device=dev)
+            qenc = [torch.empty((Be, T, 128), dtype=torch.float32, device=dev) for _ in range(2)]
+            gate = [None]                 # the first search batch of the previous group has finished: the next encode may start
+            lat = []
+
+            def serve_group(g, record):
+                off = (g * Be) % (n_queries - Be + 1)
+                with torch.cuda.stream(enc_stream):
+                    if gate[0] is not None:
+                        enc_stream.wait_event(gate[0])
+                    t_in = torch.cuda.Event(enable_timing=True)
+                    t_in.record(enc_stream)
+                    enc.query_embeddings_device(d_ids[off:off + Be], d_mask[off:off + Be], d_skip, qenc[g % 2])
+                    encoded = torch.cuda.Event()
+                    encoded.record(enc_stream)
+                for j in range(per):
+                    i = per * g + j
+                    st = compute[i % NF] if overlap[0] else compute[0]
+                    with torch.cuda.stream(st):
+                        st.wait_event(encoded)
+                        plan.step_on_current_stream(i, plan.queries(i))
+                        t_out = torch.cuda.Event(enable_timing=True)
+                        t_out.record(st)
+                        if j == 0:
+                            gate[0] = t_out
+                        if record:
+                            lat.append((t_in, t_out))
+
+            for g in range(2):
+                serve_group(g, False)
+            barrier()
+            n_groups = max(args.steps // 2, 8)
+            t0 = time.perf_counter()
+            for g in range(n_groups):
+                serve_group(2 + g, True)
+            barrier()
+            dts = time.perf_counter() - t0
+            lat_ms = np.array([a.elapsed_time(b_) for a, b_ in lat])
+            e2e["serving_shape"] = {
+                "value": round(Be * n_groups / dts, 2), "unit": "queries/s", "queries_per_encode": Be, "queries_per_search_batch": B,
+                "groups": n_groups, "ms_per_group": round(dts / n_groups * 1e3, 4),
+                "latency_ms_per_query": {"p50": round(float(np.quantile(lat_ms, 0.5)), 4), "p99": round(float(np.quantile(lat_ms, 0.99)), 4),
+                                         "max": round(float(lat_ms.max()), 4),
+                                         "note": "encode of the query's 128-group entering its stream -> end of the query's own 32-query search "
+                                                 "batch, HIP events, under sustained load (groups enqueued back to back)"}}
+            del qenc
         # the passage side of the same encoder (what index() spends its time in: 1 M passages = 15 600 such batches): one batch
         # of index_bsize = 64 passages x doc_maxlen = 300 tokens, output left on the device (clb_encode_docs_device)
         if rank == 0 and not args.no_passage_encoder:
@@ -975,7 +1119,8 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
     roof = None
     if dom:
-        roof = roofline_of(dom, prof, stats, s.mode, T, K, B)
+        copy_gbs = measured_copy_rate(clb, local_rank)
+        roof = roofline_of(dom, prof, stats, s.mode, T, K, B, copy_gbs=copy_gbs)
         # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the committed
         # rocprofv3 --pmc passes of this same command (tools/pmc_summary.py), which record the hash of the kernel
         # sources they were measured on.  A summary taken on different sources is stale: traffic stays null.
@@ -989,7 +1134,7 @@ def main():
         elif world == 1:
             traffic_from_pmc(pmc_file, dom, stats, roof)
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(prof_steps, 1), 4) for kname, v in prof.items()}
-        roof["other_kernels"] = [roofline_of(kn, prof, stats, s.mode, T, K, B) for kn in ("score_approx", "score_exact", "centroid_scores")
+        roof["other_kernels"] = [roofline_of(kn, prof, stats, s.mode, T, K, B, copy_gbs=copy_gbs) for kn in ("score_approx", "score_exact", "centroid_scores")
                                  if kn in prof and kn != dom and prof[kn]["launches"]]
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N = 1
@@ -1011,29 +1156,6 @@ def main():
         cpu = {"value": round(nq_cpu / t_cpu, 4), "unit": "queries/s", "cores": orc.num_threads(), "kind": "port",
                "sample": f"{nq_cpu} queries of the same workload, one at a time, OpenMP over the host cores",
                "gpu_matches_cpu_top_k": ok}
-
-    # ---- N > 1: the MERGED result of one batch (every shard's search, the exchange, the merge) against the CPU oracle's search
-    #      of the UNSHARDED index, generated on rank 0 (the same passages the shards hold: test_block_generated_shards_equal_the_full_index)
-    merged_check = None
-    if world > 1 and not args.no_cpu and not args.built_index:
-        mp_, ms_ = plan.step(0)
-        barrier()
-        if rank == 0:
-            from oracle import oracle as orc
-            orc.build()
-            t1 = time.time()
-            full = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=n_blocks, blocks=range(n_blocks), topical=not args.uniform_codes)
-            full["emb2pid"] = orc.build_emb2pid(full["doclens"])
-            mp_h, ms_h = mp_.cpu().numpy(), ms_.cpu().numpy()
-            n_chk = min(plan.B, 8 if args.docs <= 400_000 else 4)
-            ok = True
-            for b in range(n_chk):
-                rp, rs, _ = orc.search(full, Q[:, :, b], args.nprobe, k)
-                ok = ok and bool(np.array_equal(rp, mp_h[b])) and bool(np.array_equal(rs.view(np.uint32), ms_h[b].view(np.uint32)))
-            merged_check = {"queries": n_chk, "merged_equals_oracle_on_the_unsharded_index": ok, "seconds": round(time.time() - t1, 1),
-                            "note": "pids identical and fp32 score bits identical, exchange = " + ("two-phase" if two_phase else "single")}
-            del full
-        barrier()
 
     # ---- N = 1 sub-records: the batch sizes the N-GPU runs use, the worst-case code distribution, and BASELINE config 2
     batch_sweep = worst = built = built_1m = None
@@ -1116,12 +1238,7 @@ def main():
         out = {"metric": "queries/sec, top-1000 on 1M-passage corpus", "value": round(qps, 2), "unit": "queries/s",
                "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-               "batch_policy": (f"fixed --batch {B}" if args.batch > 0 else
-                                f"{B} queries per step = 32 per GPU (at most 256); the corpus is fixed (strong scaling of the passages), "
-                                "fixed_batch_32 / batch_sweep give the same batch at every N"),
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "query_pool": {"distinct_queries": int(n_queries), "issued_in_timed_region": int(B * args.steps),
-                              "note": "warmup + timed steps never issue a query twice; the sustained leg and the sweeps cycle the pool"},
                "config": {"workload": (f"BASELINE config 2: {n_docs_total} passages of mixture embeddings indexed by this repo's own build "
                                        f"(K={K}), " if args.built_index else
                                        f"synthetic {args.docs} passages (dim 128, nbits 2, doclen~80, K={K}"
@@ -1129,7 +1246,23 @@ def main():
                                       f"top-{k}, nprobe {args.nprobe}, query_maxlen {T}, batch {B} queries/step, "
                                       f"passages sharded over {world} GPU(s)",
                           "search_mode": ("two-pass (fp16 MFMA prefilter + exact fp32 re-score)" if (prof and "score_approx" in prof) else "exact fp32 single pass")
-                                         + (", global threshold exchange between the passes" if two_phase else "")},
+                                         + (", global threshold exchange between the passes" if two_phase else ""),
+                          # scalars a reader of the first 2 KB needs (the full records follow further down the line)
+                          "batch": B,
+                          "exchange": (None if not gather else "two-phase" if two_phase else "single"),
+                          "p50_latency_ms": None if p50_ms is None else round(p50_ms, 4),
+                          "p50_text_to_topk_ms": (text_lat or {}).get("stream_launches", {}).get("p50_ms"),
+                          "end_to_end_with_query_encoder_qps": (e2e or {}).get("value"),
+                          "end_to_end_serving_shape_qps": ((e2e or {}).get("serving_shape") or {}).get("value"),
+                          "built_index_1M_qps": (built_1m or {}).get("value"),
+                          "uniform_codes_qps": (worst or {}).get("value"),
+                          "fixed_batch_32_qps": (fixed32 or {}).get("value"),
+                          "single_exchange_qps": (single_exchange or {}).get("value")},
+               "batch_policy": (f"fixed --batch {B}" if args.batch > 0 else
+                                f"{B} queries per step = 32 per GPU (at most 256); the corpus is fixed (strong scaling of the passages), "
+                                "fixed_batch_32 / batch_sweep give the same batch at every N"),
+               "query_pool": {"distinct_queries": int(n_queries), "issued_in_timed_region": int(B * args.steps),
+                              "note": "warmup + timed steps never issue a query twice; the sustained leg and the sweeps cycle the pool"},
                "batches_in_flight": NF if overlap[0] else 1, "in_flight_matches_serial": in_flight_ok,
                "one_batch_at_a_time": {"value": round(B * args.steps / serial_s, 2), "ms_per_step": round(serial_s / args.steps * 1e3, 4)},
                "sustained": {"steps": sustained_steps, "seconds": round(sustained_s, 4),

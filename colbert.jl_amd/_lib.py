@@ -97,6 +97,13 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def measure_copy_rate(device: int = 0, nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """GB/s (read + written) of a device-to-device copy of `nbytes` on `device`, now (clb_measure_copy_rate)."""
+    out = C.c_double(0.0)
+    check(lib().clb_measure_copy_rate(C.c_int(device), C.c_int64(nbytes), C.c_int(reps), C.byref(out)))
+    return float(out.value)
+
+
 def check(rc: int) -> None:
     if rc != 0:
         msg = lib().clb_last_error().decode(errors="replace")

@@ -1122,6 +1122,14 @@ constexpr bool kSplitLut = true;    // experiment: the 16 table reads of a step 
 #else
 constexpr bool kSplitLut = false;
 #endif
+// experiment builds (make SUF=_prio EXTRA=-DCLB_APPROX_PRIO=1): the wave raises its issue priority for the ten dependent MFMAs of a step
+#if defined(CLB_APPROX_PRIO) && CLB_APPROX_PRIO
+#define CLB_APPROX_PRIO_UP __builtin_amdgcn_s_setprio(CLB_APPROX_PRIO);
+#define CLB_APPROX_PRIO_DOWN __builtin_amdgcn_s_setprio(0);
+#else
+#define CLB_APPROX_PRIO_UP
+#define CLB_APPROX_PRIO_DOWN
+#endif
 constexpr int kApproxThreads = 64 * CLB_APPROX_WAVES;   // 12 waves per work-group = 3 per SIMD, one work-group per CU
 constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slots x 8 B
 
@@ -1384,6 +1392,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
             }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
+        CLB_APPROX_PRIO_UP                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = acc_init;                                   \
         if (CELL8) {         /* byte b -> fp16 1024 + b (0x6400 | b): two cells per v_perm_b32 */            \
             const u32x4 raw_ = X0;                                                                          \
@@ -1409,6 +1418,7 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                     __builtin_bit_cast(f16x8, qb[s_]), ACC, 0, 0, 0);                                       \
             }                                                                                               \
         }                                                                                                   \
+        CLB_APPROX_PRIO_DOWN                                                                                \
     }
 #define CLB_STAGE_E(ACC, INVB, PM, TAG)                                                                     \
     {                                                                                                       \

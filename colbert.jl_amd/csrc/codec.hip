@@ -68,7 +68,7 @@ int nearest_centroids(hipStream_t st, const float* dC, const float* dc2, int dim
             x1 = dc > 0.f && std::isfinite(dc);
             if (!x1) CLB_HIP(hipMemsetAsync(w.cn.as<unsigned int>() + 1, 0, sizeof(unsigned int), st));
         }
-        const char* staging = getenv("COLBERT_NEAREST_STAGING");          // "registers": the first form of the kernel (comparison runs)
+        const char* staging = CLB_ENV("COLBERT_NEAREST_STAGING");         // "registers": the first form of the kernel (tuning builds)
         const bool dma = x1 && !(staging && strcmp(staging, "registers") == 0);
         if (dma) {          // the tiled table of nearest_top_f16_dma_kernel: whole tiles, the last one padded with copies of row K - 1
             const int64_t n_chunks = (int64_t)((K + 31) / 32) * 512;
@@ -103,12 +103,14 @@ if (dma && MODE == 1)
             else if (dma)
                 hipLaunchKernelGGL((nearest_top_f16_dma_kernel<false>), grid1, dim3(256), 3 * 8192, st, w.hi.as<uint16_t>(),
                                    dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, (const float*)nullptr, m);
+#ifdef CLB_ABLATIONS
             else if (x1 && MODE == 1)
                 hipLaunchKernelGGL((nearest_top_f16_kernel<true, kNq>), grid1, dim3(256), lds / 2, st, w.hi.as<uint16_t>(),
                                    dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, w.bias.as<float>(), m);
             else if (x1)
                 hipLaunchKernelGGL((nearest_top_f16_kernel<false, kNq>), grid1, dim3(256), lds / 2, st, w.hi.as<uint16_t>(),
                                    dX + (size_t)p0 * kDim, w.partial.as<ValIdx>(), K, groups32, n_tiles, (const float*)nullptr, m);
+#endif
             else if (MODE == 1)
                 hipLaunchKernelGGL((centroid_top_bf16x3_mq_kernel<false, true>), grid, dim3(256), lds, st,
                                    w.hi.as<uint16_t>(), w.lo.as<uint16_t>(), dX + (size_t)p0 * kDim,
@@ -177,7 +179,7 @@ if (dma && MODE == 1)
                                    w.ovf2_count.as<unsigned int>(), w.ovf2_keys.as<unsigned long long>(), w.codes_c.as<uint32_t>());
                 hipLaunchKernelGGL(scatter_codes_kernel, dim3(blocks_for(mc)), dim3(256), 0, st, w.ovf_list.as<uint32_t>(), mc,
                                    w.codes_c.as<uint32_t>(), dOut + p0);
-                if (getenv("COLBERT_DEBUG_NEAREST")) {
+                if (CLB_ENV("COLBERT_DEBUG_NEAREST")) {
                     CLB_HIP(hipMemcpyAsync(&undecided2, w.ovf2_count.p, sizeof undecided2, hipMemcpyDeviceToHost, st));
                     CLB_HIP(hipStreamSynchronize(st));
                 }
@@ -190,7 +192,7 @@ if (dma && MODE == 1)
                 hipLaunchKernelGGL(nearest_list_finalize_kernel, dim3(64), dim3(256), 0, st, w.ovf_list.as<uint32_t>(),
                                    w.ovf_count.as<unsigned int>(), w.ovf_keys.as<unsigned long long>(), dOut + p0);
             }
-            if (getenv("COLBERT_DEBUG_NEAREST")) {      // how many points the lists left undecided (a wait per chunk: debugging only)
+            if (CLB_ENV("COLBERT_DEBUG_NEAREST")) {      // how many points the lists left undecided (a wait per chunk: debugging only)
                 unsigned int cnt = 0;
                 CLB_HIP(hipMemcpyAsync(&cnt, w.ovf_count.p, sizeof cnt, hipMemcpyDeviceToHost, st));
                 CLB_HIP(hipStreamSynchronize(st));

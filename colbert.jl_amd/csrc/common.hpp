@@ -110,6 +110,15 @@ inline void allow_dynamic_lds(const void* kernel, int bytes) {
 
 // Launch-geometry knobs used while tuning: the shipped library compiles them to their defaults; a build with
 // -DCLB_ABLATIONS reads CLB_DEBUG_* from the environment instead (make ABLATIONS=1).
+// Comparison switches read from the environment (COLBERT_ENC_PLAN, COLBERT_PASS1_GATHER, ...): tuning builds only.  The product
+// library answers "not set" without looking, and the kernels only those switches select are not compiled into it.
+#ifdef CLB_ABLATIONS
+#define CLB_ENV(NAME) getenv(NAME)
+constexpr bool kAblations = true;
+#else
+#define CLB_ENV(NAME) (static_cast<const char*>(nullptr))
+constexpr bool kAblations = false;
+#endif
 #ifdef CLB_ABLATIONS
 inline int tuning_knob(const char* name, int dflt) {
     const char* v = getenv(name);

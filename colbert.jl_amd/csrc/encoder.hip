@@ -13,7 +13,11 @@
 
 using namespace clb;
 
-namespace clb { bool launch_planes2_wide(hipStream_t st, int ln_mode, const GemmPArgs& g, unsigned grid); }   // encoder_big.hip
+#ifdef CLB_ABLATIONS
+namespace clb { bool launch_planes2_wide(hipStream_t st, int ln_mode, const GemmPArgs& g, unsigned grid); }   // encoder_big.hip (tuning builds)
+#else
+namespace clb { inline bool launch_planes2_wide(hipStream_t, int, const GemmPArgs&, unsigned) { return false; } }
+#endif
 
 struct clb_encoder {
     int device = 0;
@@ -144,7 +148,7 @@ void gemm(hipStream_t st, const float* A, const float* B, float* C, const float*
 struct LnArgs { const float* gamma; const float* beta; float eps; };
 // small tiles (query batches): two LDS tile buffers, one barrier per step (COLBERT_ENCODER_DOUBLE_BUFFER=0: the
 // single-buffer loop, for comparison)
-static const bool g_double_buffer = [] { const char* v = getenv("COLBERT_ENCODER_DOUBLE_BUFFER"); return !v || atoi(v) != 0; }();
+static const bool g_double_buffer = [] { const char* v = CLB_ENV("COLBERT_ENCODER_DOUBLE_BUFFER"); return !v || atoi(v) != 0; }();
 
 // ln != null: the caller applies a LayerNorm to the output next; returns true when it was applied here (split-K path:
 // fused into the reduction pass)
@@ -209,7 +213,7 @@ static const PlanCfg* plan_override(int role) {
     static PlanCfg cfg[LR_COUNT];
     static bool have[LR_COUNT] = {false, false, false, false, false};
     static const bool parsed = [] {
-        const char* v = getenv("COLBERT_ENC_PLAN");
+        const char* v = CLB_ENV("COLBERT_ENC_PLAN");
         if (!v) return true;
         static const char* names[LR_COUNT] = {"qkv", "attn_out", "ffn_in", "ffn_out", "proj"};
         std::string sv(v);
@@ -235,13 +239,13 @@ static const PlanCfg* plan_override(int role) {
 
 // COLBERT_ENC_GEMM_FORM=1: the first form of the plane GEMM (element-wise epilogue, LDS reads not pipelined) -- comparison runs
 static bool planes_first_form() {
-    static const bool v = [] { const char* e = getenv("COLBERT_ENC_GEMM_FORM"); return e && atoi(e) == 1; }();
-    return v;
+    static const bool v = [] { const char* e = CLB_ENV("COLBERT_ENC_GEMM_FORM"); return e && atoi(e) == 1; }();
+    return kAblations && v;
 }
 
 // COLBERT_ENC_ATT_QB=1: one query block per wave in attention_f16_kernel whatever the length -- comparison runs
 static bool att_qb2() {
-    static const bool v = [] { const char* e = getenv("COLBERT_ENC_ATT_QB"); return !(e && atoi(e) == 1); }();
+    static const bool v = [] { const char* e = CLB_ENV("COLBERT_ENC_ATT_QB"); return !(e && atoi(e) == 1); }();
     return v;
 }
 
@@ -259,8 +263,8 @@ struct LnFold {
 // accumulators in AGPRs) instead of eight of 64 x 128 -- bit-identical and SLOWER (a 64 x 300 batch 16.6 against 13.9 ms: with
 // one wave per SIMD nothing covers the barrier and the DMA wait of every step); kept for comparison runs (tools/r5_wide_waves.py)
 static bool wide_waves() {
-    static const bool v = [] { const char* e = getenv("COLBERT_ENC_WIDE_WAVES"); return e && atoi(e) == 1; }();
-    return v;
+    static const bool v = [] { const char* e = CLB_ENV("COLBERT_ENC_WIDE_WAVES"); return e && atoi(e) == 1; }();
+    return kAblations && v;
 }
 
 bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
@@ -281,6 +285,14 @@ bool launch_planes_ln(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     return false;
 }
 
+// (the first form of the plane GEMM, gemm_planes_kernel, is a comparison kernel: tuning builds; it also takes N % 4 != 0, which
+// no Linear of the encoder has -- linear_planes falls back to the fp32 GEMM for such a shape)
+#ifdef CLB_ABLATIONS
+#define CLB_PLANES_KERNEL(SECOND, WGM_, WGN_, WM_, WN_, NS_, ST_, F16_) \
+    ((SECOND) ? gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, NS_, ST_, 0, F16_> : gemm_planes_kernel<WGM_, WGN_, WM_, WN_, NS_, ST_, 0, F16_>)
+#else
+#define CLB_PLANES_KERNEL(SECOND, WGM_, WGN_, WM_, WN_, NS_, ST_, F16_) (gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, NS_, ST_, 0, F16_>)
+#endif
 template <int NS, bool F16>
 bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     const dim3 grid((unsigned)gemm_planes_grid(g.M, g.N, c.bm, c.bn, c.ks));
@@ -289,7 +301,7 @@ bool launch_planes(hipStream_t st, const PlanCfg& c, const GemmPArgs& g) {
     if (NS == 2 && F16 && second && c.bm == 256 && c.bn == 256 && c.stages == 2 && wide_waves()) return launch_planes2_wide(st, 0, g, grid.x);
 #define CLB_GP_CASE(BM_, BN_, ST_, WGM_, WGN_, WM_, WN_)                                                              \
     if (c.bm == BM_ && c.bn == BN_ && c.stages == ST_) {                                                              \
-        auto kern = second ? gemm_planes2_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16> : gemm_planes_kernel<WGM_, WGN_, WM_, WN_, NS, ST_, 0, F16>; \
+        auto kern = CLB_PLANES_KERNEL(second, WGM_, WGN_, WM_, WN_, NS, ST_, F16);                                    \
         if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);                        \
         hipLaunchKernelGGL(kern, grid, dim3(64 * WGM_ * WGN_), lds, st, g);                                           \
         return true;                                                                                                  \
@@ -341,7 +353,7 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         // big-tile rule of long activations below, 128 x 128 at least when it produces statistics (a part = two 32-wide tiles
         // of one wave); the narrow projection (N = dim) only consumes: 64 x 64
         const bool wide = N % 4 == 0 && !(epi & EPI_GELU);
-        c = N < 128 && !lf->stats_out ? PlanCfg{64, 64, 2, 1}
+        c = N <= 128 && !lf->stats_out ? PlanCfg{64, 64, 2, 1}
             : wgs(128, 128) >= 256 ? pick_long_tile(M, N, wide && !att && !lf->u, wide) : PlanCfg{128, 128, 2, 1};
         part = nullptr;
     }
@@ -485,7 +497,9 @@ int split_weights(clb_encoder* e, int fmt) {
     e->wp_fmt = fmt;
     // ---- the folded operands of "LayerNorm without a pass of its own" (gemm_planes2_kernel<LN>): PF_F16X2 only
     e->fold_ready = false;
-    if (fmt == PF_F16X2 && e->layers >= 1 && H % 64 == 0 && H % 4 == 0 && e->dim % 4 == 0) {
+    // (a row's statistics travel as H / 64 partial (mean, M2) pairs, at most kLnMaxParts of them: hidden sizes up to 1 024 --
+    // a wider model keeps its LayerNorm passes)
+    if (fmt == PF_F16X2 && e->layers >= 1 && H % 64 == 0 && H / 64 <= kLnMaxParts && H % 4 == 0 && e->dim % 4 == 0) {
         const int64_t L = e->layers;
         struct Fold { int64_t w_off, rows, g_off, b_off, bias_off, p_off, v_off; };
         std::vector<Fold> folds;
@@ -656,6 +670,7 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
             const dim3 grid((unsigned)((L + 31) / 32), (unsigned)heads, (unsigned)N);
             uint16_t* cp_ = P ? ctxp : nullptr;
 #define CLB_ATT(NT_) hipLaunchKernelGGL(attention_fused_kernel<NT_>, grid, dim3(64), 0, st, qkv, d_mask, ctx, (int)L, (int)H, inv_sqrt, cp_, hp, PF)
+#ifdef CLB_ABLATIONS
             if (att16 && L > 32 && e->attention_mode == 5) {
                 // the query blocks of a (sequence, head) share its K / V tiles through LDS (attention_f16_lds_kernel): NW waves
                 // of QB blocks per work-group -- a whole sequence up to 512 tokens at QB = 2; bit-identical to the kernels below
@@ -672,7 +687,9 @@ int forward(clb_encoder* e, int64_t L, int64_t N, hipStream_t st, const int32_t*
                 CLB_ATTL(1, 2) CLB_ATTL(1, 3) CLB_ATTL(1, 4) CLB_ATTL(2, 2) CLB_ATTL(2, 3) CLB_ATTL(2, 4) CLB_ATTL(2, 5) CLB_ATTL(2, 6) CLB_ATTL(2, 8)
                 CLB_ATTL(1, 5) CLB_ATTL(1, 6) CLB_ATTL(1, 8)
 #undef CLB_ATTL
-            } else if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
+            } else
+#endif
+            if (att16 && L >= 128 && att_qb2()) {     // long sequences: two query blocks per wave share a key tile's K / V fragments
                 const dim3 grid2((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)N);
                 hipLaunchKernelGGL(attention_f16_kernel<2>, grid2, dim3(64), 0, st, att_out.qk, qk_plane, T, att_out.vt, vt_plane, d_mask, (int)L,
                                    (int)H, inv_sqrt, ctxp, hp, PF, pk ? pk->cu : nullptr);
@@ -861,9 +878,11 @@ int clb_encoder_create(int device, int64_t vocab, int64_t hidden, int64_t layers
     }
     {   // the Linear weights as bf16 planes, split ONCE (the region from the first layer to the end of the blob: biases and
         // LayerNorm parameters ride along unused).  1.5x the bytes of the fp32 region.
-        const char* v = getenv("COLBERT_ENCODER_PLANES");
+        const char* v = CLB_ENV("COLBERT_ENCODER_PLANES");
         const int64_t n_lin = n_weights - e->o_layer0;
-        e->planes = (!v || atoi(v) != 0) && H % 32 == 0 && I % 32 == 0 && e->o_layer0 % 4 == 0 && n_lin * 6 < ((int64_t)1 << 31);
+        // (every Linear's N must be a multiple of 4 for the plane GEMM of the product library: H, 3H and I are; dim may not be)
+        e->planes = (!v || atoi(v) != 0) && H % 32 == 0 && I % 32 == 0 && e->o_layer0 % 4 == 0 && n_lin * 6 < ((int64_t)1 << 31) &&
+                    (kAblations || e->dim % 4 == 0);
         if (e->planes) {
             e->wp_plane = n_lin;
             if ((rc = e->wplanes.alloc(sizeof(uint16_t) * 3 * n_lin)) || (rc = split_weights(e, plane_format(e->gemm_mode)))) {
@@ -896,12 +915,17 @@ int clb_encoder_set_gemm_mode(clb_encoder* e, int mode) {
 int clb_encoder_set_ln_fold(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
     if (mode < -1 || mode > 1) return fail(CLB_EARGUMENT, "LayerNorm folding: -1 = long batches only (default), 0 = never, 1 = always");
+    if (mode == 1 && e->H / 64 > kLnMaxParts)
+        return fail(CLB_EUNSUPPORTED, "LayerNorm folding carries at most %d partial statistics per row: hidden sizes up to %d (this model: %lld)",
+                    kLnMaxParts, 64 * kLnMaxParts, (long long)e->H);
     e->ln_fold = mode;
     return CLB_OK;
 }
 
 int clb_encoder_set_attention_mode(clb_encoder* e, int mode) {
     if (!e) return fail(CLB_EARGUMENT, "null encoder");
+    if (mode == 5 && !kAblations)
+        return fail(CLB_EUNSUPPORTED, "attention mode 5 (K / V tiles shared through LDS: bit-identical to mode 0 and slower) is built into tuning libraries only (make ABLATIONS=1)");
     if (mode < 0 || mode > 5 || mode == 4)
         return fail(CLB_EARGUMENT, "attention mode %d: 0 = fused, 1 = register-resident, 2 = three kernels, 3 = fused on the fp32 MFMA, "
                                    "5 = fused with the K / V tiles of a (sequence, head) shared through LDS", mode);

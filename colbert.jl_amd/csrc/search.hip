@@ -830,8 +830,45 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
 
 extern "C" {
 
+#ifdef CLB_ABLATIONS
+const char* clb_version(void) { return "colbert_hip 0.1 (gfx950, tuning build: ablation variants and comparison kernels)"; }
+#else
 const char* clb_version(void) { return "colbert_hip 0.1 (gfx950)"; }
+#endif
 const char* clb_last_error(void) { return clb::last_error().c_str(); }
+// What a plain stream reaches on THIS device at THIS moment: a device-to-device copy of `bytes` (16 bytes per lane, non-temporal
+// loads, grid-stride over one resident round of work-groups), `reps` times between two HIP events after one untimed pass.
+// bench.py quotes pass 1's achieved bandwidth against it next to the 8 TB/s of the data sheet.
+static __global__ __launch_bounds__(256) void copy_rate_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s) {
+    if (!gb_per_s || bytes < 4096 || reps < 1) return fail(CLB_EARGUMENT, "copy rate: bytes >= 4096, reps >= 1, a result pointer");
+    CLB_TRY(use_device(device));
+    const size_t n16 = (size_t)bytes / 16;
+    DevBuf a, b;
+    CLB_TRY(a.alloc(n16 * 16));
+    CLB_TRY(b.alloc(n16 * 16));
+    CLB_HIP(hipMemset(a.p, 0x5a, n16 * 16));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CLB_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(CLB_EHIP, "hipEventCreate failed"); }
+    const dim3 grid(256 * 8);      // eight work-groups per CU
+    hipLaunchKernelGGL(copy_rate_kernel, grid, dim3(256), 0, nullptr, (const u32x4*)a.as<u32x4>(), b.as<u32x4>(), n16);
+    (void)hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(copy_rate_kernel, grid, dim3(256), 0, nullptr, (const u32x4*)a.as<u32x4>(), b.as<u32x4>(), n16);
+    (void)hipEventRecord(e1, nullptr);
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && hipGetLastError() == hipSuccess;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok || !(ms > 0.f)) return fail(CLB_EHIP, "copy rate: timing failed");
+    *gb_per_s = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;      // bytes read + bytes written
+    return CLB_OK;
+}
+
 int clb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -993,7 +1030,7 @@ static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, c
         if ((rc = s->cent_f16.alloc(sizeof(uint16_t) * dim * K))) return bail(rc);
         hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s->stream,
                            s->centroids.as<float>(), s->cent_f16.as<uint16_t>(), nel);
-        if (const char* g = getenv("COLBERT_S1_PRODUCTS")) s->s1_x1 = strcmp(g, "1") == 0;      // "1" / "3": comparison runs
+        if (const char* g = CLB_ENV("COLBERT_S1_PRODUCTS")) s->s1_x1 = strcmp(g, "1") == 0;      // "1" / "3": comparison runs
     }
     s->cbits = 1;
     while (((int64_t)1 << s->cbits) < K) ++s->cbits;
@@ -1018,7 +1055,7 @@ static int searcher_create_impl(int device, int64_t dim, int nbits, int64_t K, c
         // ... and only pays when the query's score table (64 B per centroid) does not fit the 4-MB L2 of an XCD: with a
         // resident table the two forms are equal within 2 % (built index, K = 32 768: 0.663 / 0.668 ms)
         s->gather_lds = s->code_adjacency < 0.2 && (int64_t)K * 64 > ((int64_t)4 << 20);
-        if (const char* g = getenv("COLBERT_PASS1_GATHER")) s->gather_lds = strcmp(g, "vgpr") != 0;   // "vgpr" / "lds": comparison runs
+        if (const char* g = CLB_ENV("COLBERT_PASS1_GATHER")) s->gather_lds = strcmp(g, "vgpr") != 0;   // "vgpr" / "lds": comparison runs
     }
     if (s->approx_ok) {
         if ((rc = s->codeinv.alloc(sizeof(uint32_t) * (n_emb + kStepRows)))) return bail(rc);

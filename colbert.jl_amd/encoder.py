@@ -93,12 +93,20 @@ class BertEncoder:
         amodes = {"fused": 0, "resident": 1, "unfused": 2, "fused_f32": 3, "fused_lds": 5}     # 1-5: comparison paths (clb_encoder_set_attention_mode)
         if attention not in amodes:
             raise ValueError(f"attention must be one of {sorted(amodes)}, not {attention!r}")
-        check(lib().clb_encoder_set_attention_mode(self._h, amodes[attention]))
+        try:
+            check(lib().clb_encoder_set_attention_mode(self._h, amodes[attention]))
+        except Exception:
+            self.close()                 # (a mode the library refuses: no handle is left behind)
+            raise
         # LayerNorm folded around the Linear layers (clb_encoder_set_ln_fold): -1 long batches only (default), 0 never, 1 always
         if ln_fold is None and "COLBERT_ENC_LNFOLD" in os.environ:
             ln_fold = int(os.environ["COLBERT_ENC_LNFOLD"])
         if ln_fold is not None:
-            check(lib().clb_encoder_set_ln_fold(self._h, C.c_int(int(ln_fold))))
+            try:
+                check(lib().clb_encoder_set_ln_fold(self._h, C.c_int(int(ln_fold))))
+            except Exception:
+                self.close()
+                raise
 
     @classmethod
     def from_export(cls, path: str, **kw) -> "BertEncoder":

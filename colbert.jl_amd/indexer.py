@@ -69,13 +69,16 @@ def index(indexer: Indexer, device_resident: Optional[bool] = None) -> Optional[
     if device_resident is None:
         device_resident = hasattr(indexer.encoder, "doc_embeddings_device") and _device_route_fits(indexer)
     if device_resident:
+        created = [False]               # set once THIS call has made the directory (os.makedirs raises if it already exists)
         try:
-            return _index_through_device(indexer)
+            return _index_through_device(indexer, created)
         except BaseException:
             # a build that dies half-way must not leave a directory behind: index() would take it for a finished index
-            # (the isdir test above, indexing.jl:64-67) and return without building
-            import shutil
-            shutil.rmtree(path, ignore_errors=True)
+            # (the isdir test above, indexing.jl:64-67) and return without building -- but only a directory this call made:
+            # one that another process or rank created between the isdir test and makedirs is not ours to delete
+            if created[0]:
+                import shutil
+                shutil.rmtree(path, ignore_errors=True)
             raise
     n_docs = len(indexer.collection)
     # sample -> embeddings (collection_indexer.jl:17-24, 56-79)
@@ -181,7 +184,7 @@ class _BackgroundWriter:
             raise e
 
 
-def _index_through_device(indexer: Indexer) -> str:
+def _index_through_device(indexer: Indexer, created=None) -> str:
     """index() over index_device: the encoder's output, the sample, the codes and the residuals stay in HBM; what is
     written is the reference's directory (sample, sample_heldout, plan.json, config.json, the codec, per chunk codes /
     residuals / doclens / metadata, ivf, ivf_lengths -- indexing.jl:84-147)."""
@@ -191,7 +194,9 @@ def _index_through_device(indexer: Indexer) -> str:
     t0 = time.time()
     source = EncoderSource(indexer.encoder, indexer.collection, indexer.device, lazy=True)    # the tokenizer overlaps the device
     t_tok = time.time() - t0
-    os.makedirs(path)
+    os.makedirs(path)                   # FileExistsError if somebody else made it meanwhile: propagates, nothing is removed
+    if created is not None:
+        created[0] = True
     state = {"write_s": 0.0}
     writer = _BackgroundWriter()
 
@@ -365,12 +370,15 @@ class EncoderSource(DeviceEmbeddingSource):
         vocab_file = getattr(tok, "vocab_file", None)
         done = 0
         proc = None
+        import tempfile
+        errlog = tempfile.TemporaryFile()       # the worker's stderr: read only if it fails (a pipe nobody drains could block it)
         try:
             if vocab_file is None or os.environ.get("COLBERT_TOKENIZER_PROCESS", "1") == "0":
                 raise OSError("no vocabulary file to hand to a worker process")
             worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tok_worker.py")
             proc = subprocess.Popen([sys.executable, worker, vocab_file, "1" if getattr(tok, "lowercase", True) else "0",
-                                     str(self._maxlen), str(int(self._marker))], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+                                     str(self._maxlen), str(int(self._marker))], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                    stderr=errlog)
 
             def read_exact(n):
                 buf = proc.stdout.read(n)
@@ -394,10 +402,34 @@ class EncoderSource(DeviceEmbeddingSource):
                 done = start + len(part)
             proc.stdin.close()
             proc.wait(timeout=30)
-        except (OSError, AssertionError, ValueError, subprocess.SubprocessError):
+        except Exception as e:      # noqa: BLE001 -- whatever went wrong with the worker, tokenising here is always safe
+            why = f"{type(e).__name__}: {e}"
             if proc is not None:
                 proc.kill()
+                try:
+                    proc.wait(timeout=10)
+                    errlog.seek(0)
+                    err = errlog.read().decode(errors="replace").strip().splitlines()
+                    if err:
+                        why += f" (worker: {err[-1][:200]})"
+                except Exception:   # noqa: BLE001
+                    pass
+            if os.environ.get("COLBERT_TOKENIZER_PROCESS", "1") != "0" and vocab_file is not None:
+                print(f"[colbert] tokenizer worker unavailable, tokenising {len(pids) - done} passages in this process: {why}", file=sys.stderr)
             self._tokenize(pids[done:])
+        finally:
+            if proc is not None:        # no zombie, no open descriptors, whichever way the worker ended
+                for pipe in (proc.stdin, proc.stdout):
+                    try:
+                        if pipe is not None:
+                            pipe.close()
+                    except Exception:   # noqa: BLE001
+                        pass
+                try:
+                    proc.wait(timeout=10)
+                except Exception:       # noqa: BLE001
+                    pass
+            errlog.close()
 
     def prepare_sample(self, pids):
         """Tokenise the passages `pids` now and everything else in the background (a worker process fed by a thread)."""

@@ -309,8 +309,96 @@ class TextSearch:
         out = self.h_out.numpy()
         return out[:k * 8].view(np.int64).copy(), out[k * 8:k * 12].view(np.float32).copy()
 
+    def search_many(self, queries, group: int = 128, batch: int = 32):
+        """Many text queries at the throughput shape (round 6): encode_queries (src/modelling/checkpoint.jl:271-301) on `group`
+        queries per call -- at 128 x 32 rows the encoder's Linear layers fill the chip, at 32 x 32 they do not -- and search
+        (src/searching.jl:102-127) on `batch` queries per call, the size the search kernels are tuned for; the encode of group
+        g + 1 runs on its own stream beside the later search batches of group g (it starts once the first of them has
+        finished).  Returns [(pids, scores)] in query order, each identical to what __call__ returns for that query; raises
+        BoundsError for the first query with fewer than k candidates."""
+        import torch
+        from . import tokenization
+        from .distributed import DeviceSearch
+        if group % batch != 0:
+            raise ValueError("group must be a multiple of batch")
+        n = len(queries)
+        if n == 0:
+            return []
+        cfg = self.enc.config
+        ids, mask = tokenization.tensorize_queries(cfg.query_token, cfg.attend_to_mask_tokens, self.enc.tokenizer, list(queries), self.T)
+        n_groups = -(-n // group)
+        pad = n_groups * group - n
+        ids_t = np.ascontiguousarray(np.concatenate([ids.T] + [ids.T[-1:]] * pad, axis=0), dtype=np.int32)        # (n + pad, T)
+        mask_t = np.ascontiguousarray(np.concatenate([mask.T] + [mask.T[-1:]] * pad, axis=0), dtype=np.uint8)
+        st = getattr(self, "_many", None)
+        if st is None or st["group"] != group or st["batch"] != batch:
+            nprobe = self.run.nprobe
+            st = {"group": group, "batch": batch,
+                  "runs": [DeviceSearch(self.s, self.T, batch, self.k, nprobe, slot=1 + i) for i in range(2)],
+                  "enc_stream": torch.cuda.Stream(self.dev), "compute": [torch.cuda.Stream(self.dev) for _ in range(2)],
+                  "d_ids": [torch.zeros((group, self.T), dtype=torch.int32, device=self.dev) for _ in range(2)],
+                  "d_mask": [torch.ones((group, self.T), dtype=torch.uint8, device=self.dev) for _ in range(2)],
+                  "d_q": [torch.empty((group, self.T, self.s.dim), dtype=torch.float32, device=self.dev) for _ in range(2)]}
+            self._many = st
+        per = group // batch
+        nb = n_groups * per
+        h_ids = torch.from_numpy(ids_t).pin_memory()
+        h_mask = torch.from_numpy(mask_t).pin_memory()
+        h_out = torch.empty((nb, st["runs"][0].packed.numel()), dtype=torch.uint8).pin_memory()
+        h_nc = torch.empty((nb, batch), dtype=torch.int64).pin_memory()
+        gate = None
+        done = [[], []]                    # events of the search batches that read d_q[0] / d_q[1]
+        torch.cuda.current_stream(self.dev).synchronize()
+        for g in range(n_groups):
+            b2 = g % 2
+            es = st["enc_stream"]
+            with torch.cuda.stream(es):
+                for ev in done[b2]:        # the group that used these buffers two groups ago has been searched
+                    es.wait_event(ev)
+                done[b2] = []
+                st["d_ids"][b2].copy_(h_ids[g * group:(g + 1) * group], non_blocking=True)
+                st["d_mask"][b2].copy_(h_mask[g * group:(g + 1) * group], non_blocking=True)
+                if gate is not None:
+                    es.wait_event(gate)
+                self.enc.query_embeddings_device(st["d_ids"][b2], st["d_mask"][b2], self.d_skip, st["d_q"][b2])
+                encoded = torch.cuda.Event()
+                encoded.record(es)
+            for j in range(per):
+                i = g * per + j
+                cs, run = st["compute"][i % 2], st["runs"][i % 2]
+                with torch.cuda.stream(cs):
+                    cs.wait_event(encoded)
+                    run(st["d_q"][b2][j * batch:(j + 1) * batch])
+                    h_out[i].copy_(run.packed, non_blocking=True)
+                    h_nc[i].copy_(run.ncand, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                    done[b2].append(ev)
+                    if j == 0:
+                        gate = ev
+        with torch.cuda.stream(st["enc_stream"]):
+            self.h_err.copy_(self.d_err, non_blocking=True)
+        for cs in st["compute"]:
+            cs.synchronize()
+        st["enc_stream"].synchronize()
+        if int(self.h_err[0]) != 0:
+            self.enc.check_last_ids()
+        k, out = self.k, []
+        raw, nc = h_out.numpy(), h_nc.numpy()
+        for q in range(n):
+            i, r = divmod(q, batch)
+            if int(nc[i, r]) < k:                                                  # searching.jl:127
+                self.s.last_num_candidates = int(nc[i, r])
+                raise BoundsError(f"attempt to access {int(nc[i, r])}-element Vector at index [1:{k}] (query {q + 1} has {int(nc[i, r])} candidate passages)")
+            pids = raw[i, :batch * k * 8].view(np.int64).reshape(batch, k)[r].copy()
+            scores = raw[i, batch * k * 8:batch * k * 12].view(np.float32).reshape(batch, k)[r].copy()
+            out.append((pids, scores))
+        self.s.last_num_candidates = int(nc[(n - 1) // batch, (n - 1) % batch])
+        return out
+
     def close(self):
         self.graph = None
+        self._many = None
 
 
 def search(searcher: Searcher, query, k: int):

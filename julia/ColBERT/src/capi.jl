@@ -288,13 +288,17 @@ function _doc_embeddings_packed_device!(ckpt::Checkpoint, d_skiplist::DeviceBuff
     d = DeviceBuffer(sizeof(buf); device = device)
     device_upload!(d, buf)
     d_lens = DeviceBuffer(8 * N + 8; device = device)
-    _check(ccall((:clb_encode_docs_packed_device, libcolbert), Cint,
-        (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32},
-            Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
-        ckpt.handle, _at(d, 0), _at(d, 4 * rows), _at(d, 8 * rows), _at(d, 12 * rows), N, Int(maximum(lens)), rows,
-        d_skiplist.ptr, n_skip, _at(out, out_offset), _at(d_lens, 0), _at(d_lens, 8 * N), C_NULL))
     doclens = Vector{Int}(undef, N + 1)
-    device_download!(doclens, d_lens)                                  # also waits for the batch (null stream)
+    # the launch is asynchronous and reads raw device pointers of d / d_lens / d_skiplist / out: no finalizer may free them before
+    # the download below has waited for the batch
+    GC.@preserve d d_lens d_skiplist out begin
+        _check(ccall((:clb_encode_docs_packed_device, libcolbert), Cint,
+            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Float32},
+                Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+            ckpt.handle, _at(d, 0), _at(d, 4 * rows), _at(d, 8 * rows), _at(d, 12 * rows), N, Int(maximum(lens)), rows,
+            d_skiplist.ptr, n_skip, _at(out, out_offset), _at(d_lens, 0), _at(d_lens, 8 * N), C_NULL))
+        device_download!(doclens, d_lens)                              # also waits for the batch (null stream)
+    end
     _check(ccall((:clb_encoder_check_last_ids, libcolbert), Cint, (Ptr{Cvoid},), ckpt.handle))
     doclens[1:N]
 end

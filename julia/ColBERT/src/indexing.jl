@@ -49,8 +49,14 @@ end
     index(indexer::Indexer)
 
 Build the index at `indexer.config.index_path` (src/indexing.jl:63-147).  Nothing is done if the directory exists.
+
+`device_resident = true` keeps every large array in HBM between the stages (`_index_device`: the route the Python twin takes
+by default).  It is opt-in here until it has run once under a real `julia` (ADVICE r05): the default is the host route, which
+moves every stage's arrays through the C ABI's host entry points.  When the packed device encode refuses a model (a head size
+other than 64, a GEMM mode other than f16x3: `ArgumentError` / `ErrorException` from `clb_encode_docs_packed_device`) the
+device route falls through to the host route instead of failing.
 """
-function index(indexer::Indexer; device::Int = 0, device_resident::Bool = true)
+function index(indexer::Indexer; device::Int = 0, device_resident::Bool = false)
     config = indexer.config
     path = config.index_path
     if isdir(path)
@@ -60,9 +66,15 @@ function index(indexer::Indexer; device::Int = 0, device_resident::Bool = true)
     if device_resident && _device_route_fits(indexer; device = device)
         try
             return _index_device(indexer; device = device)
-        catch
-            rm(path; recursive = true, force = true)      # a half-built directory would be taken for a finished index next time
-            rethrow()
+        catch err
+            # remove only what THIS call created (_index_device makes the directory after tokenising: nothing of anyone else's
+            # can be inside a directory that did not exist a moment ago)
+            isdir(path) && rm(path; recursive = true, force = true)
+            if err isa ArgumentError || (err isa ErrorException && occursin("packed", err.msg))
+                @warn "the device-resident route refused this model; indexing through the host route" exception = err
+            else
+                rethrow()
+            end
         end
     end
     n_docs = length(indexer.collection)

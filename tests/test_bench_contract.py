@@ -31,6 +31,18 @@ def test_bench_line_has_the_contract_fields():
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None                       # PMC bytes are only reported for the workload they were measured on
+    # the copy rate is MEASURED in the run (clb_measure_copy_rate: 5 x 1 GB device-to-device), not a constant of the script
+    if r["bound"] == "hbm":
+        assert 1000.0 < r["measured_copy_rate"] < 8000.0 and "clb_measure_copy_rate" in r["measured_copy_rate_how"]
+        assert abs(r["frac_of_measured_copy_rate"] - r["achieved"] / r["measured_copy_rate"]) < 1e-3
+    # the scalars a reader of the first 2 KB of the line needs sit in `config` (the driver's record keeps config, not the sub-records)
+    cfgd = d["config"]
+    for key in ("batch", "exchange", "p50_latency_ms", "p50_text_to_topk_ms", "end_to_end_with_query_encoder_qps", "end_to_end_serving_shape_qps",
+                "built_index_1M_qps", "uniform_codes_qps", "fixed_batch_32_qps", "single_exchange_qps"):
+        assert key in cfgd, key
+    assert cfgd["batch"] == 32 and cfgd["exchange"] is None and cfgd["p50_latency_ms"] == d["p50_latency_ms"]
+    assert cfgd["built_index_1M_qps"] == d["built_index_1M"]["value"] and cfgd["uniform_codes_qps"] == d["worst_case_uniform_codes"]["value"]
+    assert len(json.dumps({k_: d[k_] for k_ in list(d)[:list(d).index("config") + 1]})) < 2048      # ... and within the first 2 KB
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

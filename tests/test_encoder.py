@@ -155,6 +155,7 @@ def _state(bert, linear):
 # products per fp32 product (differences are summation order / < 2^-22 per product); "bf16x3" = three plane products,
 # < 2^-15 relative error per product on top of that
 # "f16x3" (round 4) = two fp16 planes per (power-of-two scaled) operand, three products: held to bf16x6's tolerances
+TUNING_BUILD = b"tuning build" in clb.lib().clb_version()      # make ABLATIONS=1: the comparison kernels exist
 GEMM_TOL = {"f32": 2e-4, "bf16x6": 2e-4, "f16x3": 2e-4, "bf16x3": 6e-4}
 GEMM_TOL_BASE = {"f32": 1e-3, "bf16x6": 1e-3, "f16x3": 1e-3, "bf16x3": 6e-3}
 
@@ -294,22 +295,29 @@ def test_fused_attention_long_sequences(L):
     assert np.abs(g16 - alt).transpose(2, 1, 0)[mask].max() < 1e-4
     # round 5: the K / V tiles of a (sequence, head) staged once in LDS for all its query blocks (attention="fused_lds",
     # from 33 tokens on) against every wave loading its own -- the same products in the same order: identical bits
-    enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_lds")
-    per_wave = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
-    enc.close()
-    assert np.array_equal(g16.view(np.uint32), per_wave.view(np.uint32))
+    # (a comparison kernel: in tuning builds of the library only -- the product library refuses the mode)
+    if TUNING_BUILD:
+        enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_lds")
+        per_wave = enc.doc((ids0.T + 1).astype(np.int32), mask.T)
+        enc.close()
+        assert np.array_equal(g16.view(np.uint32), per_wave.view(np.uint32))
+    else:
+        with pytest.raises(clb.Unsupported):
+            clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", attention="fused_lds")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["two_layers", "wide_three_layers", "long_batch_auto"])
+@pytest.mark.parametrize("shape", ["two_layers", "wide_three_layers", "long_batch_auto", "hidden_1280"])
 def test_layernorm_folded_around_the_linear_layers(shape):
     """Round 5: the LayerNorms as statistics carried between the Linear layers (clb_encoder_set_ln_fold; the producing Linear
     leaves raw rows + per-row partial (mean, M2), the consuming Linear multiplies gamma (.) W and applies
     rstd (a . W'^T - mean u) + c) against the independent fp32 reference at the tolerance of the unfolded path, against the
     unfolded path itself, and deterministic.  `long_batch_auto`: more than 4 096 rows take the folded path on their own
-    (what a 64 x 300 passage batch and the packed batches of index() do); padded AND packed."""
+    (what a 64 x 300 passage batch and the packed batches of index() do); padded AND packed.
+    `hidden_1280`: a row's statistics travel as hidden / 64 <= 16 partial pairs, so a model wider than 1 024 must
+    keep its LayerNorm passes -- the long batch takes the unfolded path bit for bit, and forcing the fold is refused."""
     hidden, layers, heads, inter, L, N = {"two_layers": (64, 2, 1, 128, 37, 5), "wide_three_layers": (192, 3, 3, 320, 50, 7),
-                                          "long_batch_auto": (128, 2, 2, 256, 130, 36)}[shape]
+                                          "long_batch_auto": (128, 2, 2, 256, 130, 36), "hidden_1280": (1280, 1, 20, 1280, 130, 36)}[shape]
     torch, cfg, bert, linear = _random_bert(hidden=hidden, layers=layers, heads=heads, inter=inter, vocab=150, max_pos=160, dim=32, seed=11)
     with torch.no_grad():                       # LayerNorm parameters away from (1, 0): the folded vectors u, c must carry them
         for name, p_ in bert.named_parameters():
@@ -333,6 +341,16 @@ def test_layernorm_folded_around_the_linear_layers(shape):
     plain = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", ln_fold=0)
     base = plain.doc(jl_ids, jl_mask)
     plain.close()
+    if shape == "hidden_1280":
+        with pytest.raises(clb.Unsupported):
+            clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", ln_fold=1)
+        enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3")            # default: folds long batches -- where it can
+        got = enc.doc(jl_ids, jl_mask)
+        enc.close()
+        assert N * L > 4096 and np.array_equal(got.view(np.uint32), base.view(np.uint32))
+        err = np.abs(got.transpose(2, 1, 0) - ref)[mask].max()
+        assert err < 2 * GEMM_TOL["f16x3"], err
+        return
     enc = clb.BertEncoder(w, bcfg, dim=32, gemm="f16x3", ln_fold=-1 if shape == "long_batch_auto" else 1)
     got = enc.doc(jl_ids, jl_mask)
     again = enc.doc(jl_ids, jl_mask)
@@ -437,6 +455,17 @@ def test_text_to_search_end_to_end(tmp_path, tok, which, monkeypatch):
             got = ts(q)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), (graph, q)
         ts.close()
+    # the throughput shape of the same session (TextSearch.search_many: encode in groups, search in batches, the next encode
+    # beside the later batches of a group): every query's result is the single-query one, bit for bit, in query order
+    ts = searcher.text_search(3, graph=False)
+    many_q = [collection[i % n] for i in range(21)] + ["hello world", query]
+    for group, batch in ((8, 4), (16, 16)):
+        got_many = ts.search_many(many_q, group=group, batch=batch)
+        assert len(got_many) == len(many_q)
+        for q, (gp, gs) in zip(many_q, got_many):
+            want = clb.search(searcher, q, 3)
+            assert np.array_equal(gp, want[0]) and np.array_equal(gs.view(np.uint32), want[1].view(np.uint32)), (group, batch, q)
+    ts.close()
     with pytest.raises(clb.BoundsError):
         searcher.text_search(n + 1, graph=False)(query)
     # the session copies the encoder's sticky error flag back with every result (clb_encoder_error_flag_device): what the
@@ -598,10 +627,11 @@ def test_packed_passage_batches_match_padded_ones(tok):
                 assert torch.equal(x[off[pid] - off[lo]:off[pid + 1] - off[lo]], smp[soff[j]:soff[j + 1]])
     assert packed.reused_passages == 4 and packed._cache is None      # released with the last chunk
     # packed sequences of different lengths through the LDS-shared K / V tiles == every wave loading its own, bit for bit
-    enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_lds")
-    a_pw = EncoderSource(enc_pw, collection, 0, packed=True).encode_pids(order)
-    assert torch.equal(a.view(torch.int32), a_pw.view(torch.int32))
-    enc_pw.close()
+    if TUNING_BUILD:
+        enc_pw = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_lds")
+        a_pw = EncoderSource(enc_pw, collection, 0, packed=True).encode_pids(order)
+        assert torch.equal(a.view(torch.int32), a_pw.view(torch.int32))
+        enc_pw.close()
     # the host entry point (clb_encode_docs: what the Julia shim calls) packs by itself -- also a mask with holes, whose
     # attended tokens keep their positions; reference: the same call on an encoder that cannot pack (fp32-MFMA attention)
     ref_enc = clb.BertEncoder(w, bcfg, dim=64, tokenizer=tok, config=config, attention="fused_f32")

@@ -155,6 +155,8 @@ def test_nearest_centroid_near_ties_below_the_fp16_product_error(oracle, monkeyp
     (argmax dot, k-means distance), with long, short and (x 1e3 + one component beyond the fp16 range: three products) centroids."""
     monkeypatch.setenv("COLBERT_NEAREST_PRODUCTS", products[0])
     if products.endswith("registers"):
+        if b"tuning build" not in clb.lib().clb_version():
+            pytest.skip("the register-staged list kernel is a comparison kernel: tuning builds of the library only")
         monkeypatch.setenv("COLBERT_NEAREST_STAGING", "registers")
     rng = np.random.default_rng(211)
     K, n = 512, 6000
