@@ -913,52 +913,66 @@ def main():
         # remaining search batches of the group before it.  Latency of a query = from its group's encode entering the stream to
         # the end of its own search batch (HIP events), under this sustained load.
         if world == 1 and not args.no_sub and n_queries >= 256 and B == 32:
-            Be, per = 128, 128 // B
+            Be = 128
             enc_stream = torch.cuda.Stream(device=dev)
             qenc = [torch.empty((Be, T, 128), dtype=torch.float32, device=dev) for _ in range(2)]
-            gate = [None]                 # the first search batch of the previous group has finished: the next encode may start
-            lat = []
 
-            def serve_group(g, record):
-                off = (g * Be) % (n_queries - Be + 1)
-                with torch.cuda.stream(enc_stream):
-                    if gate[0] is not None:
-                        enc_stream.wait_event(gate[0])
-                    t_in = torch.cuda.Event(enable_timing=True)
-                    t_in.record(enc_stream)
-                    enc.query_embeddings_device(d_ids[off:off + Be], d_mask[off:off + Be], d_skip, qenc[g % 2])
-                    encoded = torch.cuda.Event()
-                    encoded.record(enc_stream)
-                for j in range(per):
-                    i = per * g + j
-                    st = compute[i % NF] if overlap[0] else compute[0]
-                    with torch.cuda.stream(st):
-                        st.wait_event(encoded)
-                        plan.step_on_current_stream(i, plan.queries(i))
-                        t_out = torch.cuda.Event(enable_timing=True)
-                        t_out.record(st)
-                        if j == 0:
-                            gate[0] = t_out
-                        if record:
-                            lat.append((t_in, t_out))
+            def serve(Bs, gated, n_groups):
+                """n_groups groups of Be queries: one encode each, Be / Bs search batches; -> (seconds, per-batch latencies in ms)"""
+                pl = plan if Bs == B else Plan(Bs, False)
+                per = Be // Bs
+                gate = [None]             # the first search batch of the previous group has finished: the next encode may start
+                lat = []
 
-            for g in range(2):
-                serve_group(g, False)
-            barrier()
+                def group(g, record):
+                    off = (g * Be) % (n_queries - Be + 1)
+                    with torch.cuda.stream(enc_stream):
+                        if gated and gate[0] is not None:
+                            enc_stream.wait_event(gate[0])
+                        t_in = torch.cuda.Event(enable_timing=True)
+                        t_in.record(enc_stream)
+                        enc.query_embeddings_device(d_ids[off:off + Be], d_mask[off:off + Be], d_skip, qenc[g % 2])
+                        encoded = torch.cuda.Event()
+                        encoded.record(enc_stream)
+                    for j in range(per):
+                        i = per * g + j
+                        st = compute[i % NF] if overlap[0] else compute[0]
+                        with torch.cuda.stream(st):
+                            st.wait_event(encoded)
+                            pl.step_on_current_stream(i, pl.queries(i))
+                            t_out = torch.cuda.Event(enable_timing=True)
+                            t_out.record(st)
+                            if j == 0:
+                                gate[0] = t_out
+                            if record:
+                                lat.append((t_in, t_out))
+                for g in range(2):
+                    group(g, False)
+                barrier()
+                t0 = time.perf_counter()
+                for g in range(n_groups):
+                    group(2 + g, True)
+                barrier()
+                dts = time.perf_counter() - t0
+                return dts, np.array([a.elapsed_time(b_) for a, b_ in lat])
+
             n_groups = max(args.steps // 2, 8)
-            t0 = time.perf_counter()
-            for g in range(n_groups):
-                serve_group(2 + g, True)
-            barrier()
-            dts = time.perf_counter() - t0
-            lat_ms = np.array([a.elapsed_time(b_) for a, b_ in lat])
+            shapes = {}
+            for Bs, gated in ((32, True), (32, False), (64, True), (64, False)):
+                if Bs > n_queries // 4:
+                    continue
+                dts, lat_ms = serve(Bs, gated, n_groups)
+                shapes[f"search_batch_{Bs}_{'gated' if gated else 'free'}"] = {
+                    "value": round(Be * n_groups / dts, 2), "ms_per_group": round(dts / n_groups * 1e3, 4),
+                    "latency_ms_per_query": {"p50": round(float(np.quantile(lat_ms, 0.5)), 4), "p99": round(float(np.quantile(lat_ms, 0.99)), 4)}}
+            main_shape = shapes["search_batch_32_gated"]
             e2e["serving_shape"] = {
-                "value": round(Be * n_groups / dts, 2), "unit": "queries/s", "queries_per_encode": Be, "queries_per_search_batch": B,
-                "groups": n_groups, "ms_per_group": round(dts / n_groups * 1e3, 4),
-                "latency_ms_per_query": {"p50": round(float(np.quantile(lat_ms, 0.5)), 4), "p99": round(float(np.quantile(lat_ms, 0.99)), 4),
-                                         "max": round(float(lat_ms.max()), 4),
-                                         "note": "encode of the query's 128-group entering its stream -> end of the query's own 32-query search "
-                                                 "batch, HIP events, under sustained load (groups enqueued back to back)"}}
+                "value": main_shape["value"], "unit": "queries/s", "queries_per_encode": Be, "queries_per_search_batch": B,
+                "groups": n_groups, "ms_per_group": main_shape["ms_per_group"], "latency_ms_per_query": main_shape["latency_ms_per_query"],
+                "variants": shapes,
+                "note": "value: one encode of 128 queries, four 32-query search batches behind it, the next encode gated on the first of them; "
+                        "latency = the group's encode entering its stream -> end of the query's own search batch (HIP events) under sustained "
+                        "load, groups enqueued back to back; variants: 64-query search batches / the next encode not gated"}
             del qenc
         # the passage side of the same encoder (what index() spends its time in: 1 M passages = 15 600 such batches): one batch
         # of index_bsize = 64 passages x doc_maxlen = 300 tokens, output left on the device (clb_encode_docs_device)

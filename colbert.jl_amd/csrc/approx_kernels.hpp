@@ -1078,7 +1078,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct StepTag {      // wave-uniform description of a step
     int j;            // candidate slot (ROWS: list position), -1 = dummy
     int rows;         // valid rows (1..32)
-    int last;         // 1 = last step of its passage
+    int last;         // 1 = last step of its passage; 3 = ... which is also the last passage of the wave's 64-passage chunk
     int base;         // index of the step's first embedding inside its passage
 };
 
@@ -1208,6 +1208,14 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
     constexpr int kRingBytes = 3 * kSlotBytes;           // three steps in flight, per wave
     static_assert(GL == 0 || CLB_APPROX_WAVES <= 12, "the 3-slot ring of the LDS-DMA form fits 160 KB of LDS up to 12 waves");
     __shared__ __attribute__((aligned(16))) unsigned char ring_s[GL ? (kApproxThreads / 64) * kRingBytes : 16];
+    // Results of up to 16 consecutive passages of a wave wait here (32 fp16 token maxima + the fp32 score each) and leave as
+    // TWO full-width stores (round 6).  A wave used to issue a 2-byte-per-lane and a one-lane store at every passage end, inside
+    // a branch: ~0.03 ms of the 0.66-ms pass went into them and into the vector-memory waits they widen (ablation variant 8).
+    // A wave therefore owns a CONTIGUOUS range of candidate slots now (it used to take every stride-th one), so that the
+    // results of consecutive passages are consecutive in memory.
+    constexpr int kStageBytes = 16 * 64 + 64;
+    __shared__ __attribute__((aligned(16))) unsigned char stage_s[ROWS ? 16 : (kApproxThreads / 64) * kStageBytes];
+    unsigned char* mystage = stage_s + (ROWS ? 0 : wave * kStageBytes);
     for (int i = threadIdx.x; i < 256 * 32; i += kApproxThreads) {
         const int v = i >> 5;
         *reinterpret_cast<uint2*>(lut_s + (size_t)i * 8) =
@@ -1285,18 +1293,22 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
         unsigned long long* rmask = ROWS ? rowmask + (size_t)b * cand_cap * 4 : nullptr;
         const float window = ROWS ? 2.f * eps_pair[b] : 0.f;
         const int n = ROWS ? nlist[b] : ncand[b];
-        const int stride = wg_count * (kApproxThreads / 64) * nsub;
+        // this wave's contiguous share of the query's n passages
+        const int n_waves = wg_count * (kApproxThreads / 64) * nsub;
+        const int my_wave = (sub * wg_count + wg_index) * (kApproxThreads / 64) + wave;
+        const int per_wave = (n + n_waves - 1) / n_waves;
+        const int j_first = min(n, my_wave * per_wave), j_end = min(n, j_first + per_wave);
         unsigned long long wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;   // ROWS: the current passage's mask (wave-uniform)
 
-        // ---- wave-uniform iterator over the steps of passages j0, j0+stride, ... ------------------------------
+        // ---- wave-uniform iterator over the steps of passages j0, j0 + 1, ... ---------------------------------
         // The headers {first embedding, length} of the wave's next 64 passages sit in one VGPR pair (lane k =
         // k-th passage) and are extracted with v_readlane: no memory wait at a passage switch.
-        for (int j0 = (sub * wg_count + wg_index) * (kApproxThreads / 64) + wave; j0 < n; j0 += 64 * stride) {
-        const int jl = j0 + lane * stride;
-        int slot_l = jl < n ? jl : j0;                       // candidate slot of this lane's passage
+        for (int j0 = j_first; j0 < j_end; j0 += 64) {
+        const int jl = j0 + lane;
+        int slot_l = jl < j_end ? jl : j0;                   // candidate slot of this lane's passage
         if (ROWS) slot_l = lst[slot_l];
         const uint2 hv = hdr[slot_l];
-        const int nd = (n - j0 + stride - 1) / stride < 64 ? (n - j0 + stride - 1) / stride : 64;   // passages here
+        const int nd = j_end - j0 < 64 ? j_end - j0 : 64;    // passages here
         int it_k = 0;
         uint32_t it_off = __builtin_amdgcn_readlane(hv.x, 0);
         int it_len = (int)__builtin_amdgcn_readlane(hv.y, 0);
@@ -1324,9 +1336,9 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
         if (ABL == 7) CV = (e0 * 97u + rr) & 131071u;                                                       \
         else if (ABL == 4) CV = cbase_[rr];                                                                 \
         else CV = __builtin_nontemporal_load(cbase_ + rr);      /* code | quantised inv_norm */              \
-        TAG.j = live ? j0 + it_k * stride : -1;                                                             \
+        TAG.j = live ? j0 + it_k : -1;                                                                      \
         TAG.rows = rows;                                                                                    \
-        TAG.last = left <= kStepRows;                                                                       \
+        TAG.last = left <= kStepRows ? (it_k + 1 >= nd ? 3 : 1) : 0;                                        \
         TAG.base = it_base;                                                                                 \
         it_base += kStepRows;                                                                               \
         if (TAG.last) {                                                                                     \
@@ -1505,9 +1517,21 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void s
                 if (CELL8) mx *= stp;                /* cells -> score units, once per passage and token */    \
                 const float sum = sum_lanes_0_31(r < T ? mx : 0.f);     /* valid in lanes 16..31 */         \
                 if (ABL == 8) { if (sum == 12345.678f) out[0] = mx; }    /* ablation: no result stores */     \
-                else {                                                                                      \
-                if (lane == 16 && TAG.j >= 0) out[TAG.j] = sum;                                             \
-                if (h == 0 && TAG.j >= 0) tmax[(size_t)TAG.j * 32] = (uint16_t)f32_to_f16_floor(mx);       \
+                else if (TAG.j >= 0) {                                                                      \
+                    /* into the wave's staging block: passage p = (j - j0) & 15 of the current group of 16 */ \
+                    const int p_ = (TAG.j - j0) & 15;                                                       \
+                    if (h == 0) *reinterpret_cast<uint16_t*>(mystage + p_ * 64 + 2 * r) = (uint16_t)f32_to_f16_floor(mx); \
+                    if (lane == 16) *reinterpret_cast<float*>(mystage + 1024 + 4 * p_) = sum;               \
+                    if (p_ == 15 || TAG.last == 3) {    /* the group is full, or the chunk ends: p_ + 1 passages leave */ \
+                        const int jb_ = TAG.j - p_;                                                         \
+                        __builtin_amdgcn_wave_barrier();                                                    \
+                        const u32x4 tk_ = *reinterpret_cast<const u32x4*>(mystage + 16 * lane);             \
+                        const float sc_ = *reinterpret_cast<const float*>(mystage + 1024 + 4 * (lane & 15)); \
+                        if (lane < 4 * (p_ + 1))                                                            \
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(tokmax + ((size_t)b * cand_cap + jb_) * 32) + 16 * lane) = tk_; \
+                        if (lane <= p_) out[jb_ + lane] = sc_;                                              \
+                        __builtin_amdgcn_wave_barrier();                                                    \
+                    }                                                                                       \
                 }                                                                                           \
                 mx = kNegInf;                                                                               \
             }                                                                                               \

@@ -840,8 +840,18 @@ const char* clb_last_error(void) { return clb::last_error().c_str(); }
 // loads, grid-stride over one resident round of work-groups), `reps` times between two HIP events after one untimed pass.
 // bench.py quotes pass 1's achieved bandwidth against it next to the 8 TB/s of the data sheet.
 static __global__ __launch_bounds__(256) void copy_rate_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
-        dst[i] = __builtin_nontemporal_load(src + i);
+    // four 16-byte loads in flight per lane, non-temporal both ways (nothing is read twice)
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s) {
     if (!gb_per_s || bytes < 4096 || reps < 1) return fail(CLB_EARGUMENT, "copy rate: bytes >= 4096, reps >= 1, a result pointer");
