@@ -123,7 +123,7 @@ def roofline_of(kname, prof, stats, mode, T, K, B, copy_gbs=None):
              "frac": round(ach / HBM_PEAK_GBS, 4)}
         if copy_gbs:
             r["measured_copy_rate"] = copy_gbs
-            r["measured_copy_rate_how"] = "clb_measure_copy_rate in this run: 5 x 1 GB device-to-device, 16 B per lane, HIP events"
+            r["measured_copy_rate_how"] = "clb_measure_copy_rate in this run: 5 x 1 GB device-to-device between HIP events, best of three 16-B-per-lane kernel forms and hipMemcpyAsync"
             r["frac_of_measured_copy_rate"] = round(ach / copy_gbs, 4)
         r["guide_copy_rate"] = GUIDE_COPY_GBS
     r["ms_per_launch"] = round(ms_launch, 4)

@@ -1130,6 +1130,12 @@ constexpr bool kSplitLut = false;
 #define CLB_APPROX_PRIO_UP
 #define CLB_APPROX_PRIO_DOWN
 #endif
+// waves per SIMD the register budget is set for: the work-group's own by default; an experiment build may ask for more than its
+// waves need (make SUF=_w8 EXTRA='-DCLB_APPROX_WAVES=8 -DCLB_APPROX_MINOCC=3': two waves per SIMD within the registers of three,
+// which leaves a third of every SIMD's register file to the kernels of the OTHER batch in flight)
+#ifndef CLB_APPROX_MINOCC
+#define CLB_APPROX_MINOCC (CLB_APPROX_WAVES / 4)
+#endif
 constexpr int kApproxThreads = 64 * CLB_APPROX_WAVES;   // 12 waves per work-group = 3 per SIMD, one work-group per CU
 constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slots x 8 B
 
@@ -1182,7 +1188,7 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // is applied once per passage (the row sweep applies it per value: the same product for the row that holds the maximum).
 // GL = 1: two adjacent lanes fetch a row -- ONE DMA instruction per step, a 1-KB ring slot, vmcnt(3).
 template <bool ROWS, int ABL = 0, int GL = 0, int PIPE = 0, bool CELL8 = false>
-static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_WAVES / 4) void score_approx32_kernel(
+static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_MINOCC) void score_approx32_kernel(
     const float* __restrict__ weights, const uint32_t* __restrict__ codeinv, const uint8_t* __restrict__ residuals,
     int cbits, float inv_lo, float inv_step, const float* __restrict__ Q, const uint32_t* __restrict__ cells16,
     const uint2* __restrict__ cand_hdr, const int* __restrict__ ncand, float* __restrict__ scores, int K, int T,

@@ -376,7 +376,16 @@ void linear_planes(clb_encoder* e, hipStream_t st, int role, const uint16_t* Ap,
         {
             const bool wide = NS == 2 && N % 4 == 0 && !(epi & EPI_GELU) && !planes_first_form();
             c = pick_long_tile(M, N, wide && !att, wide);
+            // round 6 (profiles/r06_encoder_plan_n128.txt, 128 queries = 4 096 rows): the Q/K/V projection of a few thousand rows
+            // is 576 tiles of 128 x 128 -- two work-groups per CU take them in 1.1 rounds whose tail costs half a round, where
+            // the 288 tiles of 128 x 256 the rule above picks take two full ones (0.85 against 1.02 ms over the 12 layers)
+            if (att && wgs(128, 128) < 1024) c = PlanCfg{128, 128, 2, 1};
         }
+    else if (part && wgs(128, 128) >= 128 && K % 64 == 0 && K / 2 >= 384)
+        // ... and its hidden-wide outputs (attention output, FFN-out: 192 tiles of 128 x 128 at 4 096 rows) fill the chip as
+        // 128 x 128 tiles over TWO K slices, the reduction fused into the LayerNorm pass that follows
+        // (gemm_splitk_reduce_ln4_kernel): 0.47 / 0.99 ms against 0.58 / 1.26 with the 64 x 64 tiles of the query-batch rule
+        c = PlanCfg{128, 128, 2, 2};
     else {
         // A query batch (M ~ 1 000): 64 x 64 tiles with a two-tile ring = 48 KB of LDS, three work-groups per CU.  Measured
         // (tools/microbench/gemm_planes_bench.hip): the loop is bound by MFMA issue (three 32 x 32 tiles per SIMD at the

@@ -40,8 +40,8 @@ const char* clb_version(void);
 const char* clb_last_error(void);
 /* number of visible HIP devices (0 without a GPU); never initialises a device */
 int clb_device_count(void);
-/* The copy rate of `device` right now: `reps` device-to-device copies of `bytes` by a 16-bytes-per-lane kernel between two HIP
- * events; *gb_per_s = (bytes read + bytes written) / time.  Measurement support for the roofline record of bench.py
+/* The copy rate of `device` right now: `reps` device-to-device copies of `bytes` between two HIP events, by three forms of a
+ * 16-bytes-per-lane kernel and by hipMemcpyAsync; *gb_per_s = (bytes read + bytes written) / time of the fastest.  Measurement support for the roofline record of bench.py
  * ("HBM 8.0 TB/s spec, 6.29 TB/s measured copy; re-measure on the box"); no counterpart in the reference. */
 int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s);
 

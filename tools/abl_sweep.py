@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--tag", default="", help="copied into every row (workload label)")
     ap.add_argument("--cell-range", action="store_true", help="print the half step of an 8-bit linear score table for this batch")
     ap.add_argument("--stats", action="store_true", help="add candidate / re-scored counts per query to every row")
+    ap.add_argument("--warm-seconds", type=float, default=1.0, help="untimed batches before the first setting (profiling runs: keep it short)")
     args = ap.parse_args()
     import torch
     import colbert_jl_amd as clb
@@ -74,7 +75,7 @@ def main():
     # the first measurement of a process used to come out ~8 % slow (0.72 against 0.665 ms for the same pass 1: the device
     # has just spent seconds in host-side index generation and idles at a low clock): one second of untimed batches first
     import time
-    t_end = time.time() + 1.0
+    t_end = time.time() + args.warm_seconds
     while time.time() < t_end:
         for i in range(8):
             run(Qdev[i * B:(i + 1) * B])
