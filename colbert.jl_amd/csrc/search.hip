@@ -826,21 +826,6 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     return CLB_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-#ifdef CLB_ABLATIONS
-const char* clb_version(void) { return "colbert_hip 0.1 (gfx950, tuning build: ablation variants and comparison kernels)"; }
-#else
-const char* clb_version(void) { return "colbert_hip 0.1 (gfx950)"; }
-#endif
-const char* clb_last_error(void) { return clb::last_error().c_str(); }
-// What a plain stream reaches on THIS device at THIS moment: device-to-device copies of `bytes`, `reps` times between two HIP
-// events after one untimed pass, by three forms of a 16-bytes-per-lane grid-stride kernel (FORM 0: non-temporal loads, plain
-// stores, one piece per lane and iteration; 1: plain loads and stores, four pieces in flight; 2: non-temporal both ways, four in
-// flight) and by the runtime's own hipMemcpyAsync -- the best of the four is reported (which one wins differs from box to box).
-// bench.py quotes pass 1's achieved bandwidth against it next to the 8 TB/s of the data sheet (SURVEY.md 8d).
 template <int FORM>
 static __global__ __launch_bounds__(256) void copy_rate_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;
@@ -864,6 +849,21 @@ static __global__ __launch_bounds__(256) void copy_rate_kernel(const u32x4* __re
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
+}  // namespace
+
+extern "C" {
+
+#ifdef CLB_ABLATIONS
+const char* clb_version(void) { return "colbert_hip 0.1 (gfx950, tuning build: ablation variants and comparison kernels)"; }
+#else
+const char* clb_version(void) { return "colbert_hip 0.1 (gfx950)"; }
+#endif
+const char* clb_last_error(void) { return clb::last_error().c_str(); }
+// What a plain stream reaches on THIS device at THIS moment: device-to-device copies of `bytes`, `reps` times between two HIP
+// events after one untimed pass, by three forms of a 16-bytes-per-lane grid-stride kernel (FORM 0: non-temporal loads, plain
+// stores, one piece per lane and iteration; 1: plain loads and stores, four pieces in flight; 2: non-temporal both ways, four in
+// flight) and by the runtime's own hipMemcpyAsync -- the best of the four is reported (which one wins differs from box to box).
+// bench.py quotes pass 1's achieved bandwidth against it next to the 8 TB/s of the data sheet (SURVEY.md 8d).
 int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s) {
     if (!gb_per_s || bytes < 4096 || reps < 1) return fail(CLB_EARGUMENT, "copy rate: bytes >= 4096, reps >= 1, a result pointer");
     CLB_TRY(use_device(device));
