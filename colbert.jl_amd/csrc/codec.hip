@@ -804,6 +804,52 @@ int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64
     return CLB_OK;
 }
 
+// Test hooks of the hand-written sort and scan (csrc/sort.hip): host arrays in, host arrays out.  key_bits = 32: uint32 keys
+// sorted on their low `end_bit` bits; 64: uint64 keys on all bits; -32: float keys (ascending, -0.0 < +0.0).  vals may be null.
+int clb_debug_sort(int device, int key_bits, const void* keys, const uint32_t* vals, int64_t n, int end_bit, void* keys_out,
+                   uint32_t* vals_out) {
+    if (n < 0 || (n > 0 && (!keys || !keys_out)) || (vals && !vals_out)) return fail(CLB_EARGUMENT, "clb_debug_sort: null argument or negative n");
+    if (key_bits != 32 && key_bits != 64 && key_bits != -32) return fail(CLB_EARGUMENT, "clb_debug_sort: key_bits must be 32, 64 or -32 (float)");
+    CLB_TRY(use_device(device));
+    if (n == 0) return CLB_OK;
+    Stream s; CLB_TRY(s.init());
+    const size_t kb = key_bits == 64 ? 8 : 4;
+    DevBuf dk, dko, dv, dvo;
+    CLB_TRY(upload(dk, keys, kb * n, s.st));
+    CLB_TRY(dko.alloc(kb * n));
+    if (vals) { CLB_TRY(upload(dv, vals, 4 * (size_t)n, s.st)); CLB_TRY(dvo.alloc(4 * (size_t)n)); }
+    if (key_bits == -32) {
+        if (vals) return fail(CLB_EUNSUPPORTED, "clb_debug_sort: float keys sort without values");
+        CLB_TRY(sort_keys_f32(dk.as<float>(), dko.as<float>(), (size_t)n, s.st));
+    } else if (key_bits == 32) {
+        if (!vals) return fail(CLB_EUNSUPPORTED, "clb_debug_sort: uint32 keys sort as pairs");
+        CLB_TRY(sort_pairs_u32(dk.as<uint32_t>(), dko.as<uint32_t>(), dv.as<uint32_t>(), dvo.as<uint32_t>(), (size_t)n, end_bit, s.st));
+    } else if (vals) {
+        CLB_TRY(sort_pairs_u64(dk.as<uint64_t>(), dko.as<uint64_t>(), dv.as<uint32_t>(), dvo.as<uint32_t>(), (size_t)n, s.st));
+    } else {
+        CLB_TRY(sort_keys_u64(dk.as<uint64_t>(), dko.as<uint64_t>(), (size_t)n, s.st));
+    }
+    CLB_HIP(hipMemcpyAsync(keys_out, dko.p, kb * n, hipMemcpyDeviceToHost, s.st));
+    if (vals) CLB_HIP(hipMemcpyAsync(vals_out, dvo.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+// out[0 .. n] = exclusive prefix sums of in[0 .. n) (out[n] = the total, modulo 2^32)
+int clb_debug_exclusive_scan(int device, const uint32_t* in, int64_t n, uint32_t* out) {
+    if (n < 0 || !out || (n > 0 && !in)) return fail(CLB_EARGUMENT, "clb_debug_exclusive_scan: null argument or negative n");
+    CLB_TRY(use_device(device));
+    Stream s; CLB_TRY(s.init());
+    DevBuf di, dout;
+    CLB_TRY(di.alloc(4 * (size_t)(n + 1)));
+    CLB_HIP(hipMemsetAsync(di.p, 0, 4 * (size_t)(n + 1), s.st));
+    if (n > 0) CLB_HIP(hipMemcpyAsync(di.p, in, 4 * (size_t)n, hipMemcpyHostToDevice, s.st));
+    CLB_TRY(dout.alloc(4 * (size_t)(n + 1)));
+    CLB_TRY(exclusive_scan_u32(di.as<uint32_t>(), dout.as<uint32_t>(), (size_t)n, s.st));
+    CLB_HIP(hipMemcpyAsync(out, dout.p, 4 * (size_t)(n + 1), hipMemcpyDeviceToHost, s.st));
+    CLB_HIP(hipStreamSynchronize(s.st));
+    return CLB_OK;
+}
+
 int clb_build_ivf_device(int device, const uint32_t* d_codes, int64_t n, int64_t K, int64_t* d_ivf,
                          int64_t* d_ivf_lengths, void* hip_stream) {
     if (K < 0 || n < 0) return fail(CLB_EARGUMENT, "negative size");

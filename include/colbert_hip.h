@@ -276,6 +276,14 @@ int clb_compute_avg_residuals(int device, int nbits, const float* centroids, int
 /* _build_ivf  (collection_indexer.jl:349-353) */
 int clb_build_ivf(int device, const uint32_t* codes, int64_t n, int64_t K, int64_t* ivf,
                   int64_t* ivf_lengths);
+/* Test hooks of the library's own stable radix sort and exclusive scan (csrc/sort.hip: the `sortperm(codes)` of
+ * collection_indexer.jl:350, the quantile sort of :147-150, the load-time re-ordering of the Searcher, the general top-k):
+ * host arrays in and out.  key_bits 32 = uint32 keys sorted stably on their low end_bit bits WITH uint32 values; 64 = uint64
+ * keys, with or without values; -32 = float keys, ascending.  clb_debug_exclusive_scan: out[0..n] = prefix sums of in[0..n),
+ * out[n] = the total (modulo 2^32). */
+int clb_debug_sort(int device, int key_bits, const void* keys, const uint32_t* vals, int64_t n, int end_bit, void* keys_out,
+                   uint32_t* vals_out);
+int clb_debug_exclusive_scan(int device, const uint32_t* in, int64_t n, uint32_t* out);
 /* The same over device arrays (80 M codes at 1 M passages never visit the host): d_codes UInt32[n] 1-based,
  * d_ivf Int64[n], d_ivf_lengths Int64[K], all on `device`; runs on `hip_stream` and waits for it (the range check of
  * counts(values, K) has to be read back: CLB_EBOUNDS). */

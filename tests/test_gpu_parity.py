@@ -1127,3 +1127,54 @@ def test_search_long_queries_large_nprobe_large_k(oracle):
     Qb = synthetic.make_queries(big, 47, 2)
     check_search(oracle, big, Qb, k=12000, nprobe=64)          # the largest power of two the top-k kernel sorts: 16 384
     check_search(oracle, big, Qb, k=17000, nprobe=128)         # past it: the full stable sort
+
+
+# ---------------------------------------------------------------------------------------------------
+# the library's own radix sort and scan (csrc/sort.hip; rocPRIM until round 5) against numpy's stable sort
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 64, 8191, 8192, 8193, 100_003, 2_500_001])
+def test_radix_sort_is_numpys_stable_sort(n):
+    """Stable LSD radix sort: (key, value) pairs on the low end_bit bits of uint32 keys (what sortperm(codes) needs:
+    collection_indexer.jl:350 -- equal codes keep their embedding order), uint64 pairs and keys, float keys; sizes around the
+    tile edges (8 192 elements per work-group, 2 048 per wave); few distinct keys (long runs of equal digits) and many."""
+    import ctypes as C
+    l = clb.lib()
+    rng = np.random.default_rng(n)
+    for end_bit, hi in ((18, 1 << 18), (32, 1 << 32), (7, 100), (32, 3)):
+        keys = rng.integers(0, hi, size=n, dtype=np.uint64).astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        ko, vo = np.empty_like(keys), np.empty_like(vals)
+        assert l.clb_debug_sort(0, 32, C.c_void_p(keys.ctypes.data), C.c_void_p(vals.ctypes.data), C.c_int64(n), end_bit,
+                                C.c_void_p(ko.ctypes.data), C.c_void_p(vo.ctypes.data)) == 0, l.clb_last_error()
+        order = np.argsort(keys & np.uint32((1 << end_bit) - 1 if end_bit < 32 else 0xffffffff), kind="stable")
+        assert np.array_equal(vo, order.astype(np.uint32)) and np.array_equal(ko, keys[order]), (n, end_bit, hi)
+    k64 = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) if n % 2 else (rng.integers(0, 50, size=n, dtype=np.uint64) << np.uint64(40))
+    vals = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    ko, vo = np.empty_like(k64), np.empty_like(vals)
+    assert l.clb_debug_sort(0, 64, C.c_void_p(k64.ctypes.data), C.c_void_p(vals.ctypes.data), C.c_int64(n), 64,
+                            C.c_void_p(ko.ctypes.data), C.c_void_p(vo.ctypes.data)) == 0, l.clb_last_error()
+    order = np.argsort(k64, kind="stable")
+    assert np.array_equal(ko, k64[order]) and np.array_equal(vo, vals[order])
+    assert l.clb_debug_sort(0, 64, C.c_void_p(k64.ctypes.data), None, C.c_int64(n), 64, C.c_void_p(ko.ctypes.data), None) == 0
+    assert np.array_equal(ko, np.sort(k64))
+    f = rng.normal(size=n).astype(np.float32)
+    f[rng.integers(0, n, size=max(1, n // 50))] = np.float32(0.0)
+    f[rng.integers(0, n, size=max(1, n // 70))] = np.float32(-0.0)
+    if n > 10:
+        f[:3] = [np.float32(np.inf), np.float32(-np.inf), np.float32(1e-42)]          # infinities and a subnormal
+    fo = np.empty_like(f)
+    assert l.clb_debug_sort(0, -32, C.c_void_p(f.ctypes.data), None, C.c_int64(n), 32, C.c_void_p(fo.ctypes.data), None) == 0
+    assert np.array_equal(fo, np.sort(f))                                              # values (-0.0 == 0.0 compare equal)
+    assert np.all((fo[:-1] != fo[1:]) | (np.signbit(fo[:-1]) >= np.signbit(fo[1:])))  # ... and -0.0 in front of +0.0
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, 16383, 16384, 16385, 300_000, 5_000_000])
+def test_exclusive_scan_matches_numpy(n):
+    import ctypes as C
+    l = clb.lib()
+    rng = np.random.default_rng(n + 1)
+    x = rng.integers(0, 1 << 12, size=n, dtype=np.uint64).astype(np.uint32)
+    out = np.empty(n + 1, dtype=np.uint32)
+    assert l.clb_debug_exclusive_scan(0, C.c_void_p(x.ctypes.data) if n else None, C.c_int64(n), C.c_void_p(out.ctypes.data)) == 0, l.clb_last_error()
+    want = (np.concatenate([np.zeros(1, np.uint64), np.cumsum(x.astype(np.uint64))]) & np.uint64(0xffffffff)).astype(np.uint32)
+    assert np.array_equal(out, want)
