@@ -28,14 +28,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GUIDE_COPY_GBS = 6290.0      # ... and the copy rate the guide quotes for this part; the line carries the rate MEASURED in the run
+MEASURED_READ = {}           # device -> GB/s of a read-only sweep over 1 GB (measured_read_rate), filled beside MEASURED_COPY
 MEASURED_COPY = {}           # device -> GB/s of a 1-GB device-to-device copy kernel, measured once per process (measured_copy_rate)
 
 
 def measured_copy_rate(clb, device):
     """GB/s of clb_measure_copy_rate on this device: five 1-GB copies between two HIP events, once per run (~2 ms of copies)."""
     if device not in MEASURED_COPY:
-        from colbert_jl_amd._lib import measure_copy_rate
+        from colbert_jl_amd._lib import measure_copy_rate, measure_read_rate
         MEASURED_COPY[device] = round(measure_copy_rate(device, 1 << 30, 5), 1)
+        MEASURED_READ[device] = round(measure_read_rate(device, 1 << 30, 5), 1)
     return MEASURED_COPY[device]
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak
@@ -125,6 +127,9 @@ def roofline_of(kname, prof, stats, mode, T, K, B, copy_gbs=None):
             r["measured_copy_rate"] = copy_gbs
             r["measured_copy_rate_how"] = "clb_measure_copy_rate in this run: 5 x 1 GB device-to-device between HIP events, best of three 16-B-per-lane kernel forms and hipMemcpyAsync"
             r["frac_of_measured_copy_rate"] = round(ach / copy_gbs, 4)
+            rd = next(iter(MEASURED_READ.values()), None) if len(MEASURED_READ) == 1 else None
+            if rd:
+                r["measured_read_rate"] = rd
         r["guide_copy_rate"] = GUIDE_COPY_GBS
     r["ms_per_launch"] = round(ms_launch, 4)
     r["units_per_launch"] = {"embeddings": int(embs), "passages": int(docs)}
@@ -155,6 +160,12 @@ def traffic_from_pmc(pmc_file, dom, stats, roof):
         roof["traffic"] = pmc["hbm_read_bytes"] + pmc.get("hbm_write_bytes", 0)
     roof["traffic_source"] = (f"{os.path.relpath(pmc_file, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "workload; " + pmc_all.get("correction", ""))
+    if roof.get("traffic") and roof.get("measured_read_rate"):
+        # what the kernel REALLY moves per second (PMC bytes per launch over the HIP-event time of this run) against the read rate
+        # measured in this run: how close the pass is to the memory system's own ceiling, wasted re-reads included
+        tr = roof["traffic"] / (roof["ms_per_launch"] * 1e-3) / 1e9
+        roof["traffic_rate_GBps"] = round(tr, 1)
+        roof["traffic_frac_of_measured_read_rate"] = round(tr / roof["measured_read_rate"], 4)
 
 
 def measure_sub(torch, clb, s, index, Q, B, k, nprobe, steps, min_seconds, cpu_queries, dev, in_flight=2, T=32, pmc_key=None):

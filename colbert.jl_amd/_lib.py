@@ -104,6 +104,13 @@ def measure_copy_rate(device: int = 0, nbytes: int = 1 << 30, reps: int = 5) -> 
     return float(out.value)
 
 
+def measure_read_rate(device: int = 0, nbytes: int = 1 << 30, reps: int = 5) -> float:
+    """GB/s of a read-only sweep over `nbytes` on `device`, now (clb_measure_read_rate)."""
+    out = C.c_double(0.0)
+    check(lib().clb_measure_read_rate(C.c_int(device), C.c_int64(nbytes), C.c_int(reps), C.byref(out)))
+    return float(out.value)
+
+
 def check(rc: int) -> None:
     if rc != 0:
         msg = lib().clb_last_error().decode(errors="replace")

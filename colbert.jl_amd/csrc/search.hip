@@ -826,29 +826,6 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
     return CLB_OK;
 }
 
-template <int FORM>
-static __global__ __launch_bounds__(256) void copy_rate_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (FORM == 0) {
-        for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
-        return;
-    }
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        u32x4 a, b, c, d;
-        if (FORM == 1) { a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride]; }
-        else {
-            a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + stride);
-            c = __builtin_nontemporal_load(src + i + 2 * stride); d = __builtin_nontemporal_load(src + i + 3 * stride);
-        }
-        if (FORM == 1) { dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d; }
-        else {
-            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-            __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
-        }
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
-}
 }  // namespace
 
 extern "C" {
@@ -859,49 +836,6 @@ const char* clb_version(void) { return "colbert_hip 0.1 (gfx950, tuning build: a
 const char* clb_version(void) { return "colbert_hip 0.1 (gfx950)"; }
 #endif
 const char* clb_last_error(void) { return clb::last_error().c_str(); }
-// What a plain stream reaches on THIS device at THIS moment: device-to-device copies of `bytes`, `reps` times between two HIP
-// events after one untimed pass, by three forms of a 16-bytes-per-lane grid-stride kernel (FORM 0: non-temporal loads, plain
-// stores, one piece per lane and iteration; 1: plain loads and stores, four pieces in flight; 2: non-temporal both ways, four in
-// flight) and by the runtime's own hipMemcpyAsync -- the best of the four is reported (which one wins differs from box to box).
-// bench.py quotes pass 1's achieved bandwidth against it next to the 8 TB/s of the data sheet.
-int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s) {
-    if (!gb_per_s || bytes < 4096 || reps < 1) return fail(CLB_EARGUMENT, "copy rate: bytes >= 4096, reps >= 1, a result pointer");
-    CLB_TRY(use_device(device));
-    const size_t n16 = (size_t)bytes / 16;
-    DevBuf a, b;
-    CLB_TRY(a.alloc(n16 * 16));
-    CLB_TRY(b.alloc(n16 * 16));
-    CLB_HIP(hipMemset(a.p, 0x5a, n16 * 16));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    CLB_HIP(hipEventCreate(&e0));
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(CLB_EHIP, "hipEventCreate failed"); }
-    const dim3 grid(256 * 8);      // eight work-groups per CU
-    const u32x4* src = a.as<u32x4>();
-    u32x4* dst = b.as<u32x4>();
-    auto once = [&](int form) {
-        if (form == 0) hipLaunchKernelGGL(copy_rate_kernel<0>, grid, dim3(256), 0, nullptr, src, dst, n16);
-        else if (form == 1) hipLaunchKernelGGL(copy_rate_kernel<1>, grid, dim3(256), 0, nullptr, src, dst, n16);
-        else if (form == 2) hipLaunchKernelGGL(copy_rate_kernel<2>, grid, dim3(256), 0, nullptr, src, dst, n16);
-        else (void)hipMemcpyAsync(b.p, a.p, n16 * 16, hipMemcpyDeviceToDevice, nullptr);
-    };
-    double best = 0.0;
-    bool ok = true;
-    for (int form = 0; form < 4 && ok; ++form) {
-        once(form);
-        (void)hipEventRecord(e0, nullptr);
-        for (int r = 0; r < reps; ++r) once(form);
-        (void)hipEventRecord(e1, nullptr);
-        float ms = 0.f;
-        ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && hipGetLastError() == hipSuccess && ms > 0.f;
-        if (ok) best = std::max(best, 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9);      // bytes read + bytes written
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (!ok) return fail(CLB_EHIP, "copy rate: timing failed");
-    *gb_per_s = best;
-    return CLB_OK;
-}
-
 int clb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -44,6 +44,9 @@ int clb_device_count(void);
  * 16-bytes-per-lane kernel and by hipMemcpyAsync; *gb_per_s = (bytes read + bytes written) / time of the fastest.  Measurement support for the roofline record of bench.py
  * ("HBM 8.0 TB/s spec, 6.29 TB/s measured copy; re-measure on the box"); no counterpart in the reference. */
 int clb_measure_copy_rate(int device, int64_t bytes, int reps, double* gb_per_s);
+/* ... and of a kernel that only READS `bytes` (16 bytes per lane, four pieces in flight): *gb_per_s = bytes / time.  Pass 1 of
+ * the search is all reads; bench.py quotes its measured HBM traffic per second against this number. */
+int clb_measure_read_rate(int device, int64_t bytes, int reps, double* gb_per_s);
 
 /* ------------------------------------------------------------------------------------------------
  * Searcher: the resident index  (struct Searcher, src/searching.jl:1-16; Searcher(index_path) :18-80,

@@ -35,6 +35,7 @@ def test_bench_line_has_the_contract_fields():
     if r["bound"] == "hbm":
         assert 1000.0 < r["measured_copy_rate"] < 8000.0 and "clb_measure_copy_rate" in r["measured_copy_rate_how"]
         assert abs(r["frac_of_measured_copy_rate"] - r["achieved"] / r["measured_copy_rate"]) < 1e-3
+        assert 1000.0 < r["measured_read_rate"] < 8000.0
     # the scalars a reader of the first 2 KB of the line needs sit in `config` (the driver's record keeps config, not the sub-records)
     cfgd = d["config"]
     for key in ("batch", "exchange", "p50_latency_ms", "p50_text_to_topk_ms", "end_to_end_with_query_encoder_qps", "end_to_end_serving_shape_qps",

@@ -82,6 +82,7 @@ def test_round3_entry_points_check_their_arguments_first():
     assert l.clb_debug_sort(0, 16, None, None, C.c_int64(4), 32, None, None) == 4          # bad key width / null arrays
     assert l.clb_debug_exclusive_scan(0, None, C.c_int64(-1), None) == 4
     assert l.clb_measure_copy_rate(0, C.c_int64(16), 1, None) == 4
+    assert l.clb_measure_read_rate(0, C.c_int64(16), 1, None) == 4
     assert l.clb_searcher_set_score_rows(null, 1) == 4
     assert l.clb_searcher_get_score_rows(null) == -1
     assert l.clb_searcher_set_centroid_products(null, 1) == 4
