@@ -643,6 +643,11 @@ def main():
     if gather:
         import zlib
         cen = np.ascontiguousarray(shard["centroids"])
+        # COLBERT_BENCH_FAULT (tests/test_gpu_dist_search.py): "centroids:R" makes rank R report a different centroid checksum,
+        # "collective:R" makes its first preflight collective raise -- the run must end at once with the rank's message
+        fault = os.environ.get("COLBERT_BENCH_FAULT", "")
+        if fault == f"centroids:{rank}":
+            cen = cen + np.float32(1.0)
         me = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "backend": backend,
               "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
               "ranks_seen": ranks_seen, "passages": int(shard["doclens"].size), "embeddings": int(shard["codes"].size),
@@ -650,7 +655,11 @@ def main():
               "exchange": "two-phase" if two_phase else "single", "batch": B}
         print("[bench preflight] " + json.dumps(me), file=sys.stderr, flush=True)
         everyone = [None] * world
-        first_contact("all_gather_object of the rank descriptions", lambda: dist.all_gather_object(everyone, me))
+        def gather_descriptions():
+            if fault == f"collective:{rank}":
+                raise RuntimeError("injected fault (COLBERT_BENCH_FAULT)")
+            dist.all_gather_object(everyone, me)
+        first_contact("all_gather_object of the rank descriptions", gather_descriptions)
         problems = []
         if len({e_["centroids_crc32"] for e_ in everyone}) != 1:
             problems.append("the replicated centroids differ between ranks: " + ", ".join(f"rank {e_['rank']}: {e_['centroids_crc32']}" for e_ in everyone))

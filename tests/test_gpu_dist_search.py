@@ -95,3 +95,22 @@ def test_rank_processes_hip_search_both_protocols(oracle, world, k):
                 p, sc = res[r][proto]
                 assert np.array_equal(p[b], rp), (r, proto, b)
                 assert np.array_equal(sc[b].view(np.uint32), rs.view(np.uint32)), (r, proto, b)
+
+
+@pytest.mark.parametrize("fault,code,needle", [("centroids:1", 4, "replicated centroids differ"), ("collective:1", 3, "FAILED: RuntimeError: injected fault")])
+def test_bench_preflight_fails_loudly(fault, code, needle):
+    """bench.py --gpus 2 (two rank processes on one GPU over gloo): a rank whose replicated centroids differ, or whose first
+    preflight collective fails, ends the run before any timing with a non-zero code and a line that names the cause -- no JSON
+    line is printed (a first run on new hardware must cost a minute and say why)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COLBERT_BENCH_BACKEND="gloo", COLBERT_BENCH_DEVICE="0", COLBERT_BENCH_FAULT=fault,
+               COLBERT_BENCH_COLLECTIVE_TIMEOUT_S="60")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--docs", "20000", "--steps", "2", "--warmup", "1",
+                          "--no-encoder", "--no-latency", "--no-cpu", "--no-index-build", "--k", "50"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0, out.stdout[-500:]
+    assert out.stdout.strip() == "", out.stdout[-500:]
+    assert "[bench preflight]" in out.stderr and needle in out.stderr, out.stderr[-1500:]
+    assert f"exited with code {code}" in out.stderr or code in (3, 4), out.stderr[-500:]
