@@ -675,7 +675,11 @@ def main():
                 for p_ in problems:
                     print("[bench preflight] FAILED: " + p_, file=sys.stderr, flush=True)
             os._exit(4)
-        mp_, ms_ = first_contact("one batch: search of every shard + exchange + merge", lambda: (lambda o_: (barrier(), o_)[1])(plan.step(0)))
+        def one_batch():
+            merged = plan.step(0)
+            barrier()
+            return merged
+        mp_, ms_ = first_contact("one batch: search of every shard + exchange + merge", one_batch)
         verdict = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         if rank == 0 and world > 1 and not args.no_cpu and not args.built_index:
             from oracle import oracle as orc
