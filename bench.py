@@ -1174,6 +1174,17 @@ def main():
         roof["all_kernels_ms_per_step"] = {kname: round(v["ms"] / max(prof_steps, 1), 4) for kname, v in prof.items()}
         roof["other_kernels"] = [roofline_of(kn, prof, stats, s.mode, T, K, B, copy_gbs=copy_gbs) for kn in ("score_approx", "score_exact", "centroid_scores")
                                  if kn in prof and kn != dom and prof[kn]["launches"]]
+        # MFMA utilisation of the kernels (north_star: "MFMA utilisation on the scorer against the chip's peak"): cycles the matrix
+        # pipes were busy over the cycles of the launch, from the committed PMC summary of this command (same hash gate as `traffic`)
+        if world == 1 and default_workload and os.path.exists(pmc_file):
+            from tools.pmc_summary import csrc_hash
+            pmc_all = json.load(open(pmc_file))
+            if pmc_all.get("csrc_sha256") == csrc_hash():
+                for rec in [roof] + roof["other_kernels"]:
+                    pk = pmc_all.get("kernels", {}).get(rec["kernel"], {})
+                    if "mfma_pipe_busy_frac" in pk:
+                        rec["mfma_pipe_busy_frac"] = pk["mfma_pipe_busy_frac"]
+                        rec["effective_clock_GHz"] = pk.get("effective_clock_GHz")
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, rank 0, N = 1
     cpu = None

@@ -76,6 +76,11 @@ def main():
             e["hbm_read_bytes"] = int(e["FETCH_SIZE"] * 1024 * 2)
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes"] = int(e["WRITE_SIZE"] * 1024)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+            # cycles the matrix pipes were busy (summed over the 1 024 SIMDs) over the cycles the launch took (GRBM_GUI_ACTIVE is
+            # summed over the 8 XCDs): the MFMA utilisation of the kernel at the clock the chip held during it
+            e["mfma_pipe_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0), 4)
+            e["effective_clock_GHz"] = round(e["GRBM_GUI_ACTIVE"] / 8.0 / (e["pmc_avg_us"] * 1e3), 3) if e.get("pmc_avg_us") else None
         if "trace" in v:
             e["trace"] = v["trace"]
         res[k] = e
