@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--two-phase", action="store_true", help="cut at the global k-th approximate score (exchange precomputed)")
+    ap.add_argument("--score-rows", type=int, default=-1, help="clb_searcher_set_score_rows: 0 fp16 rows, 1 8-bit cells (-1 default)")
     args = ap.parse_args()
     import torch
     import colbert_jl_amd as clb
@@ -25,6 +26,7 @@ def main():
     K = synthetic.num_partitions_for(args.docs, 80.0)
     shard = synthetic.make_index(seed=2024, n_docs=args.docs, K=K, n_blocks=8, blocks=range(0, per))
     s = clb.Searcher(index=shard, device=0, pid_offset=int(shard["pid_offset"]))
+    s.set_score_rows(args.score_rows)
     nb = 6                                                     # distinct batches
     Q = synthetic.make_topic_queries(shard["centroids"], seed=77, n_queries=max(256, nb * B), T=T)
     Qdev = torch.from_numpy(np.ascontiguousarray(Q.transpose(2, 1, 0))).cuda()
@@ -68,7 +70,7 @@ def main():
     torch.cuda.synchronize()
     prof = s.profile_read()
     stats = s.last_batch_stats()
-    print(json.dumps({"world": args.world, "batch": B, "two_phase": bool(args.two_phase), "shard_passages": int(shard["doclens"].size), "ms_per_batch": round(dt * 1e3, 4),
+    print(json.dumps({"world": args.world, "batch": B, "two_phase": bool(args.two_phase), "score_rows": s.score_rows, "shard_passages": int(shard["doclens"].size), "ms_per_batch": round(dt * 1e3, 4),
                       "queries_per_s_per_rank": round(B / dt, 1), "stats": stats,
                       "kernels_ms": {n: round(v["ms"] / max(v["launches"], 1), 4) for n, v in prof.items() if v["launches"]}}))
 
