@@ -636,14 +636,16 @@ def test_bench_sharding_path_matches_unsharded(oracle):
         s.close()
 
 
-@pytest.mark.parametrize("world,k,wide,nq", [(4, 200, -1, 9), (8, 1000, -1, 19), (2, 5000, -1, 9), (4, 200, 1, 19), (2, 5000, 1, 9),
-                                             (2, 300, -1, 32)])
-def test_two_phase_sharded_search(oracle, world, k, wide, nq):
+@pytest.mark.parametrize("world,k,wide,nq,rows", [(4, 200, -1, 9, 0), (8, 1000, -1, 19, 0), (2, 5000, -1, 9, 0), (4, 200, 1, 19, 0), (2, 5000, 1, 9, 0),
+                                                  (2, 300, -1, 32, 0), (8, 1000, -1, 19, 1), (2, 300, 1, 32, 1)])
+def test_two_phase_sharded_search(oracle, world, k, wide, nq, rows):
     """clb_search_shard_phase1/2 on `world` shards of one index (the all-gather is simulated by stacking the shards'
     score blocks): every shard cuts at the global k-th approximate score, the merged result equals the oracle's on
     the full index, and the shards together list far fewer passages than with shard-local thresholds.  k = 5000
     exceeds what some queries can return (padding, tau = -inf).  Batches of 16+ queries on shards that share a bound build
-    their score table from one fp16 product (clb_searcher_set_centroid_products' default on a shard group): nq = 19."""
+    their score table from one fp16 product (clb_searcher_set_centroid_products' default on a shard group): nq = 19.
+    rows = 1 (round 6): the same with the score tables as 8-bit rows on every shard (clb_searcher_set_score_rows, set alike on all
+    shards: the global threshold is cut with a bound that covers every shard's table)."""
     torch = pytest.importorskip("torch")
     from colbert_jl_amd.distributed import DeviceSearch, merge_packed, share_bound_consts
     full = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8)
@@ -656,6 +658,7 @@ def test_two_phase_sharded_search(oracle, world, k, wide, nq):
         sh = synthetic.make_index(seed=2024, n_docs=8000, K=512, n_blocks=8, blocks=range(per * rank, per * rank + per))
         s = clb.Searcher(index=sh, pid_offset=int(sh["pid_offset"]))
         s.set_wide_select(wide)                                          # 1: the sixteen-work-group selection in both phases
+        s.set_score_rows(rows)
         runs.append(DeviceSearch(s, 32, nq, kk, 2)); keep.append(s)
     tops = torch.stack([r.phase1(Qdev).clone() for r in runs])           # (world, B, k) as an all-gather delivers
     torch.cuda.synchronize()
