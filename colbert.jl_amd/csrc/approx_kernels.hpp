@@ -1154,6 +1154,8 @@ constexpr int kApproxLdsLut = 256 * 256;            // 256 entries x 32 lane slo
 // wrong by design): 1 no score-row gather; 2 gather from a 64-KB window of the table (always L2-hot); 3 no residual
 // stream; 4 plain (temporal) stream loads; 5 no LUT expansion / MFMA; 6 v_pk_mul_f32 instead of v_mul_f32; 7 no memory
 // access in the loop at all; 8 no result stores (what the passage-end stores and the waits they widen cost).
+// Round 6: 11 = the walk over the passages in closed form (every passage three steps, no v_readlane header look-ups, a third of
+// the scalar instructions): the most a step-descriptor table read with s_load could save (profiles/r06_experiments.md section 2).
 // Round 5 (profiles/r05_pass1_ablations.jsonl): 10 = the row-mask sweep folded into pass 1 (every step compares its 16 values
 // against the RUNNING per-token maximum and the passage's 256-bit mask is stored at its last step: what that costs the
 // dominant kernel).  (Variant 9 of that round, the timing side of the 8-bit score rows, became CELL8.)
@@ -1320,12 +1322,17 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_MINOCC) void scor
         int it_len = (int)__builtin_amdgcn_readlane(hv.y, 0);
         int it_slot = __builtin_amdgcn_readlane(slot_l, 0);
         int it_base = 0;
+        // ABL 11: every passage of the chunk 82 embeddings long (the headline mean; 3 steps, mean 3.05), their first embeddings evenly
+        // spread over the chunk's real span: the memory pattern of the real walk without its per-passage header look-ups
+        const uint32_t abl_stride = ABL == 11 ? ((uint32_t)__builtin_amdgcn_readlane(hv.x, nd - 1) - it_off) / (uint32_t)nd : 0u;
+        if (ABL == 11) it_len = 82;
+        const uint32_t abl_bound = ABL == 11 ? (uint32_t)__builtin_amdgcn_readlane(hv.x, nd - 1) : 0u;   // (the arrays are padded by a step)
 
         // stage A: residual bytes (16 B / lane), code and inv_norm of the lane's row (dword each), ROWS: stored maximum
 #define CLB_STAGE_A(RB, CV, PM, TAG)                                                                    \
     {                                                                                                       \
         const bool live = it_k < nd;                                                                        \
-        const uint32_t e0 = live ? it_off + (uint32_t)it_base : 0u;                                         \
+        const uint32_t e0 = live ? (ABL == 11 ? min(it_off + (uint32_t)it_base, abl_bound) : it_off + (uint32_t)it_base) : 0u; \
         const int left = live ? it_len - it_base : kStepRows;                                               \
         const int rows = left < kStepRows ? left : kStepRows;                                               \
         if (ROWS) PM = tmax[(size_t)(live ? it_slot : 0) * 32];   /* the passage's stored maximum of token r */ \
@@ -1347,6 +1354,9 @@ static __global__ __launch_bounds__(kApproxThreads, CLB_APPROX_MINOCC) void scor
         TAG.last = left <= kStepRows ? (it_k + 1 >= nd ? 3 : 1) : 0;                                        \
         TAG.base = it_base;                                                                                 \
         it_base += kStepRows;                                                                               \
+        if (ABL == 11) {        /* closed-form walk: no header look-ups (what a step-descriptor table could save at most) */ \
+            if (TAG.last) { it_k += 1; it_off += abl_stride; it_base = 0; }                                 \
+        } else                                                                                              \
         if (TAG.last) {                                                                                     \
             it_k += 1;                                                                                      \
             const int kk = it_k < 64 ? it_k : 63;                                                           \

@@ -739,6 +739,7 @@ int run_search(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ, i
                 case 6: CLB_LAUNCH_APPROX(6); break;
                 case 7: CLB_LAUNCH_APPROX(7); break;
                 case 8: CLB_LAUNCH_APPROX(8); break;
+                case 11: CLB_LAUNCH_APPROX(11); break;
                 case 10:     // the fused row mask writes the slot-indexed row-mask buffer (4 words per candidate slot)
                     hipLaunchKernelGGL((score_approx32_kernel<false, 10>), approx_grid, dim3(kApproxThreads), 0, st, s->weights.as<float>(),
                                        s->codeinv.as<uint32_t>(), s->residuals.as<uint8_t>(), s->cbits, s->inv_lo, s->inv_step, dQ,
