@@ -358,7 +358,8 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* sh /*>=8 int
 // grid = (ceil(nblk / kMarkSliceBlocks), B), block = 1024.
 constexpr int kMarkSliceBlocks = 4;
 constexpr int kMarkSliceBlocksBig = 16;   // with slice_bounds_kernel (shards of more than 16 small slices)
-constexpr int kMarkLists = 32;       // IVF lists in flight per round (one entry per thread and list)
+constexpr int kMarkLists = 64;       // IVF lists per round: 16 threads of the 1 024 walk one list
+constexpr int kMarkDepth = 16;       // entries of its list a thread keeps in flight
 constexpr int kMarkSliceWords = kMarkSliceBlocks * kScanBlock * kWordsPerThread;   // 4096
 
 // SEARCH: shards with more than 16 slices (2 M passages and up).  Re-reading every list in every slice would cost
@@ -404,6 +405,7 @@ static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __re
                                                                  const uint32_t* __restrict__ bounds = nullptr) {
     __shared__ uint32_t lbm[(SB * 1024)];
     __shared__ int cnt[SB];
+    __shared__ uint32_t s_lo[kMarkLists], s_hi[kMarkLists];
     const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < (SB * 1024); i += 1024) lbm[i] = 0u;
     if (tid < SB) cnt[tid] = 0;
@@ -411,37 +413,43 @@ static __global__ __launch_bounds__(1024) void mark_count_kernel(const int* __re
     const int* s = sel + (size_t)b * Tpad * NP;
     const uint32_t p_lo = (uint32_t)slice * (SB * 1024) * 32u, p_n = (uint32_t)(SB * 1024) * 32u;
     const int nl = T * nprobe;
+    // kMarkLists lists per round, 1024 / kMarkLists threads each.  The bounds of the round's lists are fetched ONCE (one thread per
+    // list) and shared through LDS -- every thread used to load all of them itself: 1 536 broadcast loads per wave and round,
+    // two thirds of this kernel's 30 us -- and a thread keeps kMarkDepth entries of its list in flight.
+    constexpr int kPer = 1024 / kMarkLists;
+    const int gl = tid / kPer, sub = tid % kPer;
     for (int l0 = 0; l0 < nl; l0 += kMarkLists) {
-        uint32_t lo[kMarkLists], hi[kMarkLists], pid[kMarkLists];
-        if (SEARCH) {
-            const uint32_t* bq = bounds + ((size_t)b * nl) * (gridDim.x + 1) + slice;      // [query][list][slice boundary]
-#pragma unroll
-            for (int u = 0; u < kMarkLists; ++u) {
-                const int l = l0 + u < nl ? l0 + u : nl - 1;
-                lo[u] = bq[(size_t)l * (gridDim.x + 1)];
-                hi[u] = bq[(size_t)l * (gridDim.x + 1) + 1];
+        if (l0) __syncthreads();                                   // the previous round's bounds have been read
+        if (tid < kMarkLists) {
+            const int l = l0 + tid;
+            uint32_t a = 0u, e = 0u;
+            if (l < nl) {
+                if (SEARCH) {
+                    const uint32_t* bq = bounds + ((size_t)b * nl + l) * (gridDim.x + 1) + slice;   // [query][list][slice boundary]
+                    a = bq[0];
+                    e = bq[1];
+                } else {
+                    const int cid = s[(l / nprobe) * NP + (l % nprobe)];
+                    a = ivf_off[cid];
+                    e = ivf_off[cid + 1];
+                }
             }
-        } else {
+            s_lo[tid] = a;
+            s_hi[tid] = e;
+        }
+        __syncthreads();
+        const uint32_t e = s_hi[gl];
+        for (uint32_t i0 = s_lo[gl] + (uint32_t)sub; i0 < e; i0 += (uint32_t)(kPer * kMarkDepth)) {
+            uint32_t pid[kMarkDepth];
 #pragma unroll
-            for (int u = 0; u < kMarkLists; ++u) {
-                const int l = l0 + u < nl ? l0 + u : nl - 1;            // past the end: the last list again (idempotent)
-                const int cid = s[(l / nprobe) * NP + (l % nprobe)];
-                lo[u] = ivf_off[cid];
-                hi[u] = ivf_off[cid + 1];
+            for (int u = 0; u < kMarkDepth; ++u) {
+                const uint32_t i = i0 + (uint32_t)(u * kPer);
+                pid[u] = i < e ? ivf_pid[i] : 0xffffffffu;
             }
-        }
 #pragma unroll
-        for (int u = 0; u < kMarkLists; ++u) {
-            const uint32_t i = lo[u] + (uint32_t)tid;
-            pid[u] = i < hi[u] ? ivf_pid[i] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int u = 0; u < kMarkLists; ++u) {
-            const uint32_t q = pid[u] - p_lo;                       // 0xffffffff - p_lo >= p_n: never in range
-            if (q < p_n && pid[u] != 0xffffffffu) atomicOr(&lbm[q >> 5], 1u << (q & 31));
-            for (uint32_t i = lo[u] + (uint32_t)tid + 1024u; i < hi[u]; i += 1024u) {      // lists longer than 1024
-                const uint32_t q2 = ivf_pid[i] - p_lo;
-                if (q2 < p_n) atomicOr(&lbm[q2 >> 5], 1u << (q2 & 31));
+            for (int u = 0; u < kMarkDepth; ++u) {
+                const uint32_t q = pid[u] - p_lo;                   // 0xffffffff - p_lo >= p_n: never in range
+                if (q < p_n && pid[u] != 0xffffffffu) atomicOr(&lbm[q >> 5], 1u << (q & 31));
             }
         }
     }
