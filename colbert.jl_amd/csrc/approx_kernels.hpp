@@ -1759,7 +1759,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
                                                                    const float* __restrict__ tau_in = nullptr,
                                                                    int coarse_tau = 0,
                                                                    const float4* __restrict__ tscale = nullptr,
-                                                                   int cell8 = 0) {
+                                                                   int cell8 = 0, int dbg_stop = 0 /* tuning builds: leave after phase N */) {
     __shared__ __attribute__((aligned(16))) int hist[256];
     __shared__ float s_aux[4];
     __shared__ int sh_scan[16];
@@ -1772,12 +1772,10 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     const float* sc = scores + (size_t)b * cand_cap;
     int* lst = list + (size_t)b * cand_cap;
     if (tid == 0) { s_prefix = 0u; s_remaining = n < k ? n : k; s_run = 0; }
-    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux, cell8 != 0);
-    float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
-    const bool unsafe = qb.unsafe;
-    if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
     // thread t owns the contiguous slots [t*chunk, (t+1)*chunk); up to kSelCache order keys stay in registers for the
-    // radix passes and the compaction (the approximate scores are read once)
+    // radix passes and the compaction (the approximate scores are read once).  The loads are issued BEFORE the bound is
+    // computed: they fly during its two barriers.  (Ownership c * 1024 + t -- coalesced loads -- was tried in round 6 and is
+    // SLOWER, 37 against 31 us: every wave then walks all of the query's 4-KB pages.)
     const int chunk = (n + 1023) >> 10;
     const int i0 = tid * chunk;
     const bool cached = chunk <= kSelCache;   // uniform over the block
@@ -1785,6 +1783,20 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
     if (cached) {
 #pragma unroll
         for (int c = 0; c < kSelCache; ++c) ckey[c] = (c < chunk && i0 + c < n) ? f32_order_key(sc[i0 + c]) : 0u;
+    }
+    const QueryBound qb = query_bound(Q, b, T, ac, &s_qn, &s_dq, tscale, s_aux, cell8 != 0);
+    float thr = kNegInf, tau_f = kNegInf, eps = 0.f;
+    const bool unsafe = qb.unsafe;
+    if (tid == 0) eps_pair[b] = unsafe ? __builtin_inff() : kEpsSafety * qb.eps_t;
+    if (kAblations && dbg_stop == 1) return;
+    if (kAblations && dbg_stop == 2) {     // (the keys must be used, or the loads go away)
+        uint32_t x = 0;
+        if (cached) {
+#pragma unroll
+            for (int c = 0; c < kSelCache; ++c) x ^= ckey[c];
+        }
+        if (x == 0x12345u) nlist[b] = 0;
+        return;
     }
 #define CLB_SEL_FOR_EACH(...)                                                                   \
     if (cached) {                                                                               \
@@ -1821,6 +1833,7 @@ static __global__ __launch_bounds__(1024) void select_margin_kernel(const float*
         tau_f = f32_from_order_key(s_prefix);
         thr = tau_f - 2.f * eps;
     }
+    if (kAblations && dbg_stop == 3) { if (tid == 0 && thr == 12345.f) nlist[b] = 0; return; }
     // ordered compaction of the slots with approx >= thr (all of them when n <= k): one block-wide scan of the
     // per-thread counts places every chunk in order
     if (!cached) {

@@ -644,7 +644,8 @@ int launch_select(clb_searcher* s, Workspace& w, hipStream_t st, const float* dQ
         hipLaunchKernelGGL(select_margin_kernel, dim3(B), dim3(1024), 0, st, w.scores.as<float>(), w.ncand.as<int>(), dQ, T, k,
                            w.cand_cap, ac, w.list.as<int>(), w.nlist.as<int>(), w.thresh.as<float>(),
                            w.eps_pair.as<float>(), tau_in, coarse_tau ? 1 : 0,
-                           w.have_range ? (const float4*)w.tscale.as<float4>() : (const float4*)nullptr, w.cell8 ? 1 : 0);
+                           w.have_range ? (const float4*)w.tscale.as<float4>() : (const float4*)nullptr, w.cell8 ? 1 : 0,
+                           CLB_KNOB("CLB_DEBUG_SELECT_STOP", 0));
         return CLB_OK;
     }
     CLB_TRY(w.wsel.ensure(sizeof(WideSel) * B));
