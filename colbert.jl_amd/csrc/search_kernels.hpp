@@ -830,9 +830,10 @@ static __global__ __launch_bounds__(256, 3) void score_exact_kernel(
 // -------------------------------------------------------------------------------------------------
 struct ExactStepTag {
     int slot;   // candidate slot to store the score to, -1 = dummy step
-    int last;   // 1 = last step of its passage
+    int slot1;  // (round 6) the passage that BEGINS inside this step at row p, see below
+    int info;   // bits 0..4: p = 16, or the row at which the wave's next passage starts inside this step (rows [0, p) end passage
+                // `slot`, rows [p, 16) begin passage `slot1`); bit 8: `slot` ends in this step; bit 9: `slot1` ends in it too
 };
-
 // the n-th (0-based) set bit of a 256-bit mask held in four wave-uniform 64-bit words; n < popcount(mask)
 __device__ __forceinline__ uint32_t nth_set_bit_256(unsigned long long w0, unsigned long long w1,
                                                     unsigned long long w2, unsigned long long w3, int n) {
@@ -944,27 +945,72 @@ static __global__ __launch_bounds__(256, 3) void score_exact_flat_kernel(
     }
             CLB_IT_LOAD(0)
 
-            // stage A: describe the next step, request the code and residual of this lane's row
+            // stage A: describe the next step, request the code and residual of this lane's row.
+            // Round 6: a passage's selected rows (26 on average) used to be padded to whole steps of 16 -- a fifth of all row slots held
+            // copies of a last row.  When the current passage has fewer than 16 rows left and the wave has a further passage in this
+            // chunk, the step's remaining row slots [p, 16) now start that passage (at most two passages per step: a next passage
+            // shorter than 16 - p rows is padded with copies of ITS last row and ends in the same step).
 #define CLB_XSTAGE_A(CODE, R0, R1, TAG)                                                                        \
     {                                                                                                          \
         const bool live = it_k < nd;                                                                           \
         const int nj = (int)(it_nj & 0x7fffffffu);                                                             \
-        const int idx = it_base + r < nj ? it_base + r : nj - 1;                                               \
-        const uint32_t row = (it_nj & 0x80000000u) ? (uint32_t)idx : nth_set_bit_256(it_m0, it_m1, it_m2, it_m3, idx); \
-        const uint32_t e = live ? it_off + row : 0u;                                                           \
+        const int rem = nj - it_base;                                                                          \
+        uint32_t e;                                                                                            \
+        if (rem < 16 && it_k + 1 < nd) {     /* (wave-uniform) the boundary step of two passages */             \
+            const int kn = it_k + 1;                                                                           \
+            const uint32_t nx_off = __builtin_amdgcn_readlane(hv.x, kn);                                       \
+            const uint32_t nx_nj = __builtin_amdgcn_readlane(nj_l, kn);                                        \
+            const int nx_slot = __builtin_amdgcn_readlane(slot_l, kn);                                         \
+            const unsigned long long nx_m0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk0 >> 32), kn) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk0, kn); \
+            const unsigned long long nx_m1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk1 >> 32), kn) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk1, kn); \
+            const unsigned long long nx_m2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk2 >> 32), kn) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk2, kn); \
+            const unsigned long long nx_m3 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(mk3 >> 32), kn) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)mk3, kn); \
+            const int njn = (int)(nx_nj & 0x7fffffffu);                                                        \
+            const int take = 16 - rem < njn ? 16 - rem : njn;                                                  \
+            const bool second = r >= rem;            /* this lane's row slot belongs to the next passage */      \
+            const int ia = it_base + r;                                                                        \
+            const int ib = r - rem < njn ? r - rem : njn - 1;                                                  \
+            const int idx = second ? ib : ia;                                                                  \
+            const bool ident = ((second ? nx_nj : it_nj) & 0x80000000u) != 0u;                                 \
+            const uint32_t row = ident ? (uint32_t)idx                                                         \
+                                       : nth_set_bit_256(second ? nx_m0 : it_m0, second ? nx_m1 : it_m1,       \
+                                                         second ? nx_m2 : it_m2, second ? nx_m3 : it_m3, idx); \
+            e = (second ? nx_off : it_off) + row;                                                              \
+            const int last1 = njn <= 16 - rem;                                                                 \
+            TAG.slot = it_slot;                                                                                \
+            TAG.slot1 = nx_slot;                                                                               \
+            TAG.info = rem | 0x100 | (last1 << 9);                                                             \
+            it_k += 1;                                                                                         \
+            if (last1) {                                                                                       \
+                it_k += 1;                                                                                     \
+                const int kk = it_k < 64 ? it_k : 63;                                                          \
+                CLB_IT_LOAD(kk)                                                                                \
+                it_base = 0;                                                                                   \
+            } else {                                                                                           \
+                it_off = nx_off; it_nj = nx_nj; it_slot = nx_slot;                                             \
+                it_m0 = nx_m0; it_m1 = nx_m1; it_m2 = nx_m2; it_m3 = nx_m3;                                    \
+                it_base = take;                                                                                \
+            }                                                                                                  \
+        } else {                                                                                               \
+            const int idx = it_base + r < nj ? it_base + r : nj - 1;                                           \
+            const uint32_t row = (it_nj & 0x80000000u) ? (uint32_t)idx : nth_set_bit_256(it_m0, it_m1, it_m2, it_m3, idx); \
+            e = live ? it_off + row : 0u;                                                                      \
+            const int last = it_base + 16 >= nj;                                                               \
+            TAG.slot = live ? it_slot : -1;                                                                    \
+            TAG.slot1 = -1;                                                                                    \
+            TAG.info = 16 | (last << 8);                                                                       \
+            it_base += 16;                                                                                     \
+            if (last) {                                                                                        \
+                it_k += 1;                                                                                     \
+                const int kk = it_k < 64 ? it_k : 63;                                                          \
+                CLB_IT_LOAD(kk)                                                                                \
+                it_base = 0;                                                                                   \
+            }                                                                                                  \
+        }                                                                                                      \
         CODE = codes0[e];                                                                                      \
         const uint4* rp = reinterpret_cast<const uint4*>(residuals + (size_t)e * 32);                          \
         R0 = rp[0];                                                                                            \
         R1 = rp[1];                                                                                            \
-        TAG.slot = live ? it_slot : -1;                                                                        \
-        TAG.last = it_base + 16 >= nj;                                                                         \
-        it_base += 16;                                                                                         \
-        if (TAG.last) {                                                                                        \
-            it_k += 1;                                                                                         \
-            const int kk = it_k < 64 ? it_k : 63;                                                              \
-            CLB_IT_LOAD(kk)                                                                                    \
-            it_base = 0;                                                                                       \
-        }                                                                                                      \
     }
             // stage C: rows (requested one step ago) -> LDS, decompress, request the next step's rows into the
             // registers just freed, MFMAs
@@ -987,26 +1033,50 @@ static __global__ __launch_bounds__(256, 3) void score_exact_flat_kernel(
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.z, a0, 0, 0, 0);                         \
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2 * k + 1], q.w, a1, 0, 0, 0);                         \
         }                                                                                                      \
-        /* rows past the selection are copies of its last row: they cannot change a max */                    \
-        m0 = fmaxf(fmaxf(m0, fmaxf(a0[0], a0[1])), fmaxf(a0[2], a0[3]));                                       \
-        m1 = fmaxf(fmaxf(m1, fmaxf(a1[0], a1[1])), fmaxf(a1[2], a1[3]));                                       \
-        if (TAG.last) {                                                                                        \
-            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));                                                            \
-            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));                                                            \
-            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64));                                                            \
-            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));                                                            \
-            /* sequential sum over tokens (ranking.jl:83).  The maxima reach the adder through v_readlane (a scalar  */ \
-            /* operand, no LDS round trip as with ds_bpermute: 32 of those per passage were a quarter of the wave's  */ \
-            /* non-MFMA time); tokens past T add +0.0, which leaves a sum that started from +0.0 unchanged            */ \
-            float total = 0.f;                                                                                 \
-            _Pragma("unroll") for (int t = 0; t < 32; ++t) {                                                   \
-                const uint32_t sv = __builtin_amdgcn_readlane(__float_as_uint(t < 16 ? m0 : m1), t & 15);      \
-                total = total + __uint_as_float(t < T ? sv : 0u);                                              \
+        /* rows past the selection are copies of a last row: they cannot change a max.  c0 / c1: the running maxima of the    */ \
+        /* passage rows [0, p) belong to; n0 / n1: those of the passage that begins at row p (accumulator row = 4 g + reg)      */ \
+        float c0, c1, n0 = kNegInf, n1 = kNegInf;                                                              \
+        const int p_ = TAG.info & 31;                                                                          \
+        if (p_ >= 16) {                                                                                        \
+            c0 = fmaxf(fmaxf(m0, fmaxf(a0[0], a0[1])), fmaxf(a0[2], a0[3]));                                   \
+            c1 = fmaxf(fmaxf(m1, fmaxf(a1[0], a1[1])), fmaxf(a1[2], a1[3]));                                   \
+        } else {                                                                                               \
+            c0 = m0;                                                                                           \
+            c1 = m1;                                                                                           \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
+                const bool first_ = 4 * g + q_ < p_;                                                           \
+                c0 = fmaxf(c0, first_ ? a0[q_] : kNegInf);                                                     \
+                c1 = fmaxf(c1, first_ ? a1[q_] : kNegInf);                                                     \
+                n0 = fmaxf(n0, first_ ? kNegInf : a0[q_]);                                                     \
+                n1 = fmaxf(n1, first_ ? kNegInf : a1[q_]);                                                     \
             }                                                                                                  \
-            if (lane == 0 && TAG.slot >= 0) out[TAG.slot] = total;                                             \
-            m0 = kNegInf;                                                                                      \
-            m1 = kNegInf;                                                                                      \
         }                                                                                                      \
+        {                                                                                                      \
+            const int nfin_ = ((TAG.info >> 8) & 1) + ((TAG.info >> 9) & 1);       /* passages that end in this step */ \
+            int cs_ = TAG.slot;                                                                                \
+            _Pragma("unroll 1") for (int f_ = 0; f_ < nfin_; ++f_) {                                           \
+                c0 = fmaxf(c0, __shfl_xor(c0, 16, 64));                                                        \
+                c0 = fmaxf(c0, __shfl_xor(c0, 32, 64));                                                        \
+                c1 = fmaxf(c1, __shfl_xor(c1, 16, 64));                                                        \
+                c1 = fmaxf(c1, __shfl_xor(c1, 32, 64));                                                        \
+                /* sequential sum over tokens (ranking.jl:83).  The maxima reach the adder through v_readlane (a scalar  */ \
+                /* operand, no LDS round trip as with ds_bpermute: 32 of those per passage were a quarter of the wave's  */ \
+                /* non-MFMA time); tokens past T add +0.0, which leaves a sum that started from +0.0 unchanged            */ \
+                float total = 0.f;                                                                             \
+                _Pragma("unroll") for (int t = 0; t < 32; ++t) {                                               \
+                    const uint32_t sv = __builtin_amdgcn_readlane(__float_as_uint(t < 16 ? c0 : c1), t & 15);  \
+                    total = total + __uint_as_float(t < T ? sv : 0u);                                          \
+                }                                                                                              \
+                if (lane == 0 && cs_ >= 0) out[cs_] = total;                                                   \
+                c0 = n0;                                                                                       \
+                c1 = n1;                                                                                       \
+                n0 = kNegInf;                                                                                  \
+                n1 = kNegInf;                                                                                  \
+                cs_ = TAG.slot1;                                                                               \
+            }                                                                                                  \
+        }                                                                                                      \
+        m0 = c0;                                                                                               \
+        m1 = c1;                                                                                               \
     }
 
             float m0 = kNegInf, m1 = kNegInf;
