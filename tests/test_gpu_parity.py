@@ -450,6 +450,30 @@ def test_search_ragged_and_empty_passages(oracle):
     check_search(oracle, idx2, synthetic.make_queries(idx2, 15, 3), k=20)
 
 
+def test_exact_steps_shared_by_consecutive_passages(oracle):
+    """Round 6: the exact kernel starts a wave's next passage in the free row slots of a passage's last 16-row step.  A batch of
+    32 queries with ~1 500 listed passages each gives every wave a dozen passages in a row; the lengths are ragged on purpose
+    (1, 2, ... rows: several passages end inside one step and the second one is padded; 16 / 17 / 32 / 33: a boundary exactly at
+    or next to a step edge; > 256: the identity mapping next to masked neighbours; empty passages in between)."""
+    idx = synthetic.make_index(seed=31, n_docs=3000, K=64, doclen_mean=12, doclen_std=14, doclen_max=400)
+    dl = idx["doclens"].copy()
+    forced = [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 255, 256, 257, 300, 0, 1, 16, 1]
+    rng = np.random.default_rng(32)
+    for j, pid in enumerate(rng.choice(3000, size=20 * len(forced), replace=False)):
+        dl[pid] = forced[j % len(forced)]
+    n_emb = int(dl.sum())
+    if n_emb > idx["codes"].shape[0]:                        # (the forced lengths may ask for more embeddings than were generated)
+        extra = n_emb - idx["codes"].shape[0]
+        idx["codes"] = np.concatenate([idx["codes"], idx["codes"][:extra]])
+        idx["residuals"] = np.asfortranarray(np.concatenate([idx["residuals"], idx["residuals"][:, :extra]], axis=1))
+    idx2 = dict(idx, doclens=dl, codes=idx["codes"][:n_emb], residuals=np.asfortranarray(idx["residuals"][:, :n_emb]))
+    idx2["ivf"], idx2["ivf_lengths"] = synthetic.build_ivf(idx2["codes"], 64)
+    Qs = synthetic.make_queries(idx2, 33, 32)
+    fewest = min(oracle.search(idx2, Qs[:, :, j], nprobe=2, k=1)[2] for j in range(Qs.shape[2]))
+    assert fewest > 600, fewest
+    check_search(oracle, idx2, Qs, k=min(1500, fewest), modes=(1,))
+
+
 def test_search_long_passages(oracle):
     """Passages longer than 256 embeddings do not fit the row mask of the two-pass mode and take every row in the
     exact pass; shorter ones in the same index use the mask.  Both must equal the oracle, in both modes."""
